@@ -1,0 +1,26 @@
+"""Names and settings of the golden variants (shared by the generator and the tests)."""
+from vln_imagine_amd import synth
+from vln_imagine_amd.hamt.config import HamtConfig
+
+HAMT_VARIANTS = {
+    "c1_language": (dict(), dict()),
+    "c1_shipped": (dict(fix_lang_embedding=True, fix_hist_embedding=True, update_lang_bert=False), dict()),
+    "c1_visual": (dict(concat_imagine_with="visual", act_pred_token="ob_txt_hist"), dict()),
+    "c1_ob": (dict(act_pred_token="ob"), dict()),
+    "c1_ob_hist": (dict(act_pred_token="ob_hist"), dict()),
+    "c1_ob_imagine_text": (dict(act_pred_token="ob_imagine_text"), dict()),
+    "c1_infonce": (dict(aux_loss_type="contrastive-InfoNCE"), dict()),
+    "c1_margin": (dict(aux_loss_type="constrastive-margin"), dict()),
+    "c1_encoder": (dict(bypass_imag_encoder=False), dict()),
+    "c1_T3_dense": (dict(), dict(T=3, ragged=False)),
+}
+HAMT_C1 = dict(num_l_layers=2, num_x_layers=2, num_h_pano_layers=2)
+HAMT_EP = dict(tag="golden", B=4, L=80, V=37, I=4, T=2, ragged=True)
+
+
+def hamt_variant_setup(name):
+    over, epkw = HAMT_VARIANTS[name]
+    cfg = HamtConfig(**HAMT_C1, **over)
+    kw = dict(HAMT_EP)
+    kw.update(epkw)
+    return cfg, synth.HamtEpisode(**kw)

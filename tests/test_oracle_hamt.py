@@ -1,0 +1,60 @@
+"""CPU: the HAMT oracle (oracle/hamt_oracle.py) against the golden vectors the reference
+produced (tests/golden/make_golden_hamt.py). This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.hamt_oracle import HamtOracle
+from vln_imagine_amd import synth
+from vln_imagine_amd.hamt.config import HamtConfig
+from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+from vln_imagine_amd.hamt.spec import param_shapes
+
+from tests.golden.variants import HAMT_VARIANTS, hamt_variant_setup
+
+TOL = 2e-5   # oracle vs reference, fp32 CPU both; gate for product is 1e-4
+
+
+def _close(a, b, tol=TOL, what=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    fin = np.isfinite(b)
+    assert (np.isfinite(a) == fin).all(), what
+    assert (a[~fin] == b[~fin]).all(), what
+    err = np.abs(a[fin] - b[fin]).max() if fin.any() else 0.0
+    assert err <= tol * max(1.0, np.abs(b[fin]).max() if fin.any() else 1.0), f"{what}: {err}"
+
+
+@pytest.mark.parametrize("name", list(HAMT_VARIANTS))
+def test_oracle_matches_reference_golden(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"hamt_{name}.npz"))
+    cfg, ep = hamt_variant_setup(name)
+    shapes = param_shapes(cfg)
+    assert set(shapes) == set(g["grad_names"].tolist())          # state_dict ABI
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes.items()).items()}
+    torch.set_num_threads(8)
+    out = run_episode(HamtOracle(cfg, sd), EpisodeTensors(ep), bypass=cfg.bypass_imag_encoder)
+    out["loss"].backward()
+    _close(out["loss"].item(), g["loss"], what="loss")
+    _close(out["aux"].item(), g["aux"], what="aux")
+    _close(out["imagine_embeds"].detach(), g["imagine_embeds"], what="imagine_embeds")
+    _close(out["hist_cls"].detach(), g["hist_cls"], what="hist_cls")
+    for t in range(ep.T):
+        _close(out["logits"][t].detach(), g[f"logits{t}"], what=f"logits{t}")
+        _close(out["states"][t].detach(), g[f"state{t}"], what=f"state{t}")
+        _close(out["hist"][t].detach(), g[f"hist{t}"], what=f"hist{t}")
+        for nm in ("txt_o", "ob_o", "hist_o"):
+            pr = synth.probe(out[nm][t].detach().numpy())
+            _close(pr["samples"], g[f"{nm}{t}.samples"], what=f"{nm}{t}")
+    names = g["grad_names"].tolist()
+    for i, n in enumerate(names):
+        gr = sd[n].grad
+        if g["grad_norms"][i] < 0:
+            assert gr is None or float(gr.abs().max()) == 0.0, n
+            continue
+        assert gr is not None, n
+        ref_norm = g["grad_norms"][i]
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * max(ref_norm, 1e-3), (n, float(gr.double().norm()), ref_norm)
+        head = gr.reshape(-1)[:8].numpy()
+        _close(head, g["grad_heads"][i][:head.size], tol=1e-4, what=f"grad {n}")
