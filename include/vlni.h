@@ -1,0 +1,110 @@
+/* vlni.h -- C-ABI of the MI355X (gfx950) operator library under the HAMT/DUET drop-in modules.
+ *
+ * The reference (akhilperincherry/VLN-Imagine) is pure PyTorch: it has no FFI for this path; the
+ * boundary the drop-in keeps is the Python module API (models.vilmodel_cmt.NavCMT,
+ * models.vilmodel.GlocalTextPathNavCMT, ...). This header is the operator layer those modules call:
+ * plain device pointers + explicit shapes/strides + a hipStream_t (as void*), no torch types, no
+ * allocation inside, no global state except the thread-local error string.
+ * Every function returns 0 (VLNI_OK) or a negative code; the message is vlni_last_error().
+ * Row strides (`ld*`) are in ELEMENTS of the tensor's dtype. dtype: 0 = float32, 1 = bfloat16.
+ * All reductions accumulate in float32. "R:" = VLN-HAMT/finetune_src/models/vilmodel_cmt.py,
+ * "D:" = VLN-DUET/map_nav_src/models/vilmodel.py, "T:" = VLN-DUET/map_nav_src/models/transformer.py.
+ */
+#ifndef VLNI_H
+#define VLNI_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLNI_F32 0
+#define VLNI_BF16 1
+#define VLNI_OK 0
+#define VLNI_EINVAL (-1)
+#define VLNI_ELAUNCH (-2)
+#define VLNI_EUNSUP (-3)
+
+const char* vlni_last_error(void);
+int vlni_version(void);
+
+/* C[M,N] = epi(alpha * A[M,K] * B[N,K]^T): replaces nn.Linear forward (R:101-103,145,174,187,327-329,
+ * 536-537, 956-960; D:598-655 MLP), its dgrad (B = transposed weight shadow) and, with
+ * atomic_f32 + split_k, its wgrad (A = dY^T, B = X^T; C float32, accumulated with atomics).
+ * epi: + bias[N] -> (store preact) -> (* act'(dact_src): 1 gelu', 2 relu') -> act (1 gelu-erf R:27-33,
+ * 2 relu) -> + residual -> C.   K, lda, ldb multiples of 16 bytes; A, B 16-byte aligned. */
+int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                 const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
+                 const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32, void* stream);
+
+/* Fused masked attention, head dim 64, heads packed along the row (head h at column h*64), Sk <= 128.
+ * kmask [B,Sk] additive float32 ((1-m)*-10000, R:1010-1012) or NULL; bias [B,Sq,Sk] additive float32
+ * shared by all heads (graph_sprels, D:1145-1147) or NULL; lse [B,nh,Sq] float32.
+ * Replaces BertSelfAttention.forward R:100-134 and BertOutAttention.forward R:326-353. */
+int vlni_attn_fwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                  const float* kmask, const float* bias, void* out, long ldo, float* lse, int B, int nh, int Sq, int Sk,
+                  float scale, void* stream);
+int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                  const float* kmask, const float* bias, const void* out, long ldo, const void* dout, long lddo,
+                  const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* dbias, int B,
+                  int nh, int Sq, int Sk, float scale, void* stream);
+
+/* LayerNorm over the last dim H in {256,512,768} (BertLayerNorm R:22; eps 1e-12, T:170-182 eps 1e-5).
+ * bwd accumulates (+=) into dgamma/dbeta (float32; both NULL to skip). */
+int vlni_layernorm_fwd(int dtype, const void* x, long ldx, const float* gamma, const float* beta, float eps, void* y,
+                       long ldy, float* mean, float* rstd, int rows, int H, void* stream);
+int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const float* gamma,
+                       const float* mean, const float* rstd, void* dx, long lddx, float* dgamma, float* dbeta, int rows,
+                       int H, void* stream);
+/* y = LayerNorm(sum_k src_k), 1..4 sources, each dense / broadcast row (ld 0) / gathered by int64 row index,
+ * float32 (parameter tables) or activation dtype; xsum (optional) keeps the pre-norm sum for backward.
+ * Replaces BertEmbeddings R:58-73, ImageEmbeddings R:535-544, HistoryEmbeddings R:576-618, D:1087-1131. */
+int vlni_sum_layernorm_fwd(int dtype, int n, const void* const* src, const long* src_ld, const long* const* src_idx,
+                           const int* src_is_f32, const float* gamma, const float* beta, float eps, void* y, long ldy,
+                           void* xsum, long ldxs, float* mean, float* rstd, int rows, int H, void* stream);
+
+int vlni_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n, void* stream);
+/* dst[c][r] = src[r][c] (r < R), zero for R <= r < Rpad: wgrad operands and transposed weight shadows */
+int vlni_transpose(int src_dtype, int dst_dtype, const void* src, long lds, void* dst, long ldd, int R, int C, int Rpad,
+                   void* stream);
+/* out[n] += sum_r x[r][n]: bias gradients */
+int vlni_colsum(int dtype, const void* x, long ldx, int rows, int N, float* out, void* stream);
+/* y = x W^T + b with K <= 16 float32 features (angle 4-d R:537,599; DUET 7-/14-d position D:1093,1140-1150) */
+int vlni_smallk_linear_fwd(int dtype, const float* x, long ldx, const float* W, const float* b, void* y, long ldy, int rows,
+                           int N, int K, void* stream);
+int vlni_smallk_linear_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, float* dW, float* db, int rows,
+                           int N, int K, void* stream);
+/* table_grad[idx[r]] += src[r] (nn.Embedding backward); idx NULL: all rows into row 0 */
+int vlni_scatter_add_rows(int dtype, const void* src, long lds, const long* idx, float* table_grad, int rows, int H,
+                          void* stream);
+/* out[b] = mean_s x[b][s] (torch.mean(pano_embeddings, 1) R:612) */
+int vlni_seqmean_fwd(int dtype, const void* x, void* out, int B, int S, int H, void* stream);
+int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, int B, int S, int H, void* stream);
+/* logits[r] = mask[r] ? -inf : <h[r], w> + bias  (NextActionPrediction.net.4 R:960 + masked_fill_ R:1200) */
+int vlni_rowdot_fwd(int dtype, const void* h, long ldh, const float* w, const float* bias, const unsigned char* mask,
+                    float* out, int rows, int H, void* stream);
+int vlni_rowdot_bwd(int dtype, const float* dl, const void* h, long ldh, const float* w, const unsigned char* mask,
+                    void* dh, long lddh, float* dw, float* dbias, int rows, int H, void* stream);
+/* CrossEntropyLoss(ignore_index, reduction='sum') (r2r/agent_cmt.py:105,547): loss_sum += ..., dlogits = softmax - onehot */
+int vlni_cross_entropy(const float* logits, long ld, const long* target, long ignore_index, float* loss_sum,
+                       float* dlogits, long lddl, int rows, int V, void* stream);
+/* aux head (AlignWithContrastiveLoss R:737-790): noun-phrase token mean (CSR: seg_off[nseg+1], rowidx) ... */
+int vlni_segment_mean_fwd(int dtype, const void* x, long ldx, const int* seg_off, const int* rowidx, void* out, int nseg,
+                          int H, void* stream);
+int vlni_segment_mean_bwd(int dtype, const void* dout, const int* seg_off, const int* rowidx, float* dx32, int nseg, int H,
+                          void* stream);
+/* ... and F.cosine_similarity(eps) per row (R:782) */
+int vlni_cosine_fwd(int dtype, const void* x, const void* y, float eps, float* cosv, float* nx, float* ny, int rows, int H,
+                    void* stream);
+int vlni_cosine_bwd(int dtype, const void* x, const void* y, const float* gcos, const float* cosv, const float* nx,
+                    const float* ny, void* dx, void* dy, int rows, int H, void* stream);
+/* dz = da * act'(z), act 1 gelu-erf / 2 relu (n multiple of 4) */
+int vlni_act_bwd(int dtype, int act, const void* da, const void* z, void* dz, long n, void* stream);
+/* optimizer side of the measured step (r2r/agent_cmt.py:827-832): clip_grad_norm_ + AdamW over a flat arena */
+int vlni_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, const float* clip_coef, void* stream);
+int vlni_sumsq(const float* g, long n, float* sumsq, void* stream);
+int vlni_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,111 @@
+"""GPU parity gate: the HIP NavCMT (fp32 compute) against the reference's golden vectors and against the CPU
+oracle on the same seeded inputs. Tolerance 1e-4 on logits and losses (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.variants import HAMT_VARIANTS, hamt_variant_setup
+from vln_imagine_amd import synth
+from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+from vln_imagine_amd.hamt.spec import param_shapes
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def build_product(cfg, dtype=torch.float32):
+    from vln_imagine_amd.hamt.models.vilmodel_cmt import NavCMT
+    m = NavCMT(cfg)
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()}
+    m.load_state_dict(sd)
+    return m.cuda().eval().set_compute_dtype(dtype)
+
+
+def _close(a, b, tol, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    fin = np.isfinite(b)
+    assert (np.isfinite(a) == fin).all(), what
+    err = np.abs(a[fin] - b[fin]).max() if fin.any() else 0.0
+    assert err <= tol * max(1.0, np.abs(b[fin]).max()), f"{what}: max|d|={err:.3e}"
+    return err
+
+
+@pytest.mark.parametrize("name", list(HAMT_VARIANTS))
+def test_product_fp32_matches_reference_golden(name, golden_dir):
+    from vln_imagine_amd import ops
+    g = np.load(os.path.join(golden_dir, f"hamt_{name}.npz"))
+    cfg, ep = hamt_variant_setup(name)
+    model = build_product(cfg)
+    out = run_episode(model, EpisodeTensors(ep, "cuda"), bypass=cfg.bypass_imag_encoder, criterion=ops.cross_entropy_sum)
+    out["loss"].backward()
+    c = lambda t: t.detach().float().cpu().numpy()
+    _close(out["loss"].item(), g["loss"], TOL, "loss")
+    _close(out["aux"].item(), g["aux"], TOL, "aux")
+    _close(c(out["imagine_embeds"]), g["imagine_embeds"], TOL, "imagine_embeds")
+    _close(c(out["hist_cls"]), g["hist_cls"], TOL, "hist_cls")
+    for t in range(ep.T):
+        _close(c(out["logits"][t]), g[f"logits{t}"], TOL, f"logits{t}")
+        _close(c(out["states"][t]), g[f"state{t}"], TOL, f"state{t}")
+        _close(c(out["hist"][t]), g[f"hist{t}"], TOL, f"hist{t}")
+        for nm in ("txt_o", "ob_o", "hist_o"):
+            _close(synth.probe(c(out[nm][t]))["samples"], g[f"{nm}{t}.samples"], TOL, f"{nm}{t}")
+    params = dict(model.named_parameters())
+    for i, n in enumerate(g["grad_names"].tolist()):
+        gr = params[n].grad
+        ref_norm = g["grad_norms"][i]
+        if ref_norm < 0:
+            assert gr is None or float(gr.abs().max()) == 0.0, n
+            continue
+        assert gr is not None, n
+        nrm = float(gr.double().norm())
+        assert abs(nrm - ref_norm) <= 2e-4 * max(ref_norm, 1e-2), (n, nrm, ref_norm)
+        head = gr.reshape(-1)[:8].cpu().numpy()
+        _close(head, g["grad_heads"][i][:head.size], 2e-4, f"grad {n}")
+
+
+def test_product_fp32_matches_oracle_config2_shape():
+    """Full-size layers (9 L + 4 X + 2 pano) at a batch the CPU oracle finishes in seconds."""
+    from oracle.hamt_oracle import HamtOracle
+    from vln_imagine_amd.hamt.config import HamtConfig
+    cfg = HamtConfig()
+    ep = synth.HamtEpisode(tag="cfg2", B=3, L=80, V=37, I=6, T=2, ragged=True)
+    shapes = param_shapes(cfg)
+    npw = synth.fill_state_dict(shapes.items())
+    sd = {k: torch.from_numpy(v) for k, v in npw.items()}
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        ref = run_episode(HamtOracle(cfg, sd), EpisodeTensors(ep, "cpu"))
+    model = build_product(cfg)
+    with torch.no_grad():
+        out = run_episode(model, EpisodeTensors(ep, "cuda"))
+    _close(out["loss"].item(), ref["loss"].item(), TOL, "loss")
+    for t in range(ep.T):
+        _close(out["logits"][t].cpu().numpy(), ref["logits"][t].numpy(), TOL, f"logits{t}")
+
+
+def test_product_bf16_tracks_fp32():
+    """bf16 throughput path vs the fp32 path of the same model (reported, loose; never the parity gate)."""
+    from vln_imagine_amd.hamt.config import HamtConfig
+    cfg, ep = hamt_variant_setup("c1_language")
+    et = EpisodeTensors(ep, "cuda")
+    m32 = build_product(cfg)
+    o32 = run_episode(m32, et)
+    o32["loss"].backward()
+    m16 = build_product(cfg, torch.bfloat16)
+    o16 = run_episode(m16, et)
+    o16["loss"].backward()
+    assert abs(o16["loss"].item() - o32["loss"].item()) < 3e-2
+    for t in range(ep.T):
+        a, b = o16["logits"][t].float(), o32["logits"][t].float()
+        fin = torch.isfinite(b)
+        assert (torch.isfinite(a) == fin).all()
+        assert (a[fin] - b[fin]).abs().max().item() < 0.15
+    num = den = 0.0
+    for (n, p16), (_, p32) in zip(m16.named_parameters(), m32.named_parameters()):
+        if p32.grad is None:
+            continue
+        num += float((p16.grad.double() - p32.grad.double()).pow(2).sum())
+        den += float(p32.grad.double().pow(2).sum())
+    assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5

@@ -1,0 +1,333 @@
+"""GPU: every HIP operator (through the C-ABI) against a plain PyTorch fp32 reference of the same op.
+fp32 path tolerance 1e-4 (BASELINE north_star); bf16 path is checked against the fp32 math on
+bf16-rounded inputs with a bf16-sized tolerance (never used for the parity gate)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    from vln_imagine_amd import ops as o
+    return o
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).cuda()
+
+
+def _err(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+TOL = {torch.float32: 1e-4, torch.bfloat16: 6e-2}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (148, 768, 768), (300, 2304, 768), (257, 768, 3072), (64, 512, 512),
+                                   (5, 1536, 768)])
+def test_gemm_nt_plain(ops, dtype, M, N, K):
+    a, b = _rand((M, K), dtype, 1, 0.5), _rand((N, K), dtype, 2, 0.05)
+    ref = a.double() @ b.double().t()
+    out = ops.gemm_nt(a, b)
+    assert out.dtype == dtype
+    e = _err(out, ref)
+    assert e < TOL[dtype] * max(1.0, ref.abs().max().item()), (M, N, K, e)
+
+
+def test_gemm_exact_integers(ops):
+    """asymmetric small-integer operands: any row/col or k-permutation slip shows as a whole-number error."""
+    M, N, K = 192, 256, 128
+    a = torch.randint(-3, 4, (M, K), generator=torch.Generator().manual_seed(3)).float()
+    b = torch.randint(-3, 4, (N, K), generator=torch.Generator().manual_seed(4)).float()
+    ref = a @ b.t()
+    for dtype in (torch.float32, torch.bfloat16):
+        out = ops.gemm_nt(a.to(dtype).cuda(), b.to(dtype).cuda()).float().cpu()
+        assert torch.equal(out, ref), dtype
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 200, 768, 768
+    a, b = _rand((M, K), dtype, 1, 0.5), _rand((N, K), dtype, 2, 0.05)
+    bias = _rand((N,), torch.float32, 3, 0.1)
+    res = _rand((M, N), dtype, 4, 0.5)
+    z = torch.empty((M, N), dtype=dtype, device="cuda")
+    out = ops.gemm_nt(a, b, bias=bias, act=1, residual=res, preact=z)
+    zr = a.double() @ b.double().t() + bias.double()
+    ref = torch.nn.functional.gelu(zr) + res.double()
+    assert _err(z, zr) < TOL[dtype] * 3
+    assert _err(out, ref) < TOL[dtype] * 3
+    # relu + dact (gelu') epilogue
+    out2 = ops.gemm_nt(a, b, dact_src=z, dact=1)
+    zz = z.double().requires_grad_(True)
+    gp = torch.autograd.grad(torch.nn.functional.gelu(zz).sum(), zz)[0]
+    ref2 = (a.double() @ b.double().t()) * gp
+    assert _err(out2, ref2) < TOL[dtype] * 3
+    out3 = ops.gemm_nt(a, b, bias=bias, act=2)
+    assert _err(out3, torch.relu(zr)) < TOL[dtype] * 3
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(148, 768, 768), (5504, 768, 768), (333, 3072, 768), (70, 768, 3072)])
+def test_wgrad(ops, dtype, M, N, K):
+    dy, x = _rand((M, N), dtype, 5, 0.1), _rand((M, K), dtype, 6, 0.5)
+    ref = dy.double().t() @ x.double()
+    out = ops.wgrad(dy, x)
+    assert out.dtype == torch.float32
+    tol = 1e-4 if dtype == torch.float32 else 2e-3
+    assert _err(out, ref) < tol * max(1.0, ref.abs().max().item()), _err(out, ref)
+    out2 = ops.wgrad(dy, x, out)                       # accumulate
+    assert _err(out2, 2 * ref) < 2 * tol * max(1.0, ref.abs().max().item())
+    cs = ops.colsum(dy)
+    assert _err(cs, dy.double().sum(0)) < tol * 10
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,H,eps", [(148, 768, 1e-12), (1, 768, 1e-12), (4099, 768, 1e-5), (37, 512, 1e-12)])
+def test_layernorm(ops, dtype, rows, H, eps):
+    x = _rand((rows, H), dtype, 7)
+    g, b = _rand((H,), torch.float32, 8, 0.1) + 1.0, _rand((H,), torch.float32, 9, 0.1)
+    dy = _rand((rows, H), dtype, 10)
+    xr = x.double().requires_grad_(True)
+    gr, br = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (H,), gr, br, eps)
+    yr.backward(dy.double())
+    y, mean, rstd = ops.ln_fwd(x, g, b, eps)
+    dx, dg, db = ops.ln_bwd(dy, x, g, mean, rstd)
+    t = TOL[dtype]
+    assert _err(y, yr) < t
+    assert _err(dx, xr.grad) < t
+    assert _err(dg, gr.grad) < t * max(1.0, gr.grad.abs().max().item())
+    assert _err(db, br.grad) < t * max(1.0, br.grad.abs().max().item())
+
+
+def _attn_ref(q, k, v, kmask, bias, B, Sq, Sk):
+    nh, dh = 12, 64
+    qq = q.double().view(B, Sq, nh, dh).transpose(1, 2)
+    kk = k.double().view(B, Sk, nh, dh).transpose(1, 2)
+    vv = v.double().view(B, Sk, nh, dh).transpose(1, 2)
+    s = qq @ kk.transpose(-1, -2) / 8.0
+    if kmask is not None:
+        s = s + kmask.double()[:, None, None, :]
+    if bias is not None:
+        s = s + bias.double()[:, None]
+    return (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(B * Sq, nh * dh)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Sq,Sk,use_bias", [(4, 80, 80, False), (3, 86, 38, False), (3, 38, 86, False), (2, 1, 5, False),
+                                              (2, 100, 128, False), (2, 33, 65, True), (5, 130, 97, False)])
+def test_attention_fwd_bwd(ops, dtype, B, Sq, Sk, use_bias):
+    H = 768
+    qkv_q = _rand((B * Sq, 3 * H), dtype, 11, 0.7)          # packed: q taken from cols 0:768
+    qkv_k = _rand((B * Sk, 3 * H), dtype, 12, 0.7)          # k from 768:1536, v from 1536:2304
+    lens = torch.randint(1, Sk + 1, (B,), generator=torch.Generator().manual_seed(13))
+    lens[0] = Sk
+    kmask = ((torch.arange(Sk)[None, :] >= lens[:, None]).float() * -10000.0).cuda()
+    bias = _rand((B, Sq, Sk), torch.float32, 14, 0.5) if use_bias else None
+    q, k, v = qkv_q[:, :H], qkv_k[:, H:2 * H], qkv_k[:, 2 * H:]
+    out, lse = ops.attn_fwd(q, k, v, B, Sq, Sk, kmask, bias)
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (q, k, v))
+    br = bias.double().clone().requires_grad_(True) if use_bias else None
+    ref = _attn_ref(qr, kr, vr, kmask, br, B, Sq, Sk)
+    t = TOL[dtype]
+    assert _err(out, ref) < t, ("fwd", _err(out, ref))
+    dout = _rand((B * Sq, H), dtype, 15)
+    ref.backward(dout.double())
+    dq_buf = torch.zeros_like(qkv_q)
+    dk_buf = torch.zeros_like(qkv_k)
+    dbias = torch.zeros_like(bias) if use_bias else None
+    ops.attn_bwd(q, k, v, out, dout, lse, dq_buf[:, :H], dk_buf[:, H:2 * H], dk_buf[:, 2 * H:], B, Sq, Sk, kmask, bias, dbias)
+    assert _err(dq_buf[:, :H], qr.grad) < t, ("dq", _err(dq_buf[:, :H], qr.grad))
+    assert _err(dk_buf[:, H:2 * H], kr.grad) < t, ("dk", _err(dk_buf[:, H:2 * H], kr.grad))
+    assert _err(dk_buf[:, 2 * H:], vr.grad) < t, ("dv", _err(dk_buf[:, 2 * H:], vr.grad))
+    assert float(dq_buf[:, H:].abs().max()) == 0.0 and float(dk_buf[:, :H].abs().max()) == 0.0   # nothing outside the slices
+    if use_bias:
+        assert _err(dbias, br.grad) < t * 5, ("dbias", _err(dbias, br.grad))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_blocks_against_torch(ops, dtype):
+    """The fused sublayer nodes (self-att, FFN, x-att pair, x-att) fwd+bwd vs the same math in torch fp64."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    B, Sl, Sv, H, FF = 3, 50, 21, 768, 3072
+    mk = lambda *s, sc=0.04: (torch.randn(*s) * sc).cuda().requires_grad_(True)
+    att = [mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1)]
+    g = (1 + 0.1 * torch.randn(H)).cuda().requires_grad_(True)
+    b = (0.1 * torch.randn(H)).cuda().requires_grad_(True)
+    ffn = [mk(FF, H), mk(FF, sc=0.1), mk(H, FF, sc=0.02), mk(H, sc=0.1)]
+    lang = torch.randn(B, Sl, H).cuda()
+    visn = torch.randn(B, Sv, H).cuda()
+    ml = (torch.rand(B, Sl) > 0.2).float()
+    mv = (torch.rand(B, Sv) > 0.2).float()
+    ml[:, 0] = 1; mv[:, 0] = 1
+    aml, amv = ((1 - ml) * -10000.0).cuda(), ((1 - mv) * -10000.0).cuda()
+
+    def ref_att(x, c, mask, W):
+        wq, bq, wk, bk, wv, bv, wo, bo = [w.double() for w in W]
+        Bq, Sq, _ = x.shape
+        Sk = c.shape[1]
+        q = F.linear(x, wq, bq).view(Bq, Sq, 12, 64).transpose(1, 2)
+        k = F.linear(c, wk, bk).view(Bq, Sk, 12, 64).transpose(1, 2)
+        v = F.linear(c, wv, bv).view(Bq, Sk, 12, 64).transpose(1, 2)
+        s = q @ k.transpose(-1, -2) / 8 + mask.double()[:, None, None, :]
+        a = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(Bq, Sq, H)
+        return F.layer_norm(F.linear(a, wo, bo) + x, (H,), g.double(), b.double(), 1e-12)
+
+    def ref_ffn(x):
+        w1, b1, w2, b2 = [w.double() for w in ffn]
+        return F.layer_norm(F.linear(F.gelu(F.linear(x, w1, b1)), w2, b2) + x, (H,), g.double(), b.double(), 1e-12)
+
+    params = att + [g, b] + ffn
+    P = tuple(att) + (g, b)
+    PF = tuple(ffn) + (g, b)
+
+    def run(fn_prod, fn_ref, inputs):
+        xs_p = [t.to(dtype).detach().requires_grad_(True) for t in inputs]
+        xs_r = [t.to(dtype).double().detach().requires_grad_(True) for t in inputs]
+        for p in params:
+            p.grad = None
+        out_p = fn_prod(*xs_p)
+        out_r = fn_ref(*xs_r)
+        out_p = out_p if isinstance(out_p, tuple) else (out_p,)
+        out_r = out_r if isinstance(out_r, tuple) else (out_r,)
+        t = TOL[dtype]
+        for a_, r_ in zip(out_p, out_r):
+            assert _err(a_, r_) < t, ("fwd", _err(a_, r_))
+        torch.manual_seed(1)
+        ws = [torch.randn_like(r_) for r_ in out_r]
+        sum((a_.double() * w).sum() for a_, w in zip(out_p, ws)).backward()
+        gp = [p.grad.clone() for p in params if p.grad is not None]
+        gx = [x.grad.clone() for x in xs_p]
+        for p in params:
+            p.grad = None
+        sum((r_ * w).sum() for r_, w in zip(out_r, ws)).backward()
+        gr = [p.grad.clone() for p in params if p.grad is not None]
+        scale = 30.0 if dtype == torch.bfloat16 else 1.0
+        for a_, r_ in zip(gx, [x.grad for x in xs_r]):
+            assert _err(a_, r_) < t * scale * max(1.0, r_.abs().max().item()), ("dx", _err(a_, r_))
+        assert len(gp) == len(gr)
+        for a_, r_ in zip(gp, gr):
+            assert _err(a_, r_) < t * scale * max(1.0, r_.abs().max().item()), ("dparam", _err(a_, r_), r_.abs().max().item())
+
+    run(lambda x: ops.self_att_block(x, aml, P), lambda x: ref_att(x, x, aml, att), [lang])
+    run(lambda x: ops.ffn_block(x, PF), ref_ffn, [lang])
+    run(lambda l, v: ops.xatt_pair_block(l, v, aml, amv, P),
+        lambda l, v: (ref_att(l, v, amv, att), ref_att(v, l, aml, att)), [lang, visn])
+    run(lambda v, l: ops.xatt_block(v, l, aml, P), lambda v, l: ref_att(v, l, aml, att), [visn, lang])
+
+
+def test_small_ops(ops):
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    dev = "cuda"
+    # cross entropy with -inf logits and ignore_index
+    lg = torch.randn(6, 37, device=dev)
+    lg[:, 30:] = -float("inf")
+    tgt = torch.tensor([0, 5, -100, 29, 3, -100], device=dev)
+    lr = lg.clone().requires_grad_(True)
+    ref = F.cross_entropy(lr, tgt, ignore_index=-100, reduction="sum")
+    (ref * 0.3).backward()
+    lp = lg.clone().requires_grad_(True)
+    out = ops.cross_entropy_sum(lp, tgt)
+    (out * 0.3).backward()
+    assert _err(out, ref) < 1e-5 and _err(lp.grad, lr.grad) < 1e-6
+    # row dot with mask
+    h = torch.randn(4, 9, 768, device=dev, requires_grad=True)
+    w = torch.randn(1, 768, device=dev, requires_grad=True)
+    bb = torch.randn(1, device=dev, requires_grad=True)
+    mask = torch.rand(4, 9, device=dev) > 0.7
+    o = ops.row_dot(h, w, bb, mask)
+    ref = (h.double() @ w.double().t()).squeeze(-1) + bb.double()
+    assert torch.isinf(o[mask]).all() and _err(o[~mask], ref[~mask]) < 1e-4
+    wts = torch.randn(4, 9, device=dev)
+    (o.masked_fill(mask, 0) * wts).sum().backward()
+    gh, gw, gb = h.grad.clone(), w.grad.clone(), bb.grad.clone()
+    h.grad = w.grad = bb.grad = None
+    (ref.masked_fill(mask, 0) * wts.double()).sum().backward()
+    assert _err(gh, h.grad) < 1e-5 and _err(gw, w.grad) < 1e-4 and _err(gb, bb.grad) < 1e-5
+    # small-K linear
+    x = torch.randn(50, 4, device=dev)
+    W = torch.randn(768, 4, device=dev, requires_grad=True)
+    b2 = torch.randn(768, device=dev, requires_grad=True)
+    y = ops.smallk_linear(x, W, b2, torch.float32)
+    yr = F.linear(x.double(), W.double(), b2.double())
+    assert _err(y, yr) < 1e-5
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    gW, gb2 = W.grad.clone(), b2.grad.clone()
+    W.grad = b2.grad = None
+    yr.backward(gy.double())
+    assert _err(gW, W.grad) < 1e-4 and _err(gb2, b2.grad) < 1e-4
+    # seq mean, cosine, segment mean
+    xs = torch.randn(5, 36, 768, device=dev, requires_grad=True)
+    m = ops.seq_mean(xs)
+    assert _err(m, xs.double().mean(1)) < 1e-6
+    m.sum().backward()
+    assert _err(xs.grad, torch.full_like(xs, 1 / 36)) < 1e-7
+    a = torch.randn(7, 768, device=dev, requires_grad=True)
+    c = torch.randn(7, 768, device=dev, requires_grad=True)
+    cs = ops.cosine(a, c)
+    ar, cr = a.double().detach().requires_grad_(True), c.double().detach().requires_grad_(True)
+    csr = F.cosine_similarity(ar, cr, dim=-1)
+    assert _err(cs, csr) < 1e-6
+    ww = torch.randn(7, device=dev)
+    (cs * ww).sum().backward(); (csr * ww.double()).sum().backward()
+    assert _err(a.grad, ar.grad) < 1e-6 and _err(c.grad, cr.grad) < 1e-6
+    t = torch.randn(40, 768, device=dev, requires_grad=True)
+    off = torch.tensor([0, 3, 4, 9], dtype=torch.int32, device=dev)
+    rows = torch.tensor([1, 2, 3, 10, 20, 21, 22, 3, 39], dtype=torch.int32, device=dev)
+    sm = ops.segment_mean(t, off, rows)
+    tr = t.double().detach().requires_grad_(True)
+    smr = torch.stack([tr[[1, 2, 3]].mean(0), tr[[10]].mean(0), tr[[20, 21, 22, 3, 39]].mean(0)])
+    assert _err(sm, smr) < 1e-6
+    wz = torch.randn_like(sm)
+    (sm * wz).sum().backward(); (smr * wz.double()).sum().backward()
+    assert _err(t.grad, tr.grad) < 1e-6
+    # sum + layernorm with gather / bcast / dense sources
+    tab = torch.randn(11, 768, device=dev, requires_grad=True)
+    row = torch.randn(768, device=dev, requires_grad=True)
+    dn = torch.randn(30, 768, device=dev, requires_grad=True)
+    idx = torch.randint(0, 11, (30,), device=dev)
+    g = (1 + 0.1 * torch.randn(768, device=dev)).requires_grad_(True)
+    be = (0.1 * torch.randn(768, device=dev)).requires_grad_(True)
+    y = ops.sum_layer_norm([(tab, "gather", idx), (row, "bcast", None), (dn, "dense", None)], g, be, 30, torch.float32)
+    leaves = [tab, row, dn, g, be]
+    dl = [l.double().detach().requires_grad_(True) for l in leaves]
+    yr = F.layer_norm(dl[0][idx] + dl[1][None] + dl[2], (768,), dl[3], dl[4], 1e-12)
+    assert _err(y, yr) < 1e-5
+    wy = torch.randn_like(y)
+    (y * wy).sum().backward(); (yr * wy.double()).sum().backward()
+    for a_, r_ in zip(leaves, dl):
+        assert _err(a_.grad, r_.grad) < 1e-4 * max(1.0, r_.grad.abs().max().item())
+
+
+def test_adamw_and_clip(ops):
+    from vln_imagine_amd import _lib
+    torch.manual_seed(0)
+    n = 4096 * 3
+    p = torch.randn(n, device="cuda"); g = torch.randn(n, device="cuda") * 3
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=1e-3, weight_decay=0.01)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    sh = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    for step in (1, 2, 3):
+        pr.grad = g.clone()
+        total = torch.nn.utils.clip_grad_norm_([pr], 40.0)
+        opt.step()
+        ss = torch.zeros(1, device="cuda"); coef = torch.empty(1, device="cuda")
+        _lib.call("vlni_sumsq", g.data_ptr(), n, ss.data_ptr(), st)
+        _lib.call("vlni_clip_coef", ss.data_ptr(), 40.0, coef.data_ptr(), st)
+        assert abs(math.sqrt(ss.item()) - total.item()) < 1e-2
+        _lib.call("vlni_adamw_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, 1e-3, 0.9, 0.999,
+                  1e-8, 0.01, step, coef.data_ptr(), st)
+        assert _err(p, pr.detach()) < 1e-5, step
+    assert _err(sh.float(), p) < 2e-2

@@ -1,0 +1,80 @@
+"""ctypes binding of libvlni.so (the C-ABI declared in include/vlni.h).
+
+The product path has no CPU fallback: if the library is missing or a call fails,
+this module raises. Pointers are passed as integers (tensor.data_ptr()).
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  MUST precede the dlopen below: libvlni.so needs libamdhip64.so.7 by SONAME and has to
+#                            bind to the copy torch already loaded (two HIP runtimes in one process cannot both
+#                            own the device: the second reports "no ROCm-capable device").
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlni.so")
+
+P, L, I, F = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes, in the order of include/vlni.h
+SIGNATURES = {
+    "vlni_gemm_nt": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, P],
+    "vlni_attn_fwd": [I, P, L, P, L, P, L, P, P, P, L, P, I, I, I, I, F, P],
+    "vlni_attn_bwd": [I, P, L, P, L, P, L, P, P, P, L, P, L, P, P, L, P, L, P, L, P, I, I, I, I, F, P],
+    "vlni_layernorm_fwd": [I, P, L, P, P, F, P, L, P, P, I, I, P],
+    "vlni_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, P, I, I, P],
+    "vlni_sum_layernorm_fwd": [I, I, P, P, P, P, P, P, F, P, L, P, L, P, P, I, I, P],
+    "vlni_cast": [I, I, P, P, L, P],
+    "vlni_transpose": [I, I, P, L, P, L, I, I, I, P],
+    "vlni_colsum": [I, P, L, I, I, P, P],
+    "vlni_smallk_linear_fwd": [I, P, L, P, P, P, L, I, I, I, P],
+    "vlni_smallk_linear_bwd": [I, P, L, P, L, P, P, I, I, I, P],
+    "vlni_scatter_add_rows": [I, P, L, P, P, I, I, P],
+    "vlni_seqmean_fwd": [I, P, P, I, I, I, P],
+    "vlni_seqmean_bwd": [I, P, P, I, I, I, P],
+    "vlni_rowdot_fwd": [I, P, L, P, P, P, P, I, I, P],
+    "vlni_rowdot_bwd": [I, P, P, L, P, P, P, L, P, P, I, I, P],
+    "vlni_cross_entropy": [P, L, P, L, P, P, L, I, I, P],
+    "vlni_segment_mean_fwd": [I, P, L, P, P, P, I, I, P],
+    "vlni_segment_mean_bwd": [I, P, P, P, P, I, I, P],
+    "vlni_cosine_fwd": [I, P, P, F, P, P, P, I, I, P],
+    "vlni_cosine_bwd": [I, P, P, P, P, P, P, P, P, I, I, P],
+    "vlni_act_bwd": [I, I, P, P, P, L, P],
+    "vlni_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, P],
+    "vlni_sumsq": [P, L, P, P],
+    "vlni_clip_coef": [P, F, P, P],
+}
+
+
+class VlniError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Loads libvlni.so (built by vln_imagine_amd.build / __graft_entry__.build). Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VlniError(
+            f"{LIB_PATH} not found: the HIP operator library is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback).")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vlni_last_error.restype = ctypes.c_char_p
+    lib.vlni_last_error.argtypes = []
+    lib.vlni_version.restype = ctypes.c_int
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise VlniError(f"{name} failed ({rc}): {lib.vlni_last_error().decode()}")

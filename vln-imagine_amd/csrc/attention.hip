@@ -1,0 +1,354 @@
+// Fused masked multi-head attention, forward and backward, head dim 64, Sk <= 128 keys per call.
+//   forward : O = softmax(Q K^T * scale + kmask[b,key] + bias[b,q,key]) V,  LSE saved
+//   backward: dQ, dK, dV (and dbias) by recomputing P from LSE (no S x S tensor ever reaches HBM)
+// restating BertSelfAttention / BertOutAttention
+//   (VLN-HAMT/finetune_src/models/vilmodel_cmt.py:100-134, :326-353) and, with `bias`, the
+//   graph_sprels self-attention of VLN-DUET/map_nav_src/models/vilmodel.py:384-399.
+// Mask semantics are the reference's: ADDITIVE (1-m)*-10000 (finite), so a fully padded query row still
+// yields a finite softmax; only the tile padding (key >= Sk) is excluded with -inf.
+//
+// v1 data path (both dtypes): Q/K/V/dO tiles are staged through LDS as f32 (row stride 65 dwords:
+// conflict-free for both "row on lane" and "column on lane" reads) and every contraction runs on the
+// exact-fp32 matrix instruction v_mfma_f32_32x32x2_f32. The score tile is produced TRANSPOSED
+// (S^T = K Q^T) in the forward pass so each lane owns one query column: the row max / row sum are
+// 16*NKT in-register ops + one 32-lane wavefront shuffle, and P^T is already the B operand of the
+// P V product (no LDS round trip for P). In the backward pass keys sit on the lanes (S = Q K^T), so
+// P and dS feed dV^T and dK^T straight from registers and only dS crosses LDS once, for dQ.
+#include "common.h"
+
+namespace {
+
+constexpr int LD = 65;   // LDS row stride (dwords) of the 64-wide head tiles
+
+template <typename T>
+__device__ __forceinline__ void stage_rows(float* dst, const T* src, long ld, int row0, int nrows_valid, int nrows_tile,
+                                           int tid, int nthreads) {
+  // dst[row][0..63] = src[(row0+row)*ld + 0..63] for row < nrows_valid, zero otherwise
+  for (int i = tid; i < nrows_tile * 16; i += nthreads) {
+    const int row = i >> 4, c4 = (i & 15) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < nrows_valid) v = DT<T>::ld4(src + (long)(row0 + row) * ld + c4);
+    float* d = dst + row * LD + c4;
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+}
+
+__device__ __forceinline__ int acc_row(int x, int hh) { return (x & 3) + 8 * (x >> 2) + 4 * hh; }
+
+struct AttnP {
+  const void *q, *k, *v;
+  long ldq, ldk, ldv;
+  const float* kmask;   // [B, Sk] additive or null
+  const float* bias;    // [B, Sq, Sk] additive or null
+  void* out; long ldo;
+  float* lse;           // [B, nh, Sq]
+  int B, nh, Sq, Sk;
+  float scale;
+  // backward only
+  const void* dout; long lddo;
+  void *dq, *dk, *dv;
+  long lddq, lddk, lddv;
+  float* dbias;         // [B, Sq, Sk] accumulated over heads (atomics) or null
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward: block = 2 waves, each wave 32 query rows; grid = (ceil(Sq/64), B*nh)
+template <typename T, int NKT>
+__global__ __launch_bounds__(128) void attn_fwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int SKP = NKT * 32;
+  float* Ks = smem;
+  float* Vs = Ks + SKP * LD;
+  float* Qs = Vs + SKP * LD;
+  const int bh = blockIdx.y, b = bh / p.nh, hd = bh % p.nh;
+  const int q0 = blockIdx.x * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+
+  stage_rows<T>(Ks, (const T*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, 128);
+  stage_rows<T>(Vs, (const T*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, 128);
+  stage_rows<T>(Qs, (const T*)p.q + (long)b * p.Sq * p.ldq + hd * 64, p.ldq, q0, min(64, p.Sq - q0), 64, tid, 128);
+  __syncthreads();
+
+  const int qloc = wave * 32 + r;         // this lane's query row inside the block
+  const int qg = q0 + qloc;               // global query index
+  float qreg[32];
+#pragma unroll
+  for (int kk = 0; kk < 32; ++kk) qreg[kk] = Qs[qloc * LD + 2 * kk + hh];
+
+  f32x16 s[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x) s[kt][x] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk)
+      s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(kt * 32 + r) * LD + 2 * kk + hh], qreg[kk], s[kt], 0, 0, 0);
+  }
+  // s[kt][x] = <Q[q=r], K[key]>, key = kt*32 + acc_row(x, hh)
+  const float* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
+  const float* bs = (p.bias && qg < p.Sq) ? p.bias + ((long)b * p.Sq + qg) * p.Sk : nullptr;
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int key = kt * 32 + acc_row(x, hh);
+      float v = s[kt][x] * p.scale;
+      if (key < p.Sk) {
+        if (km) v += km[key];
+        if (bs) v += bs[key];
+      } else {
+        v = -INFINITY;
+      }
+      s[kt][x] = v;
+      m = fmaxf(m, v);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const float e = __expf(s[kt][x] - m);
+      s[kt][x] = e;
+      l += e;
+    }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+
+  T* out = (T*)p.out + ((long)b * p.Sq + qg) * p.ldo + hd * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    f32x16 o;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) o[x] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int x = 0; x < 16; ++x)
+        o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[(kt * 32 + acc_row(x, hh)) * LD + dt * 32 + r], s[kt][x], o, 0, 0, 0);
+    // o[y] = O^T[d = dt*32 + acc_row(y, hh)][q = r]
+    if (qg < p.Sq) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+        DT<T>::st4(out + dt * 32 + 8 * g + 4 * hh, v);
+      }
+    }
+  }
+  if (p.lse && hh == 0 && qg < p.Sq) p.lse[((long)b * p.nh + hd) * p.Sq + qg] = m + __logf(l);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: block = 4 waves; wave w owns key tile w (32 keys); grid = B*nh; query rows in chunks of 64
+template <typename T, int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int SKP = NKT * 32, LDS_S = SKP + 1;
+  float* Ks = smem;
+  float* Vs = Ks + SKP * LD;
+  float* Qs = Vs + SKP * LD;
+  float* dOs = Qs + 64 * LD;
+  float* dSs = dOs + 64 * LD;             // [64][SKP+1]
+  float* lse_s = dSs + 64 * LDS_S;        // [64]
+  float* del_s = lse_s + 64;              // [64]
+  const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+
+  stage_rows<T>(Ks, (const T*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, 256);
+  stage_rows<T>(Vs, (const T*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, 256);
+  __syncthreads();
+
+  const bool owner = wave < NKT;
+  const int key = wave * 32 + r;           // this lane's key (phase 1)
+  float kreg[32], vreg[32];
+  if (owner) {
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk) {
+      kreg[kk] = Ks[key * LD + 2 * kk + hh];
+      vreg[kk] = Vs[key * LD + 2 * kk + hh];
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) { dk[dt][x] = 0.f; dv[dt][x] = 0.f; }
+  const float kmv = (p.kmask && key < p.Sk) ? p.kmask[(long)b * p.Sk + key] : 0.f;
+
+  for (int q0 = 0; q0 < p.Sq; q0 += 64) {
+    const int nq = min(64, p.Sq - q0);
+    stage_rows<T>(Qs, (const T*)p.q + (long)b * p.Sq * p.ldq + hd * 64, p.ldq, q0, nq, 64, tid, 256);
+    stage_rows<T>(dOs, (const T*)p.dout + (long)b * p.Sq * p.lddo + hd * 64, p.lddo, q0, nq, 64, tid, 256);
+    // delta[q] = sum_d dO[q][d] * O[q][d]; one wave per row, lane = d
+    for (int row = wave; row < 64; row += 4) {
+      float dl = 0.f;
+      if (row < nq) {
+        const long qrow = (long)b * p.Sq + q0 + row;
+        dl = DT<T>::ld((const T*)p.dout + qrow * p.lddo + hd * 64 + lane) *
+             DT<T>::ld((const T*)p.out + qrow * p.ldo + hd * 64 + lane);
+      }
+      dl = wave_sum(dl);
+      if (lane == 0) {
+        del_s[row] = dl;
+        lse_s[row] = row < nq ? p.lse[((long)b * p.nh + hd) * p.Sq + q0 + row] : 0.f;
+      }
+    }
+    __syncthreads();
+
+    if (owner) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) { s[x] = 0.f; dp[x] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+          s = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[(qt * 32 + r) * LD + 2 * kk + hh], kreg[kk], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[(qt * 32 + r) * LD + 2 * kk + hh], vreg[kk], dp, 0, 0, 0);
+        }
+        // s[x] / dp[x]: q = qt*32 + acc_row(x, hh), key = this lane's key
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const int ql = qt * 32 + acc_row(x, hh);
+          float pv = 0.f, ds = 0.f;
+          if (key < p.Sk && ql < nq) {
+            float sv = s[x] * p.scale + kmv;
+            if (p.bias) sv += p.bias[((long)b * p.Sq + q0 + ql) * p.Sk + key];
+            pv = __expf(sv - lse_s[ql]);
+            ds = pv * (dp[x] - del_s[ql]);
+            if (p.dbias) atomicAdd(p.dbias + ((long)b * p.Sq + q0 + ql) * p.Sk + key, ds);
+          }
+          s[x] = pv;
+          dp[x] = ds * p.scale;
+          dSs[ql * LDS_S + key] = dp[x];
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int x = 0; x < 16; ++x) {
+            const int ql = qt * 32 + acc_row(x, hh);
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dOs[ql * LD + dt * 32 + r], s[x], dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[ql * LD + dt * 32 + r], dp[x], dk[dt], 0, 0, 0);
+          }
+      }
+    }
+    __syncthreads();
+
+    // phase 2: dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q]; 4 tiles (qt, dt), one per wave
+    {
+      const int qt = wave >> 1, dt = wave & 1;
+      f32x16 dq;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) dq[x] = 0.f;
+#pragma unroll 8
+      for (int kk = 0; kk < SKP / 2; ++kk)
+        dq = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[(2 * kk + hh) * LD + dt * 32 + r], dSs[(qt * 32 + r) * LDS_S + 2 * kk + hh], dq,
+                                                  0, 0, 0);
+      const int ql = qt * 32 + r;
+      if (ql < nq) {
+        T* o = (T*)p.dq + ((long)b * p.Sq + q0 + ql) * p.lddq + hd * 64 + dt * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]};
+          DT<T>::st4(o + 8 * g + 4 * hh, v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (owner && key < p.Sk) {
+    T* ok = (T*)p.dk + ((long)b * p.Sk + key) * p.lddk + hd * 64;
+    T* ov = (T*)p.dv + ((long)b * p.Sk + key) * p.lddv + hd * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a = {dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]};
+        f32x4 c = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
+        DT<T>::st4(ok + dt * 32 + 8 * g + 4 * hh, a);
+        DT<T>::st4(ov + dt * 32 + 8 * g + 4 * hh, c);
+      }
+  }
+}
+
+template <typename T, int NKT>
+int launch_fwd(const AttnP& p, hipStream_t st) {
+  const size_t lds = (size_t)(2 * NKT * 32 * LD + 64 * LD) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(cdiv(p.Sq, 64), p.B * p.nh), dim3(128), lds, st, p);
+  return 0;
+}
+template <typename T, int NKT>
+int launch_bwd(const AttnP& p, hipStream_t st) {
+  const size_t lds = (size_t)(2 * NKT * 32 * LD + 2 * 64 * LD + 64 * (NKT * 32 + 1) + 128) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attn_bwd_kernel<T, NKT>), dim3(p.B * p.nh), dim3(256), lds, st, p);
+  return 0;
+}
+
+template <typename T>
+int dispatch(const AttnP& p, bool bwd, hipStream_t st) {
+  const int nkt = cdiv(p.Sk, 32);
+  switch (nkt) {
+    case 1: return bwd ? launch_bwd<T, 1>(p, st) : launch_fwd<T, 1>(p, st);
+    case 2: return bwd ? launch_bwd<T, 2>(p, st) : launch_fwd<T, 2>(p, st);
+    case 3: return bwd ? launch_bwd<T, 3>(p, st) : launch_fwd<T, 3>(p, st);
+    case 4: return bwd ? launch_bwd<T, 4>(p, st) : launch_fwd<T, 4>(p, st);
+  }
+  return -1;
+}
+
+int check_common(const char* who, int dtype, const AttnP& p) {
+  VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "%s: bad dtype %d", who, dtype);
+  VLNI_CHECK(p.B > 0 && p.nh > 0 && p.Sq > 0 && p.Sk > 0, VLNI_EINVAL, "%s: empty problem", who);
+  VLNI_CHECK(p.Sk <= 128, VLNI_EUNSUP, "%s: Sk=%d > 128 keys not covered by this build", who, p.Sk);
+  VLNI_CHECK(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, VLNI_EINVAL,
+             "%s: row strides must be multiples of 4 elements", who);
+  VLNI_CHECK(p.ldq >= p.nh * 64 && p.ldk >= p.nh * 64 && p.ldv >= p.nh * 64 && p.ldo >= p.nh * 64, VLNI_EINVAL,
+             "%s: row strides smaller than nh*64", who);
+  return VLNI_OK;
+}
+
+}  // namespace
+
+extern "C" int vlni_attn_fwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                             const float* kmask, const float* bias, void* out, long ldo, float* lse, int B, int nh, int Sq,
+                             int Sk, float scale, void* stream) {
+  AttnP p = {};
+  p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kmask = kmask; p.bias = bias;
+  p.out = out; p.ldo = ldo; p.lse = lse; p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
+  int rc = check_common("attn_fwd", dtype, p);
+  if (rc) return rc;
+  rc = dtype == VLNI_F32 ? dispatch<float>(p, false, (hipStream_t)stream) : dispatch<__bf16>(p, false, (hipStream_t)stream);
+  VLNI_CHECK(rc == 0, VLNI_EUNSUP, "attn_fwd: no kernel for Sk=%d", Sk);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                             const float* kmask, const float* bias, const void* out, long ldo, const void* dout, long lddo,
+                             const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* dbias,
+                             int B, int nh, int Sq, int Sk, float scale, void* stream) {
+  AttnP p = {};
+  p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kmask = kmask; p.bias = bias;
+  p.out = (void*)out; p.ldo = ldo; p.lse = (float*)lse; p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
+  p.dout = dout; p.lddo = lddo; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv; p.dbias = dbias;
+  int rc = check_common("attn_bwd", dtype, p);
+  if (rc) return rc;
+  VLNI_CHECK(lddo % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, VLNI_EINVAL, "attn_bwd: grad strides");
+  VLNI_CHECK(lse != nullptr, VLNI_EINVAL, "attn_bwd: lse required");
+  rc = dtype == VLNI_F32 ? dispatch<float>(p, true, (hipStream_t)stream) : dispatch<__bf16>(p, true, (hipStream_t)stream);
+  VLNI_CHECK(rc == 0, VLNI_EUNSUP, "attn_bwd: no kernel for Sk=%d", Sk);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}

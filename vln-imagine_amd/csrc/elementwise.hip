@@ -1,0 +1,485 @@
+// HBM-bound row/element kernels of the hot path: dtype casts, tile transposes (wgrad operands and
+// transposed weight shadows), column sums (bias gradients), the tiny-K feature projections
+// (angle / position features, K <= 16), embedding-gradient scatter, sequence mean, the action-head
+// row dot + nav-type mask, masked cross-entropy, and the imagination-grounding auxiliary pieces
+// (noun-phrase segment mean, cosine loss). All coalesced 16-B/8-B accesses; reductions through
+// wavefront shuffles; f32 accumulation everywhere.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ s, D* __restrict__ d, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) DT<D>::st4(d + i, DT<S>::ld4(s + i));
+  if (i < n && i + 3 >= n)
+    for (long j = i; j < n; ++j) DT<D>::st(d + j, DT<S>::ld(s + j));
+}
+
+// dst[c][r] = src[r][c] for r < R, zero for R <= r < Rpad.   64x64 tiles through LDS.
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void transpose_kernel(const S* __restrict__ src, long lds_, D* __restrict__ dst, long ldd,
+                                                        int R, int C, int Rpad) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < R && c < C) ? DT<S>::ld(src + (long)r * lds_ + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < Rpad) DT<D>::st(dst + (long)c * ldd + r, tile[tx][i]);
+  }
+}
+
+// out[n] += sum_r x[r][n]      (bias gradients).  grid.x over column groups of 256, grid.y over row slabs.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ldx, int rows, int N,
+                                                     float* __restrict__ out) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  const int per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float a = 0.f;
+  for (int r = r0; r < r1; ++r) a += DT<T>::ld(x + (long)r * ldx + col);
+  atomicAdd(out + col, a);
+}
+
+// y[r][n] = b[n] + sum_k x[r][k] W[n][k],  K <= 16, x f32 features, W/b f32 parameters.
+template <typename T>
+__global__ __launch_bounds__(256) void smallk_fwd_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ W,
+                                                         const float* __restrict__ b, T* __restrict__ y, long ldy, int rows,
+                                                         int N, int K) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float w[16];
+  for (int k = 0; k < K; ++k) w[k] = W[(long)n * K + k];
+  const float bv = b ? b[n] : 0.f;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    float a = bv;
+    for (int k = 0; k < K; ++k) a += x[(long)r * ldx + k] * w[k];
+    DT<T>::st(y + (long)r * ldy + n, a);
+  }
+}
+// dW[n][k] += sum_r dy[r][n] x[r][k];  db[n] += sum_r dy[r][n]
+template <typename T>
+__global__ __launch_bounds__(256) void smallk_bwd_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ x,
+                                                         long ldx, float* __restrict__ dW, float* __restrict__ db, int rows,
+                                                         int N, int K) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float a[16], s = 0.f;
+  for (int k = 0; k < 16; ++k) a[k] = 0.f;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float d = DT<T>::ld(dy + (long)r * lddy + n);
+    s += d;
+    for (int k = 0; k < K; ++k) a[k] += d * x[(long)r * ldx + k];
+  }
+  for (int k = 0; k < K; ++k) atomicAdd(dW + (long)n * K + k, a[k]);
+  if (db) atomicAdd(db + n, s);
+}
+
+// table_grad[idx[r]][:] += src[r][:]   (embedding backward; idx == null: every row goes to row 0)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const T* __restrict__ src, long lds_,
+                                                               const long* __restrict__ idx, float* __restrict__ tab, int rows,
+                                                               int H) {
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const long t = idx ? idx[r] : 0;
+    for (int c = threadIdx.x; c < H; c += 256) atomicAdd(tab + t * H + c, DT<T>::ld(src + (long)r * lds_ + c));
+  }
+}
+
+// out[b][:] = mean_s x[b][s][:]   and its backward dx[b][s][:] = dout[b][:] / S
+template <typename T>
+__global__ __launch_bounds__(256) void seqmean_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int S, int H) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += DT<T>::ld(x + ((long)b * S + s) * H + c);
+    DT<T>::st(out + (long)b * H + c, a / S);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void seqmean_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int B, int S, int H) {
+  const int b = blockIdx.x;
+  const float inv = 1.0f / S;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    const float g = DT<T>::ld(dout + (long)b * H + c) * inv;
+    for (int s = 0; s < S; ++s) DT<T>::st(dx + ((long)b * S + s) * H + c, g);
+  }
+}
+
+// logits[r] = mask[r] ? -inf : (bias + sum_c h[r][c] w[c])      (NextActionPrediction.net.4 + masked_fill)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ h, long ldh, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const unsigned char* __restrict__ mask,
+                                                         float* __restrict__ out, int rows, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+    float a = 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+      const f32x4 v = DT<T>::ld4(h + (long)r * ldh + c), ww = *(const f32x4*)(w + c);
+      a += v[0] * ww[0] + v[1] * ww[1] + v[2] * ww[2] + v[3] * ww[3];
+    }
+    a = wave_sum(a);
+    if (lane == 0) out[r] = (mask && mask[r]) ? -INFINITY : a + (bias ? bias[0] : 0.f);
+  }
+}
+// dh[r][c] = dl[r] * w[c] (0 where masked); dw[c] += sum_r dl[r] h[r][c]; dbias += sum_r dl[r]
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ dl, const T* __restrict__ h, long ldh,
+                                                         const float* __restrict__ w, const unsigned char* __restrict__ mask,
+                                                         T* __restrict__ dh, long lddh, float* __restrict__ dw,
+                                                         float* __restrict__ dbias, int rows, int H) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const float wc = c < H ? w[c] : 0.f;
+  float aw = 0.f, ab = 0.f;
+  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float g = (mask && mask[r]) ? 0.f : dl[r];
+    if (c < H) {
+      DT<T>::st(dh + (long)r * lddh + c, g * wc);
+      aw += g * DT<T>::ld(h + (long)r * ldh + c);
+    }
+    ab += g;
+  }
+  if (c < H) atomicAdd(dw + c, aw);
+  if (c == 0 && dbias) atomicAdd(dbias, ab);
+}
+
+// Masked cross-entropy, reduction = sum, ignore_index: one wave per row.
+// loss += sum_r [t_r != ignore] (logsumexp(l_r) - l_r[t_r]);  dlogits[r] = softmax(l_r) - onehot(t_r) (0 if ignored)
+__global__ __launch_bounds__(64) void ce_kernel(const float* __restrict__ logits, long ld, const long* __restrict__ target,
+                                                long ignore, float* __restrict__ loss, float* __restrict__ dlogits, long lddl,
+                                                int rows, int V) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const long t = target[r];
+  if (t == ignore) {
+    for (int c = lane; c < V; c += 64) dlogits[(long)r * lddl + c] = 0.f;
+    return;
+  }
+  float m = -INFINITY;
+  for (int c = lane; c < V; c += 64) m = fmaxf(m, logits[(long)r * ld + c]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < V; c += 64) s += __expf(logits[(long)r * ld + c] - m);
+  s = wave_sum(s);
+  const float lse = m + __logf(s);
+  for (int c = lane; c < V; c += 64) {
+    const float p = __expf(logits[(long)r * ld + c] - lse);
+    dlogits[(long)r * lddl + c] = p - (c == t ? 1.f : 0.f);
+  }
+  if (lane == 0) atomicAdd(loss, lse - logits[(long)r * ld + t]);
+}
+
+// Noun-phrase segment mean (aux head): out[s][:] = mean over tok in [off[s], off[s+1]) of x[rowidx[tok]][:]
+template <typename T>
+__global__ __launch_bounds__(256) void segmean_fwd_kernel(const T* __restrict__ x, long ldx, const int* __restrict__ off,
+                                                          const int* __restrict__ rowidx, T* __restrict__ out, int H) {
+  const int s = blockIdx.x, a = off[s], b = off[s + 1];
+  const float inv = 1.0f / (float)(b - a);
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float acc = 0.f;
+    for (int t = a; t < b; ++t) acc += DT<T>::ld(x + (long)rowidx[t] * ldx + c);
+    DT<T>::st(out + (long)s * H + c, acc * inv);
+  }
+}
+// dx32[rowidx[tok]][:] += dout[s][:] / len_s      (f32 scratch, atomics: a token may sit in several phrases)
+template <typename T>
+__global__ __launch_bounds__(256) void segmean_bwd_kernel(const T* __restrict__ dout, const int* __restrict__ off,
+                                                          const int* __restrict__ rowidx, float* __restrict__ dx32, int H) {
+  const int s = blockIdx.x, a = off[s], b = off[s + 1];
+  const float inv = 1.0f / (float)(b - a);
+  for (int c = threadIdx.x; c < H; c += 256) {
+    const float g = DT<T>::ld(dout + (long)s * H + c) * inv;
+    for (int t = a; t < b; ++t) atomicAdd(dx32 + (long)rowidx[t] * H + c, g);
+  }
+}
+
+// cos[r] = <x/max(|x|,eps), y/max(|y|,eps)>   (torch.nn.functional.cosine_similarity, eps 1e-8), one wave per row.
+// Saves nx, ny for backward.
+template <typename T>
+__global__ __launch_bounds__(64) void cosine_fwd_kernel(const T* __restrict__ x, const T* __restrict__ y, float eps,
+                                                        float* __restrict__ cosv, float* __restrict__ nx, float* __restrict__ ny,
+                                                        int H) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  float xy = 0.f, xx = 0.f, yy = 0.f;
+  for (int c = lane; c < H; c += 64) {
+    const float a = DT<T>::ld(x + (long)r * H + c), b = DT<T>::ld(y + (long)r * H + c);
+    xy += a * b; xx += a * a; yy += b * b;
+  }
+  xy = wave_sum(xy); xx = wave_sum(xx); yy = wave_sum(yy);
+  const float nxx = fmaxf(sqrtf(xx), eps), nyy = fmaxf(sqrtf(yy), eps);
+  if (lane == 0) { cosv[r] = xy / (nxx * nyy); nx[r] = nxx; ny[r] = nyy; }
+}
+// dx = g * (y/(nx ny) - cos * x / nx^2),  dy symmetric   (norms above eps)
+template <typename T>
+__global__ __launch_bounds__(64) void cosine_bwd_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                        const float* __restrict__ gcos, const float* __restrict__ cosv,
+                                                        const float* __restrict__ nx, const float* __restrict__ ny,
+                                                        T* __restrict__ dx, T* __restrict__ dy, int H) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float g = gcos[r], cv = cosv[r], a = nx[r], b = ny[r];
+  for (int c = lane; c < H; c += 64) {
+    const float xv = DT<T>::ld(x + (long)r * H + c), yv = DT<T>::ld(y + (long)r * H + c);
+    if (dx) DT<T>::st(dx + (long)r * H + c, g * (yv / (a * b) - cv * xv / (a * a)));
+    if (dy) DT<T>::st(dy + (long)r * H + c, g * (xv / (a * b) - cv * yv / (b * b)));
+  }
+}
+
+// dz = da * act'(z)   (act: 1 gelu-erf, 2 relu); used where the activation derivative cannot ride a GEMM epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(int act, const T* __restrict__ da, const T* __restrict__ z,
+                                                      T* __restrict__ dz, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    const f32x4 g = DT<T>::ld4(da + i), zz = DT<T>::ld4(z + i);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = g[j] * (act == 1 ? gelu_erf_grad(zz[j]) : (zz[j] > 0.f ? 1.f : 0.f));
+    DT<T>::st4(dz + i, o);
+  }
+}
+
+// Fused AdamW over a flat parameter arena (torch.optim.AdamW semantics, decoupled weight decay), plus
+// global-norm clipping folded in: g <- g * clip_coef[0].   Optionally refreshes a bf16 shadow of p.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, __bf16* __restrict__ shadow, long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                    const float* __restrict__ clip_coef) {
+  const float cc = clip_coef ? clip_coef[0] : 1.f;
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    f32x4 pv = *(f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gv[j] * cc;
+      pv[j] *= (1.f - lr * wd);
+      mv[j] = b1 * mv[j] + (1.f - b1) * gg;
+      vv[j] = b2 * vv[j] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vv[j]) / sqrtf(bc2) + eps;
+      pv[j] -= (lr / bc1) * mv[j] / denom;
+    }
+    *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
+    if (shadow) {
+      bf16x4 s = {(__bf16)pv[0], (__bf16)pv[1], (__bf16)pv[2], (__bf16)pv[3]};
+      *(bf16x4*)(shadow + i) = s;
+    }
+  }
+}
+
+// sumsq[0] += sum g^2
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float a = 0.f;
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    const f32x4 v = *(const f32x4*)(g + i);
+    a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+// coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))      (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef) {
+  coef[0] = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
+}
+
+}  // namespace
+
+#define BY_DTYPE(dtype, CALL_F32, CALL_BF16)        \
+  do {                                              \
+    if ((dtype) == VLNI_F32) { CALL_F32; }          \
+    else if ((dtype) == VLNI_BF16) { CALL_BF16; }   \
+    else { vlni_set_error("bad dtype %d", (dtype)); return VLNI_EINVAL; } \
+  } while (0)
+
+extern "C" int vlni_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n, void* stream) {
+  VLNI_CHECK(n > 0, VLNI_EINVAL, "cast: n=%ld", n);
+  dim3 grid((unsigned)std::min<long>(2048, (n / 4 + 255) / 256 + 1)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == VLNI_F32 && dst_dtype == VLNI_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, __bf16>), grid, block, 0, st, (const float*)src, (__bf16*)dst, n);
+  else if (src_dtype == VLNI_BF16 && dst_dtype == VLNI_F32)
+    hipLaunchKernelGGL((cast_kernel<__bf16, float>), grid, block, 0, st, (const __bf16*)src, (float*)dst, n);
+  else if (src_dtype == VLNI_F32 && dst_dtype == VLNI_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, st, (const float*)src, (float*)dst, n);
+  else if (src_dtype == VLNI_BF16 && dst_dtype == VLNI_BF16)
+    hipLaunchKernelGGL((cast_kernel<__bf16, __bf16>), grid, block, 0, st, (const __bf16*)src, (__bf16*)dst, n);
+  else { vlni_set_error("cast: bad dtypes %d %d", src_dtype, dst_dtype); return VLNI_EINVAL; }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_transpose(int src_dtype, int dst_dtype, const void* src, long lds_, void* dst, long ldd, int R, int C,
+                              int Rpad, void* stream) {
+  VLNI_CHECK(R > 0 && C > 0 && Rpad >= R && ldd >= Rpad && lds_ >= C, VLNI_EINVAL, "transpose: R=%d C=%d Rpad=%d", R, C, Rpad);
+  dim3 grid(cdiv(C, 64), cdiv(Rpad, 64)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == VLNI_F32 && dst_dtype == VLNI_BF16)
+    hipLaunchKernelGGL((transpose_kernel<float, __bf16>), grid, block, 0, st, (const float*)src, lds_, (__bf16*)dst, ldd, R, C, Rpad);
+  else if (src_dtype == VLNI_BF16 && dst_dtype == VLNI_BF16)
+    hipLaunchKernelGGL((transpose_kernel<__bf16, __bf16>), grid, block, 0, st, (const __bf16*)src, lds_, (__bf16*)dst, ldd, R, C, Rpad);
+  else if (src_dtype == VLNI_F32 && dst_dtype == VLNI_F32)
+    hipLaunchKernelGGL((transpose_kernel<float, float>), grid, block, 0, st, (const float*)src, lds_, (float*)dst, ldd, R, C, Rpad);
+  else { vlni_set_error("transpose: bad dtypes %d %d", src_dtype, dst_dtype); return VLNI_EINVAL; }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_colsum(int dtype, const void* x, long ldx, int rows, int N, float* out, void* stream) {
+  VLNI_CHECK(rows > 0 && N > 0, VLNI_EINVAL, "colsum: rows=%d N=%d", rows, N);
+  dim3 grid(cdiv(N, 256), std::max(1, std::min(rows / 32, 256))), block(256);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, ldx, rows, N, out),
+           hipLaunchKernelGGL((colsum_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)x, ldx, rows, N, out));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_smallk_linear_fwd(int dtype, const float* x, long ldx, const float* W, const float* b, void* y, long ldy,
+                                      int rows, int N, int K, void* stream) {
+  VLNI_CHECK(K >= 1 && K <= 16 && rows > 0 && N > 0, VLNI_EINVAL, "smallk_fwd: rows=%d N=%d K=%d", rows, N, K);
+  dim3 grid(cdiv(N, 256), std::min(rows, 1024)), block(256);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((smallk_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, x, ldx, W, b, (float*)y, ldy, rows, N, K),
+           hipLaunchKernelGGL((smallk_fwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, x, ldx, W, b, (__bf16*)y, ldy, rows, N, K));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_smallk_linear_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, float* dW, float* db,
+                                      int rows, int N, int K, void* stream) {
+  VLNI_CHECK(K >= 1 && K <= 16 && rows > 0 && N > 0, VLNI_EINVAL, "smallk_bwd: rows=%d N=%d K=%d", rows, N, K);
+  dim3 grid(cdiv(N, 256), std::max(1, std::min(rows / 16, 128))), block(256);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((smallk_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dy, lddy, x, ldx, dW, db, rows, N, K),
+           hipLaunchKernelGGL((smallk_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)dy, lddy, x, ldx, dW, db, rows, N, K));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_scatter_add_rows(int dtype, const void* src, long lds_, const long* idx, float* table_grad, int rows,
+                                     int H, void* stream) {
+  VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "scatter_add_rows: rows=%d H=%d", rows, H);
+  dim3 grid(std::min(rows, 2048)), block(256);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((scatter_add_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, lds_, idx, table_grad, rows, H),
+           hipLaunchKernelGGL((scatter_add_rows_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_seqmean_fwd(int dtype, const void* x, void* out, int B, int S, int H, void* stream) {
+  VLNI_CHECK(B > 0 && S > 0 && H > 0, VLNI_EINVAL, "seqmean_fwd: %d %d %d", B, S, H);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_fwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, B, S, H),
+           hipLaunchKernelGGL((seqmean_fwd_kernel<__bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)out, B, S, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, int B, int S, int H, void* stream) {
+  VLNI_CHECK(B > 0 && S > 0 && H > 0, VLNI_EINVAL, "seqmean_bwd: %d %d %d", B, S, H);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_bwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)dout, (float*)dx, B, S, H),
+           hipLaunchKernelGGL((seqmean_bwd_kernel<__bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, (__bf16*)dx, B, S, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_rowdot_fwd(int dtype, const void* h, long ldh, const float* w, const float* bias,
+                               const unsigned char* mask, float* out, int rows, int H, void* stream) {
+  VLNI_CHECK(rows > 0 && H % 4 == 0 && ldh % 4 == 0, VLNI_EINVAL, "rowdot_fwd: rows=%d H=%d", rows, H);
+  dim3 grid(std::min(cdiv(rows, 4), 1024)), block(256);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((rowdot_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)h, ldh, w, bias, mask, out, rows, H),
+           hipLaunchKernelGGL((rowdot_fwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)h, ldh, w, bias, mask, out, rows, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_rowdot_bwd(int dtype, const float* dl, const void* h, long ldh, const float* w, const unsigned char* mask,
+                               void* dh, long lddh, float* dw, float* dbias, int rows, int H, void* stream) {
+  VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "rowdot_bwd: rows=%d H=%d", rows, H);
+  dim3 grid(cdiv(H, 256), 1), block(256);   // one row slab: dh rows are written exactly once
+  BY_DTYPE(dtype, hipLaunchKernelGGL((rowdot_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, dl, (const float*)h, ldh, w, mask, (float*)dh, lddh, dw, dbias, rows, H),
+           hipLaunchKernelGGL((rowdot_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, dl, (const __bf16*)h, ldh, w, mask, (__bf16*)dh, lddh, dw, dbias, rows, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_cross_entropy(const float* logits, long ld, const long* target, long ignore_index, float* loss_sum,
+                                  float* dlogits, long lddl, int rows, int V, void* stream) {
+  VLNI_CHECK(rows > 0 && V > 0, VLNI_EINVAL, "cross_entropy: rows=%d V=%d", rows, V);
+  hipLaunchKernelGGL(ce_kernel, dim3(rows), dim3(64), 0, (hipStream_t)stream, logits, ld, target, ignore_index, loss_sum, dlogits, lddl, rows, V);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_segment_mean_fwd(int dtype, const void* x, long ldx, const int* seg_off, const int* rowidx, void* out,
+                                     int nseg, int H, void* stream) {
+  VLNI_CHECK(nseg > 0 && H > 0, VLNI_EINVAL, "segment_mean_fwd: nseg=%d H=%d", nseg, H);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((segmean_fwd_kernel<float>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, seg_off, rowidx, (float*)out, H),
+           hipLaunchKernelGGL((segmean_fwd_kernel<__bf16>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, ldx, seg_off, rowidx, (__bf16*)out, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_segment_mean_bwd(int dtype, const void* dout, const int* seg_off, const int* rowidx, float* dx32, int nseg,
+                                     int H, void* stream) {
+  VLNI_CHECK(nseg > 0 && H > 0, VLNI_EINVAL, "segment_mean_bwd: nseg=%d H=%d", nseg, H);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((segmean_bwd_kernel<float>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const float*)dout, seg_off, rowidx, dx32, H),
+           hipLaunchKernelGGL((segmean_bwd_kernel<__bf16>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, seg_off, rowidx, dx32, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_cosine_fwd(int dtype, const void* x, const void* y, float eps, float* cosv, float* nx, float* ny, int rows,
+                               int H, void* stream) {
+  VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "cosine_fwd: rows=%d H=%d", rows, H);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((cosine_fwd_kernel<float>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const float*)x, (const float*)y, eps, cosv, nx, ny, H),
+           hipLaunchKernelGGL((cosine_fwd_kernel<__bf16>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const __bf16*)x, (const __bf16*)y, eps, cosv, nx, ny, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_cosine_bwd(int dtype, const void* x, const void* y, const float* gcos, const float* cosv, const float* nx,
+                               const float* ny, void* dx, void* dy, int rows, int H, void* stream) {
+  VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "cosine_bwd: rows=%d H=%d", rows, H);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((cosine_bwd_kernel<float>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const float*)x, (const float*)y, gcos, cosv, nx, ny, (float*)dx, (float*)dy, H),
+           hipLaunchKernelGGL((cosine_bwd_kernel<__bf16>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const __bf16*)x, (const __bf16*)y, gcos, cosv, nx, ny, (__bf16*)dx, (__bf16*)dy, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_act_bwd(int dtype, int act, const void* da, const void* z, void* dz, long n, void* stream) {
+  VLNI_CHECK(n > 0 && n % 4 == 0 && (act == 1 || act == 2), VLNI_EINVAL, "act_bwd: n=%ld act=%d", n, act);
+  dim3 grid((unsigned)std::min<long>(2048, (n / 4 + 255) / 256)), block(256);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((act_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, act, (const float*)da, (const float*)z, (float*)dz, n),
+           hipLaunchKernelGGL((act_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, act, (const __bf16*)da, (const __bf16*)z, (__bf16*)dz, n));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, int step, const float* clip_coef, void* stream) {
+  VLNI_CHECK(n > 0 && n % 4 == 0 && step >= 1, VLNI_EINVAL, "adamw_step: n=%ld (multiple of 4) step=%d", n, step);
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  dim3 grid((unsigned)std::min<long>(4096, (n / 4 + 255) / 256)), block(256);
+  hipLaunchKernelGGL(adamw_kernel, grid, block, 0, (hipStream_t)stream, p, g, m, v, (__bf16*)bf16_shadow, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2, clip_coef);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// sumsq[0] += sum(g^2) (caller zeroes sumsq); then vlni_clip_coef turns it into the clip_grad_norm_ factor.
+extern "C" int vlni_sumsq(const float* g, long n, float* sumsq, void* stream) {
+  VLNI_CHECK(n > 0 && n % 4 == 0, VLNI_EINVAL, "sumsq: n=%ld", n);
+  dim3 grid((unsigned)std::min<long>(2048, (n / 4 + 255) / 256)), block(256);
+  hipLaunchKernelGGL(sumsq_kernel, grid, block, 0, (hipStream_t)stream, g, n, sumsq);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream) {
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}

@@ -1,0 +1,214 @@
+// MFMA GEMM for gfx950:  C[M,N] = epilogue( A[M,K] * B[N,K]^T )      ("NT": both operands K-contiguous)
+//
+// One kernel template serves every dense contraction of the HAMT/DUET hot path:
+//   forward   Y  = X  * W^T          (A = X [rows,in],  B = W  [out,in])
+//   dgrad     dX = dY * (W^T)^T      (A = dY [rows,out], B = W^T [in,out], a transposed shadow copy)
+//   wgrad     dW = dY^T * X          (A = dY^T [out,rows], B = X^T [in,rows]; split over rows, f32 atomics)
+// replacing the nn.Linear / torch.matmul calls of
+//   VLN-HAMT/finetune_src/models/vilmodel_cmt.py:101-103,145,174,187,327-329 and their autograd.
+//
+// Geometry (64-wide waves): 128x128 output tile, 256 threads = 4 waves in 2x2, each wave a 64x64
+// sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs). A k-tile is 128 BYTES of K per row for
+// both dtypes (bf16: BK=64 -> v_mfma_f32_32x32x16_bf16; f32: BK=32 -> v_mfma_f32_32x32x2_f32, the
+// exact-fp32 parity path). Global->register->LDS staging in 16-B chunks with an XOR swizzle
+// (chunk ^ ((row>>1)&7)) so the ds_read_b128 fragment reads of 16 different rows hit 16 different
+// 16-B slots of the 256-B bank row; two LDS stages, next tile's global loads issued before the MFMAs
+// of the current one (issue-early / write-late), one barrier per k-tile. Tiles are dealt to XCDs in
+// contiguous chunks (bijective remap) so the N-tiles sharing an A row-panel hit one L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, ROWB = 128;     // ROWB: bytes of K per tile row
+constexpr int NT = 256;
+
+struct GemmP {
+  const char* A; long lda;      // byte pointers; ld in ELEMENTS
+  const char* B; long ldb;
+  char* C; long ldc;
+  int M, N, K;
+  const float* bias;            // [N] or null
+  int act;                      // 0 none, 1 gelu(erf), 2 relu
+  const char* residual; long ldr;   // added after act
+  char* preact; long ldp;       // value before act (after bias), same dtype as C
+  const char* dact_src; long ldd; int dact;   // multiply by act'(src) (1 gelu', 2 relu')
+  float alpha;
+  int atomic_f32;               // C is float, accumulate with atomics (split-K wgrad)
+  int kt_per_split;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <typename T> struct Mma;
+template <> struct Mma<__bf16> {
+  static constexpr int KSTEPS = 4;   // 4 x k16 per 128-byte tile row
+  __device__ static __forceinline__ void step(const char* As, const char* Bs, int kk, int rowA0, int rowB0, int r, int h,
+                                              f32x16 (&acc)[2][2]) {
+    const int chunk = kk * 2 + h;
+    bf16x8 a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)(As + lds_off(rowA0 + i * 32 + r, chunk));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)(Bs + lds_off(rowB0 + j * 32 + r, chunk));
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KSTEPS = 16;  // 16 x k2 per 128-byte tile row (BK = 32 floats)
+  __device__ static __forceinline__ void step(const char* As, const char* Bs, int kk, int rowA0, int rowB0, int r, int h,
+                                              f32x16 (&acc)[2][2]) {
+    const int k = kk * 2 + h;
+    const int chunk = k >> 2, within = (k & 3) * 4;
+    float a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = *(const float*)(As + lds_off(rowA0 + i * 32 + r, chunk) + within);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = *(const float*)(Bs + lds_off(rowB0 + j * 32 + r, chunk) + within);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
+  constexpr int ES = sizeof(T);
+  constexpr int BK = ROWB / ES;        // elements of K per tile
+  constexpr int EPC = 16 / ES;         // elements per 16-B chunk
+  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * ROWB];   // 64 KiB
+  constexpr int STAGE = (BM + BN) * ROWB;   // A tile then B tile
+
+  // ---- tile assignment: contiguous chunk of the tile list per XCD (bijective for any grid) ----
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int m0 = (wgid / ntn) * BM, n0 = (wgid % ntn) * BN;
+
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt0 = blockIdx.z * p.kt_per_split;
+  const int kt1 = min(nkt, kt0 + p.kt_per_split);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  const int lc = tid & 7, lr = tid >> 3;       // staging: chunk column, first row
+
+  // per-thread global row pointers (rows clamped: out-of-range rows load valid memory, never stored)
+  const char* ga[4];
+  const char* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = min(m0 + lr + 32 * i, p.M - 1), rb = min(n0 + lr + 32 * i, p.N - 1);
+    ga[i] = p.A + ((long)ra * p.lda + lc * EPC) * ES;
+    gb[i] = p.B + ((long)rb * p.ldb + lc * EPC) * ES;
+  }
+  uint4 sa[4], sb[4];
+  auto gload = [&](int kt) {
+    const long koff = (long)kt * BK;
+    const bool ok = (koff + lc * EPC) < p.K;   // K is a multiple of EPC: a chunk is all-in or all-out
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sa[i] = ok ? *(const uint4*)(ga[i] + koff * ES) : make_uint4(0, 0, 0, 0);
+      sb[i] = ok ? *(const uint4*)(gb[i] + koff * ES) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(uint4*)(smem + buf * STAGE + lds_off(lr + 32 * i, lc)) = sa[i];
+      *(uint4*)(smem + buf * STAGE + BM * ROWB + lds_off(lr + 32 * i, lc)) = sb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+
+  if (kt0 < kt1) {
+    gload(kt0);
+    lstore(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool more = (kt + 1) < kt1;
+      if (more) gload(kt + 1);                       // issue early: latency hides under the MFMAs below
+#pragma unroll
+      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::step(smem + cur * STAGE, smem + cur * STAGE + BM * ROWB, kk, wr * 64, wc * 64, r, h, acc);
+      if (more) lstore(cur ^ 1);                     // write late: other stage, nobody reads it now
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (x&3) + 8*(x>>2) + 4*(lane>>5) ----
+  T* C = (T*)p.C;
+  float* Cf = (float*)p.C;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wc * 64 + j * 32 + r;
+    if (col >= p.N) continue;
+    const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int row = m0 + wr * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+        if (row >= p.M) continue;
+        float v = acc[i][j][x] * p.alpha + bv;
+        if (p.atomic_f32) {
+          atomicAdd(&Cf[(long)row * p.ldc + col], v);
+          continue;
+        }
+        if (p.preact) DT<T>::st((T*)p.preact + (long)row * p.ldp + col, v);
+        if (p.dact) {
+          const float z = DT<T>::ld((const T*)p.dact_src + (long)row * p.ldd + col);
+          v *= (p.dact == 1) ? gelu_erf_grad(z) : (z > 0.f ? 1.f : 0.f);
+        }
+        if (p.act == 1) v = gelu_erf(v);
+        else if (p.act == 2) v = fmaxf(v, 0.f);
+        if (p.residual) v += DT<T>::ld((const T*)p.residual + (long)row * p.ldr + col);
+        DT<T>::st(C + (long)row * p.ldc + col, v);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
+                            int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
+                            const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,
+                            void* stream) {
+  VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt: bad dtype %d", dtype);
+  VLNI_CHECK(M > 0 && N > 0 && K > 0, VLNI_EINVAL, "gemm_nt: empty problem %d %d %d", M, N, K);
+  const int es = dtype == VLNI_F32 ? 4 : 2, epc = 16 / es, bk = ROWB / es;
+  VLNI_CHECK(K % epc == 0 && lda % epc == 0 && ldb % epc == 0, VLNI_EINVAL,
+             "gemm_nt: K/lda/ldb (%d/%ld/%ld) must be multiples of %d", K, lda, ldb, epc);
+  VLNI_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, VLNI_EINVAL, "gemm_nt: A/B must be 16-B aligned");
+  VLNI_CHECK(lda >= K && ldb >= K && ldc >= N, VLNI_EINVAL, "gemm_nt: leading dims too small");
+  VLNI_CHECK(!(atomic_f32 && (bias || act || residual || preact || dact)), VLNI_EINVAL, "gemm_nt: atomic output takes no epilogue");
+  VLNI_CHECK(split_k >= 1 && (split_k == 1 || atomic_f32), VLNI_EINVAL, "gemm_nt: split_k needs atomic_f32");
+  GemmP p;
+  p.A = (const char*)A; p.lda = lda; p.B = (const char*)B; p.ldb = ldb; p.C = (char*)C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.residual = (const char*)residual; p.ldr = ldr;
+  p.preact = (char*)preact; p.ldp = ldp; p.dact_src = (const char*)dact_src; p.ldd = ldd; p.dact = dact;
+  p.alpha = alpha; p.atomic_f32 = atomic_f32;
+  const int nkt = cdiv(K, bk);
+  p.kt_per_split = cdiv(nkt, split_k);
+  const int splits = cdiv(nkt, p.kt_per_split);
+  dim3 grid(cdiv(M, BM) * cdiv(N, BN), 1, splits);
+  if (dtype == VLNI_F32)
+    hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(gemm_nt_kernel<__bf16>, grid, dim3(NT), 0, (hipStream_t)stream, p);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}

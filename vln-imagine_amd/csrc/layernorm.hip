@@ -1,0 +1,274 @@
+// Row LayerNorm forward/backward (+ the multi-source "sum then LayerNorm" used by every embedding
+// block), HBM-bound: one 64-lane wave per row, the whole row in registers (16-B/8-B vector loads,
+// two-pass variance), wavefront-shuffle reductions, no LDS on the forward path.
+// Restates BertLayerNorm = torch.nn.LayerNorm at
+//   VLN-HAMT/finetune_src/models/vilmodel_cmt.py:22,71,147,189,536-542,593-616 (eps 1e-12)
+//   VLN-DUET/map_nav_src/models/transformer.py:170-182 (eps 1e-5).
+#include "common.h"
+
+namespace {
+
+constexpr int WAVES = 4;
+
+template <typename T, int NC>     // H = 256 * NC
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows) {
+  constexpr int H = 256 * NC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 gv[NC], bv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    gv[c] = *(const f32x4*)(g + c * 256 + lane * 4);
+    bv[c] = *(const f32x4*)(b + c * 256 + lane * 4);
+  }
+  for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
+    f32x4 v[NC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      v[c] = DT<T>::ld4(x + (long)row * ldx + c * 256 + lane * 4);
+      s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+    const float mu = wave_sum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[c][j] - mu;
+        q += d * d;
+      }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / H) + eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mu) * rs * gv[c][j] + bv[c][j];
+      DT<T>::st4(y + (long)row * ldy + c * 256 + lane * 4, o);
+    }
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+  }
+}
+
+// dx = rstd * (g*dy - mean_H(g*dy) - xhat * mean_H(g*dy*xhat)); dgamma += sum_rows dy*xhat; dbeta += sum_rows dy
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx,
+                                                     const float* __restrict__ g, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx, long lddx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+  constexpr int H = 256 * NC;
+  __shared__ float red[WAVES][2][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 gv[NC], pg[NC], pb[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    gv[c] = *(const f32x4*)(g + c * 256 + lane * 4);
+    pg[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    pb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
+    const float mu = mean[row], rs = rstd[row];
+    f32x4 xh[NC], d[NC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const f32x4 xv = DT<T>::ld4(x + (long)row * ldx + c * 256 + lane * 4);
+      d[c] = DT<T>::ld4(dy + (long)row * lddy + c * 256 + lane * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[c][j] = (xv[j] - mu) * rs;
+        pg[c][j] += d[c][j] * xh[c][j];
+        pb[c][j] += d[c][j];
+        const float dg = d[c][j] * gv[c][j];
+        s1 += dg;
+        s2 += dg * xh[c][j];
+      }
+    }
+    s1 = wave_sum(s1) * (1.0f / H);
+    s2 = wave_sum(s2) * (1.0f / H);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = rs * (d[c][j] * gv[c][j] - s1 - xh[c][j] * s2);
+      DT<T>::st4(dx + (long)row * lddx + c * 256 + lane * 4, o);
+    }
+  }
+  if (dgamma == nullptr) return;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[wave][0][c * 256 + lane * 4 + j] = pg[c][j];
+      red[wave][1][c * 256 + lane * 4 + j] = pb[c][j];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H; i += 256) {
+    float a = 0.f, bsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      a += red[w][0][i];
+      bsum += red[w][1][i];
+    }
+    atomicAdd(dgamma + i, a);
+    atomicAdd(dbeta + i, bsum);
+  }
+}
+
+// ---- sum of up to 4 row sources, then LayerNorm --------------------------------------------------
+struct SumSrc {
+  const void* p;        // base
+  long ld;              // row stride in elements (0 = one broadcast row)
+  const long* idx;      // optional row gather: row r reads p + idx[r]*ld
+  int is_f32;           // 1: float source (parameter tables); 0: activation dtype T
+};
+struct SumP {
+  SumSrc s[4];
+  int n;
+};
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void sum_ln_fwd_kernel(SumP sp, const float* __restrict__ g, const float* __restrict__ b,
+                                                         float eps, T* __restrict__ y, long ldy, T* __restrict__ xsum,
+                                                         long ldxs, float* __restrict__ mean, float* __restrict__ rstd,
+                                                         int rows) {
+  constexpr int H = 256 * NC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
+    f32x4 v[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < sp.n; ++k) {
+      const SumSrc& s = sp.s[k];
+      const long r = s.idx ? s.idx[row] : (long)row;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const long off = r * s.ld + c * 256 + lane * 4;
+        const f32x4 t = s.is_f32 ? *(const f32x4*)((const float*)s.p + off) : DT<T>::ld4((const T*)s.p + off);
+        v[c] += t;
+      }
+    }
+    if (xsum) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        DT<T>::st4(xsum + (long)row * ldxs + c * 256 + lane * 4, v[c]);
+        v[c] = DT<T>::ld4(xsum + (long)row * ldxs + c * 256 + lane * 4);   // normalise exactly what backward will re-read
+      }
+    }
+    float s0 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s0 += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    const float mu = wave_sum(s0) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[c][j] - mu;
+        q += d * d;
+      }
+    const float rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / H) + eps);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const f32x4 gv = *(const f32x4*)(g + c * 256 + lane * 4), bv = *(const f32x4*)(b + c * 256 + lane * 4);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mu) * rs * gv[j] + bv[j];
+      DT<T>::st4(y + (long)row * ldy + c * 256 + lane * 4, o);
+    }
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+  }
+}
+
+int ln_grid(int rows) { return max(1, min(cdiv(rows, WAVES), 2048)); }
+
+}  // namespace
+
+#define LN_DISPATCH(KERNEL, T, ...)                                                                      \
+  do {                                                                                                   \
+    const int nc = H / 256;                                                                              \
+    dim3 grid(ln_grid(rows)), block(256);                                                                \
+    hipStream_t st = (hipStream_t)stream;                                                                \
+    if (nc == 3) hipLaunchKernelGGL((KERNEL<T, 3>), grid, block, 0, st, __VA_ARGS__);                    \
+    else if (nc == 2) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, st, __VA_ARGS__);               \
+    else hipLaunchKernelGGL((KERNEL<T, 1>), grid, block, 0, st, __VA_ARGS__);                            \
+  } while (0)
+
+static int ln_check(const char* who, int dtype, int rows, int H, long ld) {
+  VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "%s: bad dtype %d", who, dtype);
+  VLNI_CHECK(H == 256 || H == 512 || H == 768, VLNI_EUNSUP, "%s: H=%d not in {256,512,768}", who, H);
+  VLNI_CHECK(rows > 0 && ld >= H && ld % 4 == 0, VLNI_EINVAL, "%s: rows=%d ld=%ld", who, rows, ld);
+  return VLNI_OK;
+}
+
+extern "C" int vlni_layernorm_fwd(int dtype, const void* x, long ldx, const float* gamma, const float* beta, float eps,
+                                  void* y, long ldy, float* mean, float* rstd, int rows, int H, void* stream) {
+  int rc = ln_check("layernorm_fwd", dtype, rows, H, ldx < ldy ? ldx : ldy);
+  if (rc) return rc;
+  if (dtype == VLNI_F32) {
+    using TT = float;
+    const float* xx = (const float*)x; float* yy = (float*)y;
+    LN_DISPATCH(ln_fwd_kernel, TT, xx, ldx, gamma, beta, eps, yy, ldy, mean, rstd, rows);
+  } else {
+    using TT = __bf16;
+    const __bf16* xx = (const __bf16*)x; __bf16* yy = (__bf16*)y;
+    LN_DISPATCH(ln_fwd_kernel, TT, xx, ldx, gamma, beta, eps, yy, ldy, mean, rstd, rows);
+  }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const float* gamma,
+                                  const float* mean, const float* rstd, void* dx, long lddx, float* dgamma, float* dbeta,
+                                  int rows, int H, void* stream) {
+  int rc = ln_check("layernorm_bwd", dtype, rows, H, ldx < lddx ? (ldx < lddy ? ldx : lddy) : (lddx < lddy ? lddx : lddy));
+  if (rc) return rc;
+  VLNI_CHECK((dgamma == nullptr) == (dbeta == nullptr), VLNI_EINVAL, "layernorm_bwd: dgamma/dbeta both or neither");
+  if (dtype == VLNI_F32) {
+    using TT = float;
+    const float* d = (const float*)dy; const float* xx = (const float*)x; float* o = (float*)dx;
+    LN_DISPATCH(ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows);
+  } else {
+    using TT = __bf16;
+    const __bf16* d = (const __bf16*)dy; const __bf16* xx = (const __bf16*)x; __bf16* o = (__bf16*)dx;
+    LN_DISPATCH(ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows);
+  }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// y = LayerNorm(sum_k src_k); xsum (optional) receives the pre-norm sum for the backward pass.
+// src arrays have n (1..4) entries: base pointer, row stride, optional int64 row-gather index, f32 flag.
+extern "C" int vlni_sum_layernorm_fwd(int dtype, int n, const void* const* src, const long* src_ld,
+                                      const long* const* src_idx, const int* src_is_f32, const float* gamma,
+                                      const float* beta, float eps, void* y, long ldy, void* xsum, long ldxs, float* mean,
+                                      float* rstd, int rows, int H, void* stream) {
+  int rc = ln_check("sum_layernorm_fwd", dtype, rows, H, ldy);
+  if (rc) return rc;
+  VLNI_CHECK(n >= 1 && n <= 4, VLNI_EINVAL, "sum_layernorm_fwd: n=%d", n);
+  SumP sp;
+  sp.n = n;
+  for (int i = 0; i < n; ++i) {
+    sp.s[i].p = src[i]; sp.s[i].ld = src_ld[i]; sp.s[i].idx = src_idx ? src_idx[i] : nullptr;
+    sp.s[i].is_f32 = src_is_f32[i];
+    VLNI_CHECK(src_ld[i] % 4 == 0, VLNI_EINVAL, "sum_layernorm_fwd: src %d ld %ld", i, src_ld[i]);
+  }
+  if (dtype == VLNI_F32) {
+    using TT = float;
+    float* yy = (float*)y; float* xs = (float*)xsum;
+    LN_DISPATCH(sum_ln_fwd_kernel, TT, sp, gamma, beta, eps, yy, ldy, xs, ldxs, mean, rstd, rows);
+  } else {
+    using TT = __bf16;
+    __bf16* yy = (__bf16*)y; __bf16* xs = (__bf16*)xsum;
+    LN_DISPATCH(sum_ln_fwd_kernel, TT, sp, gamma, beta, eps, yy, ldy, xs, ldxs, mean, rstd, rows);
+  }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}

@@ -1,0 +1,75 @@
+"""`VLNBertCMT` / `Critic` wrappers (drop-in for VLN-HAMT/finetune_src/models/model_HAMT.py:13-96,289-300):
+feature dropout on the caller's inputs, mode dispatch into NavCMT, state = txt[CLS] * hist[CLS]."""
+import torch
+import torch.nn as nn
+
+from vln_imagine_amd import ops
+from .vlnbert_init import get_vlnbert_models
+
+
+def length2mask(length, size=None, device=None):
+    """True where position >= length (utils/misc.py:13-18)."""
+    size = int(max(length)) if size is None else size
+    ar = torch.arange(size, dtype=torch.int64, device=device)
+    return ar[None, :] > (torch.as_tensor(length, dtype=torch.int64, device=device) - 1)[:, None]
+
+
+class VLNBertCMT(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.args = args
+        self.vln_bert = get_vlnbert_models(args, config=None)
+        self.drop_env = nn.Dropout(p=args.feat_dropout)
+
+    def forward(self, mode, txt_ids=None, txt_masks=None, txt_embeds=None, hist_img_feats=None, hist_ang_feats=None,
+                hist_pano_img_feats=None, hist_pano_ang_feats=None, hist_embeds=None, hist_lens=None, ob_step=None,
+                ob_img_feats=None, ob_ang_feats=None, ob_nav_types=None, ob_masks=None, imagine_pano_img_feats=None,
+                imagine_masks=None, imagine_embeds=None, align_txt_embeds=None, align_imagine_embeds=None,
+                sub_instr_segs=None, sub_instr_imag_flag=None, noun_phrase_segs=None, obs_instr_ids=None,
+                return_states=False, return_cross_attention_probs=False):
+        m = self.vln_bert
+        if mode == "language":
+            return m(mode, txt_ids=txt_ids, txt_masks=txt_masks)
+        if mode == "imagine":
+            if imagine_pano_img_feats is not None:
+                imagine_pano_img_feats = self.drop_env(imagine_pano_img_feats)
+            return m(mode, imagine_pano_img_feats=imagine_pano_img_feats, imagine_masks=imagine_masks)
+        if mode == "align_with_contrastive_loss":
+            return m(mode, align_txt_embeds=align_txt_embeds, txt_masks=txt_masks, align_imagine_embeds=align_imagine_embeds,
+                     imagine_masks=imagine_masks, sub_instr_segs=sub_instr_segs, sub_instr_imag_flag=sub_instr_imag_flag,
+                     noun_phrase_segs=noun_phrase_segs, obs_instr_ids=obs_instr_ids)
+        if mode == "history":
+            if hist_img_feats is not None:
+                hist_img_feats = self.drop_env(hist_img_feats)
+            if hist_pano_img_feats is not None:
+                hist_pano_img_feats = self.drop_env(hist_pano_img_feats)
+            step = torch.tensor([ob_step], dtype=torch.long, device=m.device) if ob_step is not None else None
+            return m(mode, hist_img_feats=hist_img_feats, hist_ang_feats=hist_ang_feats, ob_step_ids=step,
+                     hist_pano_img_feats=hist_pano_img_feats, hist_pano_ang_feats=hist_pano_ang_feats)
+        if mode == "visual":
+            hist = torch.stack(hist_embeds, 1)
+            hist_masks = length2mask(hist_lens, size=hist.size(1), device=hist.device).logical_not()
+            act_logits, txt_o, hist_o, ob_o = m(
+                mode, txt_embeds=txt_embeds, txt_masks=txt_masks, hist_embeds=hist, hist_masks=hist_masks,
+                ob_img_feats=self.drop_env(ob_img_feats), ob_ang_feats=ob_ang_feats, ob_nav_types=ob_nav_types,
+                ob_masks=ob_masks, imagine_embeds=imagine_embeds, imagine_masks=imagine_masks,
+                return_cross_attention_probs=return_cross_attention_probs)
+            if return_states:
+                states = hist_o[:, 0] if self.args.no_lang_ca else txt_o[:, 0] * hist_o[:, 0]
+                return act_logits, states
+            return (act_logits,)
+        raise NotImplementedError("wrong mode: %s" % mode)
+
+
+class Critic(nn.Module):
+    """state -> value, Linear(768,512) ReLU Dropout Linear(512,1) (model_HAMT.py:289-300)."""
+
+    def __init__(self, args):
+        super().__init__()
+        self.state2value = nn.Sequential(nn.Linear(768, 512), nn.ReLU(), nn.Dropout(args.dropout), nn.Linear(512, 1))
+
+    def forward(self, state):
+        s = self.state2value
+        h = ops.linear(state, s[0].weight, s[0].bias, act=2)
+        h = s[2](h)
+        return ops.row_dot(h, s[3].weight, s[3].bias, None).squeeze()

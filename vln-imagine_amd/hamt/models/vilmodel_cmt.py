@@ -1,0 +1,525 @@
+"""MI355X-native HAMT `NavCMT` (drop-in for VLN-HAMT/finetune_src/models/vilmodel_cmt.py).
+
+Same constructor / forward(mode, ...) contract and the same state_dict keys as the reference
+(vilmodel_cmt.py:966-1205), but the modules below are only PARAMETER HOLDERS: all arithmetic is
+done by the fused HIP sublayer operators in vln_imagine_amd.ops (one autograd node per attention /
+FFN / bidirectional-cross-attention block). nn.Linear / nn.LayerNorm / nn.Embedding instances are
+used for their parameter registration and checkpoint compatibility, never for their forward.
+
+Numerics: `compute_dtype` float32 (parity gate, exact-fp32 MFMA) or bfloat16 (throughput;
+float32 master weights, bf16 shadows, float32 accumulation and LayerNorm/softmax statistics).
+Dropout: the fused blocks implement p = 0 / eval only; see DESIGN.md (gap list).
+"""
+import copy
+import os
+
+import torch
+from torch import nn
+
+from vln_imagine_amd import ops
+
+HID_EPS = 1e-12
+
+
+def _att(m):
+    """(wq,bq,wk,bk,wv,bv,wo,bo,gamma,beta) of a BertAttention / BertXAttention holder."""
+    core = m.self if hasattr(m, "self") else m.att
+    return (core.query.weight, core.query.bias, core.key.weight, core.key.bias, core.value.weight, core.value.bias,
+            m.output.dense.weight, m.output.dense.bias, m.output.LayerNorm.weight, m.output.LayerNorm.bias)
+
+
+def _ffn(inter, out):
+    return (inter.dense.weight, inter.dense.bias, out.dense.weight, out.dense.bias, out.LayerNorm.weight, out.LayerNorm.bias)
+
+
+# ---- parameter holders (names are checkpoint ABI) -------------------------------------------
+class BertEmbeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(c.vocab_size, c.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(c.max_position_embeddings, c.hidden_size)
+        self.token_type_embeddings = nn.Embedding(c.type_vocab_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class BertSelfAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        if c.hidden_size % c.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (c.hidden_size, c.num_attention_heads))
+        h = c.hidden_size
+        self.query, self.key, self.value = nn.Linear(h, h), nn.Linear(h, h), nn.Linear(h, h)
+
+
+BertOutAttention = BertSelfAttention
+
+
+class BertSelfOutput(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self = BertSelfAttention(c)
+        self.output = BertSelfOutput(c)
+
+    def forward(self, x, kmask):
+        return ops.self_att_block(x, kmask, _att(self))
+
+
+class BertXAttention(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.att = BertOutAttention(c)
+        self.output = BertSelfOutput(c)
+
+
+class BertIntermediate(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.hidden_size, c.intermediate_size)
+
+
+class BertOutput(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.dense = nn.Linear(c.intermediate_size, c.hidden_size)
+        self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attention = BertAttention(c)
+        self.intermediate = BertIntermediate(c)
+        self.output = BertOutput(c)
+
+    def forward(self, x, kmask):
+        return ops.ffn_block(self.attention(x, kmask), _ffn(self.intermediate, self.output))
+
+
+class BertEncoder(nn.Module):
+    def __init__(self, c, n_layers):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(c) for _ in range(n_layers)])
+
+    def forward(self, x, kmask):
+        for l in self.layer:
+            x = l(x, kmask)
+        return x
+
+
+class LXRTXLayer(nn.Module):
+    """Cross-modal layer (reference vilmodel_cmt.py:366-445): bidirectional cross-attention with shared
+    weights on pre-update inputs, then per-stream self-attention and FFN: 5 fused nodes instead of ~45 kernels.
+    The four visualisation softmaxes of the reference (:391,393,438,439) are not computed."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.no_lang_ca = c.no_lang_ca
+        self.lang_self_att = BertAttention(c)
+        self.lang_inter = BertIntermediate(c)
+        self.lang_output = BertOutput(c)
+        self.visn_self_att = BertAttention(c)
+        self.visn_inter = BertIntermediate(c)
+        self.visn_output = BertOutput(c)
+        self.visual_attention = BertXAttention(c)
+
+    def forward(self, lang, lang_mask, visn, visn_mask):
+        if self.no_lang_ca:
+            visn = ops.xatt_block(visn, lang, lang_mask, _att(self.visual_attention))
+        else:
+            lang, visn = ops.xatt_pair_block(lang, visn, lang_mask, visn_mask, _att(self.visual_attention))
+            lang = ops.ffn_block(self.lang_self_att(lang, lang_mask), _ffn(self.lang_inter, self.lang_output))
+        visn = ops.ffn_block(self.visn_self_att(visn, visn_mask), _ffn(self.visn_inter, self.visn_output))
+        return lang, visn
+
+
+class LxmertEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(c) for _ in range(c.num_l_layers)])
+        if not c.update_lang_bert:
+            for p in self.layer.parameters():
+                p.requires_grad = False
+        self.h_layers = nn.ModuleList([BertLayer(c) for _ in range(c.num_h_layers)]) if c.num_h_layers > 0 else None
+        self.r_layers = nn.ModuleList([BertLayer(c) for _ in range(c.num_r_layers)]) if c.num_r_layers > 0 else None
+        self.x_layers = nn.ModuleList([LXRTXLayer(c) for _ in range(c.num_x_layers)])
+
+
+class _FeatEmbed(nn.Module):
+    """LN(Linear(img)) + LN(Linear(ang)) pair shared by observation / history / panorama embeddings."""
+
+    def _feat(self, img, ang, pre, dt):
+        il, iln = getattr(self, pre + "img_linear"), getattr(self, pre + "img_layer_norm")
+        al, aln = getattr(self, pre + "ang_linear"), getattr(self, pre + "ang_layer_norm")
+        ti = ops.layer_norm(ops.linear(img, il.weight, il.bias, out_dtype=dt), iln.weight, iln.bias, HID_EPS)
+        ta = ops.layer_norm(ops.smallk_linear(ang, al.weight, al.bias, dt), aln.weight, aln.bias, HID_EPS)
+        return ti, ta
+
+
+class ImageEmbeddings(_FeatEmbed):
+    def __init__(self, c):
+        super().__init__()
+        h = c.hidden_size
+        self.img_linear = nn.Linear(c.image_feat_size, h)
+        self.img_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.ang_linear = nn.Linear(c.angle_feat_size, h)
+        self.ang_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.nav_type_embedding = nn.Embedding(3, h)
+        self.layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+
+    def forward(self, img, ang, type_row, nav_types, dt):
+        B, S, _ = img.shape
+        ti, ta = self._feat(img, ang, "", dt)
+        srcs = [(ti, "dense", None), (ta, "dense", None), (type_row, "bcast", None)]
+        if nav_types is not None:
+            srcs.append((self.nav_type_embedding.weight, "gather", nav_types.reshape(-1).contiguous()))
+        y = ops.sum_layer_norm(srcs, self.layer_norm.weight, self.layer_norm.bias, B * S, dt, HID_EPS)
+        return y.view(B, S, -1)
+
+
+class HistoryEmbeddings(_FeatEmbed):
+    def __init__(self, c):
+        super().__init__()
+        h = c.hidden_size
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, h))
+        self.img_linear = nn.Linear(c.image_feat_size, h)
+        self.img_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.ang_linear = nn.Linear(c.angle_feat_size, h)
+        self.ang_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.position_embeddings = nn.Embedding(c.max_action_steps, h)
+        self.type_embedding = nn.Embedding(1, h)
+        self.layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.hist_enc_pano = c.hist_enc_pano
+        if c.hist_enc_pano:
+            self.pano_img_linear = nn.Linear(c.image_feat_size, h)
+            self.pano_img_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+            self.pano_ang_linear = nn.Linear(c.angle_feat_size, h)
+            self.pano_ang_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+            self.pano_encoder = BertEncoder(c, c.num_h_pano_layers)
+        else:
+            self.pano_encoder = None
+
+    def forward(self, img, ang, pos_ids, pano_img, pano_ang, dt):
+        g, b = self.layer_norm.weight, self.layer_norm.bias
+        if img is None:                                   # CLS path, reference :592-595
+            srcs = [(self.cls_token, "bcast", None), (self.type_embedding.weight, "bcast", None)]
+            return ops.sum_layer_norm(srcs, g, b, 1, dt, HID_EPS)
+        B = img.shape[0]
+        ti, ta = self._feat(img, ang, "", dt)
+        row = self.position_embeddings.weight[pos_ids].reshape(1, -1) + self.type_embedding.weight
+        srcs = [(ti, "dense", None), (ta, "dense", None), (row, "bcast", None)]
+        if self.pano_encoder is not None:                 # :603-614, pano mask is all ones -> no key mask
+            Bp, P, _ = pano_img.shape
+            pi, pa = self._feat(pano_img, pano_ang, "pano_", dt)
+            pe = (pi + pa).view(Bp, P, -1)
+            srcs.append((ops.seq_mean(self.pano_encoder(pe, None)), "dense", None))
+        return ops.sum_layer_norm(srcs, g, b, B, dt, HID_EPS)
+
+
+class BypassImagineEmbeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.type_embedding = nn.Embedding(1, c.hidden_size)
+
+    def forward(self, feats, masks, dt):
+        return (feats + self.type_embedding.weight[0]).to(dt)      # reference :625-631 (one broadcast add)
+
+
+class ImagineEmbeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        h = c.hidden_size
+        self.position_embeddings = nn.Embedding(c.max_imagination_len, h)
+        self.type_embedding = nn.Embedding(1, h)
+        self.layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.pano_img_linear = nn.Linear(c.image_feat_size, h)
+        self.pano_img_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.pano_encoder = BertEncoder(c, c.num_h_pano_layers)
+        self.max_imagination_len = c.max_imagination_len
+
+    def forward(self, feats, masks, dt):                 # reference :659-703
+        B, n, _ = feats.shape
+        assert n < self.max_imagination_len, "imagination length out of bounds."
+        x = feats + self.position_embeddings.weight[:n] + self.type_embedding.weight[0]
+        x = ops.layer_norm(ops.linear(x, self.pano_img_linear.weight, self.pano_img_linear.bias, out_dtype=dt),
+                           self.pano_img_layer_norm.weight, self.pano_img_layer_norm.bias, HID_EPS)
+        x = self.pano_encoder(x, ops.additive_mask(masks))
+        return ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, HID_EPS)
+
+
+class MLPProjectionHead(nn.Module):
+    def __init__(self, i, h, o):
+        super().__init__()
+        self.fc1 = nn.Linear(i, h, bias=False)
+        self.fc2 = nn.Linear(h, h, bias=False)
+        self.fc3 = nn.Linear(h, o, bias=False)
+
+    def forward(self, x):
+        x = ops.linear(x, self.fc1.weight, None, act=2)
+        x = ops.linear(x, self.fc2.weight, None, act=2)
+        return ops.linear(x, self.fc3.weight, None)
+
+
+class AlignWithContrastiveLoss(nn.Module):
+    """Imagination-grounding auxiliary head (reference vilmodel_cmt.py:730-950), vectorised:
+    host builds index lists once; device does ONE batched 3-layer MLP over all flagged imagination
+    slots, one segment-mean kernel over all noun-phrase tokens, one cosine kernel, and an out-of-place
+    row scatter that has the forward values of the reference's in-place write (:781)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.image_proj = MLPProjectionHead(768, 512, c.hidden_size)
+        self.config = c
+
+    def forward(self, align_txt_embeds=None, txt_masks=None, align_imagine_embeds=None, imagine_masks=None,
+                sub_instr_segs=None, sub_instr_imag_flag=None, noun_phrase_segs=None, obs_instr_ids=None):
+        txt, img = align_txt_embeds, align_imagine_embeds
+        B, L, H = txt.shape
+        I = img.shape[1]
+        dev = img.device
+        im_host = imagine_masks.cpu() if torch.is_tensor(imagine_masks) else imagine_masks
+        tm_host = txt_masks.cpu() if torch.is_tensor(txt_masks) else txt_masks
+        typ = self.config.aux_loss_type
+        mlp_rows, scored, seg_off, tok_rows = [], [], [0], []        # scored: index into mlp_rows
+        neg_off, neg_rows, neg_owner = [0], [], []                    # per-noun-phrase means (InfoNCE / margin)
+        for b in range(B):
+            flags = [x == "True" for x in sub_instr_imag_flag[b]]
+            assert len(flags) == len(sub_instr_segs[b]) and len(flags) == len(noun_phrase_segs[b])
+            for i, f in enumerate(flags):
+                if not f:
+                    continue
+                assert bool(im_host[b, i]), "Imagine embeds is not valid where embedding addition is being applied."
+                s0, s1 = sub_instr_segs[b][i]
+                nps = noun_phrase_segs[b][i]
+                mlp_rows.append(b * I + i)
+                for (a, z) in nps:
+                    assert a >= s0 and z <= s1, "check np indices and sub-instr indices. They seem off."
+                    assert bool(tm_host[b, a:z + 1].all()), "Text_embeds is not valid where embedding addition is being applied."
+                    tok_rows.extend(range(b * L + a, b * L + z + 1))
+                    if typ != "cosine":
+                        neg_rows.extend(range(b * L + a, b * L + z + 1))
+                        neg_off.append(len(neg_rows))
+                        neg_owner.append(b)
+                if len(nps) > 0:
+                    scored.append(len(mlp_rows) - 1)
+                    seg_off.append(len(tok_rows))
+        if not scored:
+            return 0, img
+        it = lambda v, d=torch.int32: torch.tensor(v, dtype=d, device=dev)
+        img2 = img.reshape(B * I, H)
+        rows_t = it(mlp_rows, torch.long)
+        proj = self.image_proj(img2.index_select(0, rows_t))             # MLP also runs for flagged slots without phrases
+        sc = it(scored, torch.long)
+        proj_s = proj.index_select(0, sc)
+        means = ops.segment_mean(txt.reshape(B * L, H), it(seg_off), it(tok_rows))
+        if typ == "cosine":
+            loss = (1.0 - ops.cosine(proj_s, means)).mean()
+        else:
+            # in-batch negatives: every noun phrase of every OTHER sample (flag-True slots only), :876-898,907
+            np_means = ops.segment_mean(txt.reshape(B * L, H), it(neg_off), it(neg_rows)).float()
+            owner = it(neg_owner, torch.long)
+            pf, mf = proj_s.float(), means.float()
+            unit = lambda v: v / v.norm(dim=-1, keepdim=True).clamp_min(1e-8)
+            pos = (unit(pf) * unit(mf)).sum(-1)
+            sims = unit(pf) @ unit(np_means).t()
+            own_b = torch.div(rows_t.index_select(0, sc), I, rounding_mode="floor")
+            is_neg = owner[None, :] != own_b[:, None]
+            if typ == "contrastive-InfoNCE":
+                t = self.config.infonce_temperature
+                lg = torch.cat([pos[:, None], sims.masked_fill(~is_neg, -float("inf"))], 1) / t
+                loss = (torch.logsumexp(lg, 1) - lg[:, 0]).mean()
+            else:
+                m = self.config.contrastive_margin_value
+                hinge = torch.relu(m + sims - pos[:, None]) * is_neg
+                loss = ((1 - pos) + hinge.sum(1) / is_neg.sum(1)).mean()
+        new_img = img2.index_copy(0, rows_t.index_select(0, sc), proj_s.to(img2.dtype)).view(B, I, H)
+        return loss, new_img
+
+
+AlignWithContrastiveLossWithNegativeSamples = AlignWithContrastiveLoss
+
+
+class NextActionPrediction(nn.Module):
+    def __init__(self, hidden, dropout_rate):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(hidden, hidden), nn.ReLU(), nn.LayerNorm(hidden, eps=HID_EPS),
+                                 nn.Dropout(dropout_rate), nn.Linear(hidden, 1))
+
+    def forward(self, x, neg_inf_mask):
+        n = self.net
+        h = ops.layer_norm(ops.linear(x, n[0].weight, n[0].bias, act=2), n[2].weight, n[2].bias, HID_EPS)
+        return ops.row_dot(h, n[4].weight, n[4].bias, neg_inf_mask)
+
+
+def _cfg(config):
+    from vln_imagine_amd.hamt.config import HamtConfig
+    if isinstance(config, HamtConfig):
+        return config
+    d = config.to_dict() if hasattr(config, "to_dict") else dict(config.__dict__)
+    known = set(HamtConfig().__dict__)
+    return HamtConfig(**{k: v for k, v in d.items() if k in known})
+
+
+class NavCMT(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        c = self.config = _cfg(config)
+        self.embeddings = BertEmbeddings(c)
+        self.img_embeddings = ImageEmbeddings(c)
+        self.hist_embeddings = HistoryEmbeddings(c)
+        if c.imagine_enc_pano and (c.use_cosine_aux_loss or c.no_loss_test):
+            if c.aux_loss_type not in ("cosine", "contrastive-InfoNCE", "constrastive-margin"):
+                raise ValueError(f"aux_loss_type {c.aux_loss_type!r}")
+            self.contrastive_alignment_model = AlignWithContrastiveLoss(c)
+        if c.imagine_enc_pano:
+            self.imagine_embeddings = BypassImagineEmbeddings(c) if c.bypass_imag_encoder else ImagineEmbeddings(c)
+        self.encoder = LxmertEncoder(c)
+        self.next_action = NextActionPrediction(c.hidden_size, c.pred_head_dropout_prob)
+        self.fix_lang_embedding = c.fix_lang_embedding
+        self.fix_hist_embedding = c.fix_hist_embedding
+        self.fix_obs_embedding = c.fix_obs_embedding
+        if c.imagine_enc_pano:
+            self.fix_imagine_embeds = c.fix_imagine_embeds
+        self.compute_dtype = torch.bfloat16 if os.environ.get("VLNI_DTYPE", "fp32").lower() in ("bf16", "bfloat16") \
+            else torch.float32
+        self.apply(self._init_weights)
+
+    @staticmethod
+    def _init_weights(m):          # BertPreTrainedModel init: N(0, 0.02) weights, zero bias, unit LayerNorm
+        if isinstance(m, (nn.Linear, nn.Embedding)):
+            m.weight.data.normal_(mean=0.0, std=0.02)
+        elif isinstance(m, nn.LayerNorm):
+            m.bias.data.zero_()
+            m.weight.data.fill_(1.0)
+        if isinstance(m, nn.Linear) and m.bias is not None:
+            m.bias.data.zero_()
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None):
+        m = cls(config)
+        if state_dict:
+            sd = {(k[5:] if k.startswith("bert.") else k): v for k, v in state_dict.items()}
+            m.load_state_dict(sd, strict=False)
+        return m
+
+    def set_compute_dtype(self, dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    @property
+    def device(self):
+        return self.next_action.net[0].weight.device
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, mode, txt_ids=None, txt_embeds=None, txt_masks=None, hist_img_feats=None, hist_ang_feats=None,
+                hist_pano_img_feats=None, hist_pano_ang_feats=None, hist_embeds=None, ob_step_ids=None, hist_masks=None,
+                ob_img_feats=None, ob_ang_feats=None, ob_nav_types=None, ob_masks=None, imagine_pano_img_feats=None,
+                imagine_masks=None, imagine_embeds=None, align_txt_embeds=None, align_imagine_embeds=None,
+                sub_instr_segs=None, sub_instr_imag_flag=None, noun_phrase_segs=None, obs_instr_ids=None,
+                return_cross_attention_probs=False):
+        c, dt = self.config, self.compute_dtype
+        if mode == "language":
+            B, L = txt_ids.shape
+            e = self.embeddings
+            pos = torch.arange(L, device=txt_ids.device).repeat(B)
+            srcs = [(e.word_embeddings.weight, "gather", txt_ids.reshape(-1).contiguous()),
+                    (e.position_embeddings.weight, "gather", pos),
+                    (e.token_type_embeddings.weight[0], "bcast", None)]
+            x = ops.sum_layer_norm(srcs, e.LayerNorm.weight, e.LayerNorm.bias, B * L, dt, HID_EPS).view(B, L, -1)
+            km = ops.additive_mask(txt_masks)
+            for layer in self.encoder.layer:
+                x = layer(x, km)
+            if self.fix_lang_embedding:
+                x = x.detach()
+            if c.no_lang_ca:
+                outs = [x]
+                for xl in self.encoder.x_layers:
+                    outs.append(ops.ffn_block(xl.lang_self_att(x, km), _ffn(xl.lang_inter, xl.lang_output)))
+                return outs
+            return x
+
+        if mode == "history":
+            h = self.hist_embeddings(hist_img_feats, hist_ang_feats, ob_step_ids, hist_pano_img_feats,
+                                     hist_pano_ang_feats, dt)
+            return h.detach() if self.fix_hist_embedding else h
+
+        if mode == "imagine":
+            assert imagine_pano_img_feats is not None
+            e = self.imagine_embeddings(imagine_pano_img_feats, imagine_masks, dt)
+            return e.detach() if self.fix_imagine_embeds else e
+
+        if mode == "align_with_contrastive_loss":
+            return self.contrastive_alignment_model(
+                align_txt_embeds=align_txt_embeds, txt_masks=txt_masks, align_imagine_embeds=align_imagine_embeds,
+                imagine_masks=imagine_masks, sub_instr_segs=sub_instr_segs, sub_instr_imag_flag=sub_instr_imag_flag,
+                noun_phrase_segs=noun_phrase_segs, obs_instr_ids=obs_instr_ids)
+
+        if mode != "visual":
+            raise NotImplementedError("wrong mode: %s" % mode)
+        if return_cross_attention_probs:
+            raise NotImplementedError("attention maps never leave the fused kernels; visualisation is out of scope")
+        hm, om, tm = ops.additive_mask(hist_masks), ops.additive_mask(ob_masks), ops.additive_mask(txt_masks)
+        hist = hist_embeds.to(dt)
+        if self.encoder.h_layers is not None:
+            for l in self.encoder.h_layers:
+                hist = l(hist, hm)
+        ob = self.img_embeddings(ob_img_feats, ob_ang_feats, self.embeddings.token_type_embeddings.weight[1],
+                                 ob_nav_types, dt)
+        if self.encoder.r_layers is not None:
+            for l in self.encoder.r_layers:
+                ob = l(ob, om)
+        if self.fix_obs_embedding:
+            ob = ob.detach()
+        nh, no = hist.shape[1], ob.shape[1]
+        txt_list = txt_embeds if isinstance(txt_embeds, list) else None
+        txt = (txt_list[0] if txt_list else txt_embeds).to(dt)
+        nt = txt.shape[1]
+        visn, vm, lang, lm = torch.cat([hist, ob], 1), torch.cat([hm, om], 1), txt, tm
+        img_side = None
+        if c.imagine_enc_pano:
+            assert imagine_embeds is not None
+            im = ops.additive_mask(imagine_masks)
+            img_side = c.concat_imagine_with
+            if img_side == "visual":
+                visn, vm = torch.cat([visn, imagine_embeds.to(dt)], 1), torch.cat([vm, im], 1)
+            elif img_side == "language":
+                lang, lm = torch.cat([lang, imagine_embeds.to(dt)], 1), torch.cat([lm, im], 1)
+        visn, lang, vm, lm = visn.contiguous(), lang.contiguous(), vm.contiguous(), lm.contiguous()
+        for i, xl in enumerate(self.encoder.x_layers):
+            if txt_list is not None:       # no_lang_ca: per-layer precomputed text states (:1138-1145)
+                lang = txt_list[i].to(dt) if img_side != "language" else lang
+            lang, visn = xl(lang, lm, visn, vm)
+        hist_o, ob_o = visn[:, :nh], visn[:, nh:nh + no]
+        txt_o = lang[:, :nt]
+        img_o = None
+        if img_side == "visual":
+            img_o = visn[:, nh + no:]
+        elif img_side == "language":
+            img_o = lang[:, nt:]
+        tok = c.act_pred_token
+        if c.no_lang_ca or tok == "ob":
+            f = ob_o
+        elif tok == "ob_txt":
+            f = ob_o * txt_o[:, :1]
+        elif tok == "ob_hist":
+            f = ob_o * hist_o[:, :1]
+        elif tok == "ob_txt_hist":
+            f = ob_o * (txt_o[:, :1] + hist_o[:, :1])
+        elif tok == "ob_imagine_text":
+            f = ob_o * (txt_o[:, :1] + img_o.float().mean(1, keepdim=True).to(dt))
+        else:
+            raise ValueError(f"act_pred_token {tok!r}")
+        act_logits = self.next_action(f.contiguous(), ob_nav_types == 0)
+        return act_logits, txt_o, hist_o, ob_o

@@ -1,0 +1,689 @@
+"""Autograd operators of the HAMT/DUET hot path on top of the vlni C-ABI.
+
+Every operator launches hand-written HIP kernels (libvlni.so) on torch's current stream;
+torch supplies device memory, the autograd graph between operators, and nothing else.
+There is no eager/CPU fallback: a CPU tensor or a missing library raises.
+
+Granularity is one autograd node per transformer SUBLAYER (attention block, FFN block,
+bidirectional cross-attention block) so that the backward pass is an explicit kernel
+sequence with fused epilogues (bias, GELU / GELU', residual) instead of ~40 tiny nodes.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+NEG_MASK = -10000.0
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"vlni ops take float32 or bfloat16 activations, got {t.dtype}")
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, name="tensor"):
+    if not t.is_cuda:
+        raise RuntimeError(f"vlni: {name} is on {t.device}; the HIP path has no CPU fallback")
+    return t
+
+
+def _rows(t):
+    """[..., H] -> contiguous 2-D view [rows, H]."""
+    t = t.reshape(-1, t.shape[-1])
+    return t if t.stride(1) == 1 and t.stride(0) >= t.shape[1] else t.contiguous()
+
+
+# =====================================================================================
+#  raw kernel wrappers (no autograd)
+# =====================================================================================
+def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_src=None, dact=0,
+            alpha=1.0, split_k=1, atomic=False, out_dtype=None):
+    """out[M,N] = epi(a[M,K] @ b[N,K]^T); a, b same dtype, K-contiguous."""
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K and a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32 if atomic else a.dtype, device=a.device)
+    _lib.call("vlni_gemm_nt", _dt(a), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+              out.stride(0), M, N, K, _p(bias), act, _p(residual), residual.stride(0) if residual is not None else 0,
+              _p(preact), preact.stride(0) if preact is not None else 0, _p(dact_src),
+              dact_src.stride(0) if dact_src is not None else 0, dact, alpha, split_k, 1 if atomic else 0, _st())
+    return out
+
+
+def transpose_pad(x, rpad, dtype=None):
+    """[R,C] -> [C,rpad] (zero-padded columns R..rpad), optional dtype change."""
+    R, C = x.shape
+    dtype = dtype or x.dtype
+    out = torch.empty((C, rpad), dtype=dtype, device=x.device)
+    _lib.call("vlni_transpose", _dt(x), _DT[dtype], x.data_ptr(), x.stride(0), out.data_ptr(), rpad, R, C, rpad, _st())
+    return out
+
+
+def wgrad(dy, x, out=None):
+    """dW[N,K] (+)= dy[M,N]^T @ x[M,K], float32, split over rows with atomics."""
+    M, N = dy.shape
+    K = x.shape[1]
+    mp = (M + 63) // 64 * 64
+    dyt = transpose_pad(dy, mp)
+    xt = transpose_pad(x, mp)
+    if out is None:
+        out = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    bk = 64 if dy.dtype == torch.bfloat16 else 32
+    nkt = (mp + bk - 1) // bk
+    split = max(1, min(nkt, 512 // tiles))
+    gemm_nt(dyt, xt, out=out, split_k=split, atomic=True)
+    return out
+
+
+def colsum(x, out=None):
+    rows, N = x.shape
+    if out is None:
+        out = torch.zeros((N,), dtype=torch.float32, device=x.device)
+    _lib.call("vlni_colsum", _dt(x), x.data_ptr(), x.stride(0), rows, N, out.data_ptr(), _st())
+    return out
+
+
+def ln_fwd(x, gamma, beta, eps):
+    rows, H = x.shape
+    y = torch.empty((rows, H), dtype=x.dtype, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    _lib.call("vlni_layernorm_fwd", _dt(x), x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), eps,
+              y.data_ptr(), y.stride(0), mean.data_ptr(), rstd.data_ptr(), rows, H, _st())
+    return y, mean, rstd
+
+
+def ln_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, want_param_grads=True):
+    rows, H = x.shape
+    dx = torch.empty((rows, H), dtype=x.dtype, device=x.device)
+    if want_param_grads and dgamma is None:
+        dgamma = torch.zeros((H,), dtype=torch.float32, device=x.device)
+        dbeta = torch.zeros((H,), dtype=torch.float32, device=x.device)
+    _lib.call("vlni_layernorm_bwd", _dt(x), dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
+              mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), rows, H, _st())
+    return dx, dgamma, dbeta
+
+
+def attn_fwd(q, k, v, B, Sq, Sk, kmask=None, bias=None, nh=12):
+    """q [B*Sq, >=nh*64] (strided view), k/v [B*Sk, ...]; returns ctx [B*Sq, nh*64], lse [B,nh,Sq]."""
+    out = torch.empty((B * Sq, nh * 64), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, nh, Sq), dtype=torch.float32, device=q.device)
+    _lib.call("vlni_attn_fwd", _dt(q), q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+              _p(kmask), _p(bias), out.data_ptr(), out.stride(0), lse.data_ptr(), B, nh, Sq, Sk, 1.0 / 8.0, _st())
+    return out, lse
+
+
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, Sq, Sk, kmask=None, bias=None, dbias=None, nh=12):
+    _lib.call("vlni_attn_bwd", _dt(q), q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+              _p(kmask), _p(bias), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0), lse.data_ptr(),
+              dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0), _p(dbias),
+              B, nh, Sq, Sk, 1.0 / 8.0, _st())
+
+
+def cast(x, dtype):
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.call("vlni_cast", _dt(x), _DT[dtype], x.data_ptr(), out.data_ptr(), x.numel(), _st())
+    return out
+
+
+def additive_mask(m):
+    """bool/0-1 mask [B,S] -> float32 additive (1-m)*-10000 (vilmodel_cmt.py:1010-1012)."""
+    return (1.0 - m.to(torch.float32)) * NEG_MASK
+
+
+# =====================================================================================
+#  compute-dtype shadows of the float32 master weights
+# =====================================================================================
+class ShadowCache:
+    """Packed / cast / transposed copies of parameters, refreshed when a parameter's
+    version counter moves (optimizer step, load_state_dict). The float32 nn.Parameters stay
+    the single source of truth so state_dict keys match the reference checkpoints."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, params, dtype, transposed=False):
+        key = (tuple(id(p) for p in params), dtype, transposed)
+        ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        with torch.no_grad():
+            for p in params:
+                _chk(p, "parameter")
+            src = params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], 0)
+            if src.dim() == 1:
+                t = src if dtype == torch.float32 else cast(src, dtype)
+            elif transposed:
+                t = transpose_pad(src, src.shape[0], dtype)
+            else:
+                t = src if (dtype == torch.float32 and len(params) == 1) else cast(src, dtype)
+        self._c[key] = (ver, t)
+        return t
+
+
+SHADOWS = ShadowCache()
+
+
+def _w(params, dtype, transposed=False):
+    return SHADOWS.get(params, dtype, transposed)
+
+
+def _split_rows(t, sizes):
+    out, o = [], 0
+    for s in sizes:
+        out.append(t[o:o + s])
+        o += s
+    return out
+
+
+# =====================================================================================
+#  sublayer autograd functions
+# =====================================================================================
+class _SelfAttBlock(torch.autograd.Function):
+    """y = LN(dense(attn(x Wq, x Wk, x Wv)) + x): BertAttention, vilmodel_cmt.py:151-161."""
+
+    @staticmethod
+    def forward(ctx, x, kmask, bias, eps, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
+        B, S, H = x.shape
+        x2 = _rows(_chk(x, "x"))
+        dt = x.dtype
+        wqkv, bqkv = _w((wq, wk, wv), dt), _w((bq, bk, bv), torch.float32)
+        qkv = gemm_nt(x2, wqkv, bias=bqkv)
+        c, lse = attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, S, kmask, bias)
+        pre = gemm_nt(c, _w((wo,), dt), bias=bo, residual=x2)
+        y, mean, rstd = ln_fwd(pre, g, b, eps)
+        ctx.save_for_backward(x2, qkv, c, lse, pre, mean, rstd, kmask, bias, wq, wk, wv, wo, g)
+        ctx.dims = (B, S, H)
+        return y.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, qkv, c, lse, pre, mean, rstd, kmask, bias, wq, wk, wv, wo, g = ctx.saved_tensors
+        B, S, H = ctx.dims
+        dt = x2.dtype
+        ng = ctx.needs_input_grad
+        wparams = any(ng[4:])
+        dy2 = _rows(dy)
+        dpre, dg, db = ln_bwd(dy2, pre, g, mean, rstd, want_param_grads=wparams)
+        dwo = wgrad(dpre, c) if wparams else None
+        dbo = colsum(dpre) if wparams else None
+        dc = gemm_nt(dpre, _w((wo,), dt, True))
+        dqkv = torch.empty_like(qkv)
+        dbias = torch.zeros_like(bias) if (bias is not None and ng[2]) else None
+        attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], c, dc, lse, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:],
+                 B, S, S, kmask, bias, dbias)
+        dwq = dwk = dwv = dbq = dbk = dbv = None
+        if wparams:
+            dwq, dwk, dwv = _split_rows(wgrad(dqkv, x2), (H, H, H))
+            dbq, dbk, dbv = _split_rows(colsum(dqkv), (H, H, H))
+        dx = gemm_nt(dqkv, _w((wq, wk, wv), dt, True), residual=dpre).view(B, S, H) if ng[0] else None
+        return dx, None, dbias, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
+
+
+class _FfnBlock(torch.autograd.Function):
+    """y = LN(W2 gelu(W1 x + b1) + b2 + x): BertIntermediate + BertOutput, vilmodel_cmt.py:164-190."""
+
+    @staticmethod
+    def forward(ctx, x, eps, w1, b1, w2, b2, g, b):
+        shp = x.shape
+        x2 = _rows(_chk(x, "x"))
+        dt = x.dtype
+        z = torch.empty((x2.shape[0], w1.shape[0]), dtype=dt, device=x.device)
+        a = gemm_nt(x2, _w((w1,), dt), bias=b1, act=1, preact=z)
+        pre = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2)
+        y, mean, rstd = ln_fwd(pre, g, b, eps)
+        ctx.save_for_backward(x2, z, a, pre, mean, rstd, w1, w2, g)
+        ctx.shp = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, z, a, pre, mean, rstd, w1, w2, g = ctx.saved_tensors
+        dt = x2.dtype
+        ng = ctx.needs_input_grad
+        wparams = any(ng[2:])
+        dpre, dg, db = ln_bwd(_rows(dy), pre, g, mean, rstd, want_param_grads=wparams)
+        dw2 = wgrad(dpre, a) if wparams else None
+        db2 = colsum(dpre) if wparams else None
+        dz = gemm_nt(dpre, _w((w2,), dt, True), dact_src=z, dact=1)      # GELU' fused in the dgrad epilogue
+        dw1 = wgrad(dz, x2) if wparams else None
+        db1 = colsum(dz) if wparams else None
+        dx = gemm_nt(dz, _w((w1,), dt, True), residual=dpre).view(ctx.shp) if ng[0] else None
+        return dx, None, dw1, db1, dw2, db2, dg, db
+
+
+class _XAttPairBlock(torch.autograd.Function):
+    """Bidirectional cross-attention with ONE shared BertXAttention on the PRE-update inputs
+    (LXRTXLayer.cross_att, vilmodel_cmt.py:385-397):
+        lang' = LN(dense(attn(q=lang, kv=visn, mask_v)) + lang);  visn' = LN(dense(attn(q=visn, kv=lang, mask_l)) + visn)
+    Q/K/V of both streams come from one packed [2304,768] projection each."""
+
+    @staticmethod
+    def forward(ctx, lang, visn, mask_l, mask_v, eps, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
+        B, Sl, H = lang.shape
+        Sv = visn.shape[1]
+        l2, v2 = _rows(_chk(lang, "lang")), _rows(_chk(visn, "visn"))
+        dt = lang.dtype
+        wqkv, bqkv, wo_c = _w((wq, wk, wv), dt), _w((bq, bk, bv), torch.float32), _w((wo,), dt)
+        ql = gemm_nt(l2, wqkv, bias=bqkv)
+        qv = gemm_nt(v2, wqkv, bias=bqkv)
+        cl, lse_l = attn_fwd(ql[:, :H], qv[:, H:2 * H], qv[:, 2 * H:], B, Sl, Sv, mask_v)
+        cv, lse_v = attn_fwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], B, Sv, Sl, mask_l)
+        pre_l = gemm_nt(cl, wo_c, bias=bo, residual=l2)
+        pre_v = gemm_nt(cv, wo_c, bias=bo, residual=v2)
+        yl, mean_l, rstd_l = ln_fwd(pre_l, g, b, eps)
+        yv, mean_v, rstd_v = ln_fwd(pre_v, g, b, eps)
+        ctx.save_for_backward(l2, v2, ql, qv, cl, cv, lse_l, lse_v, pre_l, pre_v, mean_l, rstd_l, mean_v, rstd_v,
+                              mask_l, mask_v, wq, wk, wv, wo, g)
+        ctx.dims = (B, Sl, Sv, H)
+        return yl.view(B, Sl, H), yv.view(B, Sv, H)
+
+    @staticmethod
+    def backward(ctx, dyl, dyv):
+        (l2, v2, ql, qv, cl, cv, lse_l, lse_v, pre_l, pre_v, mean_l, rstd_l, mean_v, rstd_v,
+         mask_l, mask_v, wq, wk, wv, wo, g) = ctx.saved_tensors
+        B, Sl, Sv, H = ctx.dims
+        dt = l2.dtype
+        ng = ctx.needs_input_grad
+        wparams = any(ng[5:])
+        dpl, dg, db = ln_bwd(_rows(dyl), pre_l, g, mean_l, rstd_l, want_param_grads=wparams)
+        dpv, dg, db = ln_bwd(_rows(dyv), pre_v, g, mean_v, rstd_v, dg, db, want_param_grads=wparams)
+        dwo = dbo = None
+        if wparams:
+            dwo = wgrad(dpv, cv, wgrad(dpl, cl))
+            dbo = colsum(dpv, colsum(dpl))
+        wot = _w((wo,), dt, True)
+        dcl, dcv = gemm_nt(dpl, wot), gemm_nt(dpv, wot)
+        dql, dqv = torch.empty_like(ql), torch.empty_like(qv)
+        attn_bwd(ql[:, :H], qv[:, H:2 * H], qv[:, 2 * H:], cl, dcl, lse_l, dql[:, :H], dqv[:, H:2 * H], dqv[:, 2 * H:],
+                 B, Sl, Sv, mask_v)
+        attn_bwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], cv, dcv, lse_v, dqv[:, :H], dql[:, H:2 * H], dql[:, 2 * H:],
+                 B, Sv, Sl, mask_l)
+        dwq = dwk = dwv = dbq = dbk = dbv = None
+        if wparams:
+            dwq, dwk, dwv = _split_rows(wgrad(dqv, v2, wgrad(dql, l2)), (H, H, H))
+            dbq, dbk, dbv = _split_rows(colsum(dqv, colsum(dql)), (H, H, H))
+        wt = _w((wq, wk, wv), dt, True)
+        dl = gemm_nt(dql, wt, residual=dpl).view(B, Sl, H) if ng[0] else None
+        dv = gemm_nt(dqv, wt, residual=dpv).view(B, Sv, H) if ng[1] else None
+        return dl, dv, None, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
+
+
+class _XAttBlock(torch.autograd.Function):
+    """One-directional cross-attention: y = LN(dense(attn(q=x, kv=ctx_in, mask)) + x)
+    (GraphLXRTXLayer cross step, VLN-DUET vilmodel.py:384-399; HAMT no_lang_ca)."""
+
+    @staticmethod
+    def forward(ctx, x, c_in, mask_c, eps, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
+        B, Sq, H = x.shape
+        Sk = c_in.shape[1]
+        x2, c2 = _rows(_chk(x, "x")), _rows(_chk(c_in, "context"))
+        dt = x.dtype
+        q = gemm_nt(x2, _w((wq,), dt), bias=bq)
+        kv = gemm_nt(c2, _w((wk, wv), dt), bias=_w((bk, bv), torch.float32))
+        a, lse = attn_fwd(q, kv[:, :H], kv[:, H:], B, Sq, Sk, mask_c)
+        pre = gemm_nt(a, _w((wo,), dt), bias=bo, residual=x2)
+        y, mean, rstd = ln_fwd(pre, g, b, eps)
+        ctx.save_for_backward(x2, c2, q, kv, a, lse, pre, mean, rstd, mask_c, wq, wk, wv, wo, g)
+        ctx.dims = (B, Sq, Sk, H)
+        return y.view(B, Sq, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, c2, q, kv, a, lse, pre, mean, rstd, mask_c, wq, wk, wv, wo, g = ctx.saved_tensors
+        B, Sq, Sk, H = ctx.dims
+        dt = x2.dtype
+        ng = ctx.needs_input_grad
+        wparams = any(ng[4:])
+        dpre, dg, db = ln_bwd(_rows(dy), pre, g, mean, rstd, want_param_grads=wparams)
+        dwo = wgrad(dpre, a) if wparams else None
+        dbo = colsum(dpre) if wparams else None
+        da = gemm_nt(dpre, _w((wo,), dt, True))
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        attn_bwd(q, kv[:, :H], kv[:, H:], a, da, lse, dq, dkv[:, :H], dkv[:, H:], B, Sq, Sk, mask_c)
+        dwq = dbq = dwk = dwv = dbk = dbv = None
+        if wparams:
+            dwq, dbq = wgrad(dq, x2), colsum(dq)
+            dwk, dwv = _split_rows(wgrad(dkv, c2), (H, H))
+            dbk, dbv = _split_rows(colsum(dkv), (H, H))
+        dx = gemm_nt(dq, _w((wq,), dt, True), residual=dpre).view(B, Sq, H) if ng[0] else None
+        dc = gemm_nt(dkv, _w((wk, wv), dt, True)).view(B, Sk, H) if ng[1] else None
+        return dx, dc, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
+
+
+# =====================================================================================
+#  generic operators
+# =====================================================================================
+class _Linear(torch.autograd.Function):
+    """y = act(x W^T + b) (+ residual); act 0 none / 1 gelu / 2 relu."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, out_dtype):
+        shp = x.shape
+        dt = out_dtype
+        x2 = _rows(_chk(x, "x"))
+        if x2.dtype != dt:
+            x2 = cast(x2, dt)
+        z = torch.empty((x2.shape[0], w.shape[0]), dtype=dt, device=x.device) if act else None
+        y = gemm_nt(x2, _w((w,), dt), bias=b, act=act, preact=z)
+        ctx.save_for_backward(x2, z, w)
+        ctx.act, ctx.shp, ctx.in_dtype = act, shp, x.dtype
+        return y.view(shp[:-1] + (w.shape[0],))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, z, w = ctx.saved_tensors
+        dt = x2.dtype
+        ng = ctx.needs_input_grad
+        dy2 = _rows(dy)
+        if ctx.act:
+            dz = torch.empty_like(dy2)
+            _lib.call("vlni_act_bwd", _dt(dy2), ctx.act, dy2.data_ptr(), z.data_ptr(), dz.data_ptr(), dy2.numel(), _st())
+            dy2 = dz
+        dw = wgrad(dy2, x2) if ng[1] else None
+        db = colsum(dy2) if ng[2] else None
+        dx = None
+        if ng[0]:
+            dx = gemm_nt(dy2, _w((w,), dt, True))
+            if dx.dtype != ctx.in_dtype:
+                dx = cast(dx, ctx.in_dtype)
+            dx = dx.view(ctx.shp)
+        return dx, dw, db, None, None
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        shp = x.shape
+        x2 = _rows(_chk(x, "x"))
+        y, mean, rstd = ln_fwd(x2, g, b, eps)
+        ctx.save_for_backward(x2, g, mean, rstd)
+        ctx.shp = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, g, mean, rstd = ctx.saved_tensors
+        wp = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dg, db = ln_bwd(_rows(dy), x2, g, mean, rstd, want_param_grads=wp)
+        return dx.view(ctx.shp), dg, db, None
+
+
+class _SmallKLinear(torch.autograd.Function):
+    """y = x W^T + b for K <= 16 float32 features (angle / position features)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, out_dtype):
+        shp = x.shape
+        x2 = _rows(_chk(x, "x")).float()
+        N, K = w.shape
+        y = torch.empty((x2.shape[0], N), dtype=out_dtype, device=x.device)
+        _lib.call("vlni_smallk_linear_fwd", _DT[out_dtype], x2.data_ptr(), x2.stride(0), w.data_ptr(), _p(b), y.data_ptr(),
+                  y.stride(0), x2.shape[0], N, K, _st())
+        ctx.save_for_backward(x2, w)
+        ctx.has_b = b is not None
+        return y.view(shp[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        N, K = w.shape
+        dy2 = _rows(dy)
+        dw = torch.zeros_like(w)
+        db = torch.zeros((N,), dtype=torch.float32, device=w.device) if ctx.has_b else None
+        _lib.call("vlni_smallk_linear_bwd", _dt(dy2), dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0),
+                  dw.data_ptr(), _p(db), x2.shape[0], N, K, _st())
+        return None, dw, db, None
+
+
+class _SumLayerNorm(torch.autograd.Function):
+    """y = LN(sum_k src_k). spec[k] = ('dense' | 'bcast' | 'gather', is_param)."""
+
+    @staticmethod
+    def forward(ctx, spec, idxs, eps, out_dtype, rows, g, b, *srcs):
+        H = g.shape[0]
+        n = len(srcs)
+        dev = g.device
+        ptrs = (ctypes.c_void_p * n)()
+        lds = (ctypes.c_long * n)()
+        ips = (ctypes.c_void_p * n)()
+        f32 = (ctypes.c_int * n)()
+        keep = []
+        for k, (s, (kind, _)) in enumerate(zip(srcs, spec)):
+            _chk(s, "source")
+            s2 = s.reshape(-1, H)
+            s2 = s2 if s2.stride(1) == 1 else s2.contiguous()
+            keep.append(s2)
+            ptrs[k] = s2.data_ptr()
+            lds[k] = 0 if kind == "bcast" else s2.stride(0)
+            ips[k] = idxs[k].data_ptr() if kind == "gather" else None
+            f32[k] = 1 if s2.dtype == torch.float32 else 0
+            if s2.dtype != torch.float32 and s2.dtype != out_dtype:
+                raise TypeError("sum_layernorm: activation sources must have the compute dtype")
+        y = torch.empty((rows, H), dtype=out_dtype, device=dev)
+        xs = torch.empty((rows, H), dtype=out_dtype, device=dev)
+        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
+        _lib.call("vlni_sum_layernorm_fwd", _DT[out_dtype], n, ptrs, lds, ips, f32, g.data_ptr(), b.data_ptr(), eps,
+                  y.data_ptr(), H, xs.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), rows, H, _st())
+        ctx.save_for_backward(xs, g, mean, rstd, *[i for i in idxs if i is not None])
+        ctx.spec, ctx.idx_pos = spec, [k for k, i in enumerate(idxs) if i is not None]
+        ctx.shapes = [(s.shape, s.dtype) for s in srcs]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, g, mean, rstd, *idl = ctx.saved_tensors
+        idxs = dict(zip(ctx.idx_pos, idl))
+        ng = ctx.needs_input_grad
+        dsum, dg, db = ln_bwd(_rows(dy), xs, g, mean, rstd, want_param_grads=ng[5] or ng[6])
+        rows, H = dsum.shape
+        grads = []
+        for k, ((kind, _), (shape, dtype)) in enumerate(zip(ctx.spec, ctx.shapes)):
+            if not ng[7 + k]:
+                grads.append(None)
+            elif kind == "dense":
+                grads.append((dsum if dtype == dsum.dtype else cast(dsum, dtype)).view(shape))
+            elif kind == "bcast":
+                grads.append(colsum(dsum).view(shape).to(dtype))
+            else:
+                tg = torch.zeros(shape, dtype=torch.float32, device=dsum.device)
+                _lib.call("vlni_scatter_add_rows", _dt(dsum), dsum.data_ptr(), dsum.stride(0), idxs[k].data_ptr(),
+                          tg.data_ptr(), rows, H, _st())
+                grads.append(tg)
+        return (None, None, None, None, None, dg, db) + tuple(grads)
+
+
+class _SeqMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, S, H = x.shape
+        x = _chk(x, "x").contiguous()
+        out = torch.empty((B, H), dtype=x.dtype, device=x.device)
+        _lib.call("vlni_seqmean_fwd", _dt(x), x.data_ptr(), out.data_ptr(), B, S, H, _st())
+        ctx.dims = (B, S, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, S, H = ctx.dims
+        dout = dout.contiguous()
+        dx = torch.empty((B, S, H), dtype=dout.dtype, device=dout.device)
+        _lib.call("vlni_seqmean_bwd", _dt(dout), dout.data_ptr(), dx.data_ptr(), B, S, H, _st())
+        return dx
+
+
+class _RowDot(torch.autograd.Function):
+    """logits[r] = mask[r] ? -inf : <h[r], w> + bias   (float32 logits)."""
+
+    @staticmethod
+    def forward(ctx, h, w, bias, mask):
+        shp = h.shape
+        h2 = _rows(_chk(h, "h"))
+        rows, H = h2.shape
+        m8 = mask.reshape(-1).to(torch.uint8).contiguous() if mask is not None else None
+        out = torch.empty((rows,), dtype=torch.float32, device=h.device)
+        _lib.call("vlni_rowdot_fwd", _dt(h2), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(bias), _p(m8), out.data_ptr(),
+                  rows, H, _st())
+        ctx.save_for_backward(h2, w, m8)
+        ctx.shp, ctx.has_b = shp, bias is not None
+        return out.view(shp[:-1])
+
+    @staticmethod
+    def backward(ctx, dl):
+        h2, w, m8 = ctx.saved_tensors
+        rows, H = h2.shape
+        dl = dl.reshape(-1).float().contiguous()
+        dh = torch.empty_like(h2)
+        dw = torch.zeros((H,), dtype=torch.float32, device=h2.device)
+        dbias = torch.zeros((1,), dtype=torch.float32, device=h2.device) if ctx.has_b else None
+        _lib.call("vlni_rowdot_bwd", _dt(h2), dl.data_ptr(), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(m8),
+                  dh.data_ptr(), dh.stride(0), dw.data_ptr(), _p(dbias), rows, H, _st())
+        return dh.view(ctx.shp), dw.view(w.shape), dbias, None
+
+
+class _CrossEntropySum(torch.autograd.Function):
+    """CrossEntropyLoss(ignore_index=-100, reduction='sum') on float32 logits (may hold -inf)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        lg = _chk(logits, "logits").float().contiguous()
+        rows, V = lg.shape
+        loss = torch.zeros((1,), dtype=torch.float32, device=lg.device)
+        dlg = torch.empty_like(lg)
+        _lib.call("vlni_cross_entropy", lg.data_ptr(), lg.stride(0), target.data_ptr(), ignore_index, loss.data_ptr(),
+                  dlg.data_ptr(), dlg.stride(0), rows, V, _st())
+        ctx.save_for_backward(dlg)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlg,) = ctx.saved_tensors
+        return dlg * g, None, None
+
+
+class _SegmentMean(torch.autograd.Function):
+    """out[s] = mean of x rows listed in CSR (seg_off, rowidx): noun-phrase token mean (vilmodel_cmt.py:766-779)."""
+
+    @staticmethod
+    def forward(ctx, x2, seg_off, rowidx):
+        _chk(x2, "x")
+        nseg, H = seg_off.numel() - 1, x2.shape[1]
+        out = torch.empty((nseg, H), dtype=x2.dtype, device=x2.device)
+        _lib.call("vlni_segment_mean_fwd", _dt(x2), x2.data_ptr(), x2.stride(0), seg_off.data_ptr(), rowidx.data_ptr(),
+                  out.data_ptr(), nseg, H, _st())
+        ctx.save_for_backward(seg_off, rowidx)
+        ctx.xshape, ctx.xdtype = x2.shape, x2.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        seg_off, rowidx = ctx.saved_tensors
+        dout = dout.contiguous()
+        nseg, H = dout.shape
+        dx32 = torch.zeros(ctx.xshape, dtype=torch.float32, device=dout.device)
+        _lib.call("vlni_segment_mean_bwd", _dt(dout), dout.data_ptr(), seg_off.data_ptr(), rowidx.data_ptr(),
+                  dx32.data_ptr(), nseg, H, _st())
+        return cast(dx32, ctx.xdtype), None, None
+
+
+class _Cosine(torch.autograd.Function):
+    """cos[r] = cosine_similarity(x[r], y[r], eps=1e-8) -> float32 [rows]."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _chk(x, "x").contiguous(), y.contiguous()
+        rows, H = x.shape
+        cosv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        nx, ny = torch.empty_like(cosv), torch.empty_like(cosv)
+        _lib.call("vlni_cosine_fwd", _dt(x), x.data_ptr(), y.data_ptr(), 1e-8, cosv.data_ptr(), nx.data_ptr(), ny.data_ptr(),
+                  rows, H, _st())
+        ctx.save_for_backward(x, y, cosv, nx, ny)
+        return cosv
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, cosv, nx, ny = ctx.saved_tensors
+        rows, H = x.shape
+        g = g.float().contiguous()
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        _lib.call("vlni_cosine_bwd", _dt(x), x.data_ptr(), y.data_ptr(), g.data_ptr(), cosv.data_ptr(), nx.data_ptr(),
+                  ny.data_ptr(), _p(dx), _p(dy), rows, H, _st())
+        return dx, dy
+
+
+# ---- functional front-ends ------------------------------------------------------------
+def self_att_block(x, kmask, p, eps=1e-12, bias=None):
+    return _SelfAttBlock.apply(x, kmask, bias, eps, *p)
+
+
+def ffn_block(x, p, eps=1e-12):
+    return _FfnBlock.apply(x, eps, *p)
+
+
+def xatt_pair_block(lang, visn, mask_l, mask_v, p, eps=1e-12):
+    return _XAttPairBlock.apply(lang, visn, mask_l, mask_v, eps, *p)
+
+
+def xatt_block(x, c_in, mask_c, p, eps=1e-12):
+    return _XAttBlock.apply(x, c_in, mask_c, eps, *p)
+
+
+def linear(x, w, b=None, act=0, out_dtype=None):
+    return _Linear.apply(x, w, b, act, out_dtype or x.dtype)
+
+
+def layer_norm(x, g, b, eps=1e-12):
+    return _LayerNorm.apply(x, g, b, eps)
+
+
+def smallk_linear(x, w, b, out_dtype):
+    return _SmallKLinear.apply(x, w, b, out_dtype)
+
+
+def sum_layer_norm(srcs, g, b, rows, out_dtype, eps=1e-12):
+    """srcs: list of (tensor, kind, idx) with kind in {'dense','bcast','gather'}; idx int64 [rows] for 'gather'."""
+    spec = tuple((k, False) for _, k, _ in srcs)
+    idxs = tuple(i for _, _, i in srcs)
+    return _SumLayerNorm.apply(spec, idxs, eps, out_dtype, rows, g, b, *[t for t, _, _ in srcs])
+
+
+def seq_mean(x):
+    return _SeqMean.apply(x)
+
+
+def row_dot(h, w, bias, mask):
+    return _RowDot.apply(h, w, bias, mask)
+
+
+def cross_entropy_sum(logits, target, ignore_index=-100):
+    return _CrossEntropySum.apply(logits, target, ignore_index)
+
+
+def segment_mean(x2, seg_off, rowidx):
+    return _SegmentMean.apply(x2, seg_off, rowidx)
+
+
+def cosine(x, y):
+    return _Cosine.apply(x, y)
