@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- episodes/sec (fwd+bwd) of the HAMT-Imagine hot path on MI355X (BASELINE.json metric).
+
+One "step" = one batch of synthetic R2R episodes through the HIP path:
+  1 'language' + 1 'imagine' + 1 'align_with_contrastive_loss' + 1 'history'(CLS)
+  + T x ('visual' + 'history' step) + CE(sum) per step -> loss = ml*0.2/B + 0.5*aux
+  -> backward -> [RCCL gradient all-reduce if N > 1] -> clip_grad_norm(40) -> AdamW.
+Default workload = BASELINE.json configs[1]: 9 L + 4 X + 2 hist-pano layers, batch 64 per GPU,
+80 text tokens, 37 observation tokens, 6 imaginations, T = 6, bf16 compute, all layers trainable.
+Inputs are resident in HBM before the timed region. N > 1: one process per GPU (torchrun), weak scaling
+(64 episodes per GPU), value = all ranks' episodes / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the MFMA GEMM, timed with HIP events
+in an instrumented pass after the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def episode_flops(cfg, B, L, V, I, T, shipped_freeze):
+    """Algorithmic FLOPs of one episode batch (SURVEY.md section 8d formulas; multiply-add = 2, bwd = 2x fwd)."""
+    H, FF = 768, 3072
+    bert = lambda S: 24 * S * H * H + 4 * S * S * H
+    xl = lambda Lt, Lv: 32 * (Lt + Lv) * H * H + 8 * Lt * Lv * H + 4 * (Lt * Lt + Lv * Lv) * H
+    lang = cfg.num_l_layers * bert(L)
+    hist_step = 2 * H * H + cfg.num_h_pano_layers * bert(36) + 2 * 36 * H * H
+    aux = 2 * I * (768 * 512 + 512 * 512 + 512 * 768)
+    total = 0.0
+    total += lang * (1 if shipped_freeze else 3)
+    total += aux * 3
+    for t in range(T):
+        Lv = (1 + t) + V
+        visual = cfg.num_x_layers * xl(L + I, Lv) + 2 * V * H * H * 2   # + obs embed + head
+        total += visual * 3
+        total += hist_step * (1 if shipped_freeze else 3)
+    return total * B
+
+
+def make_model(cfg, dtype, device):
+    from vln_imagine_amd import synth
+    from vln_imagine_amd.hamt.models.vilmodel_cmt import NavCMT
+    from vln_imagine_amd.hamt.spec import param_shapes
+    m = NavCMT(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()})
+    return m.to(device).eval().set_compute_dtype(dtype)      # eval(): dropout p = 0 as in the survey probe
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("VLNI_CPU_THREADS", "64"))))
+
+
+def cpu_baseline(cfg, args):
+    """The CPU oracle (plain PyTorch fp32 restatement pinned to the reference's golden vectors) on the host cores."""
+    from oracle.hamt_oracle import HamtOracle
+    from vln_imagine_amd import synth
+    from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+    from vln_imagine_amd.hamt.spec import param_shapes
+    cores = host_cores()
+    log(f"cpu_baseline: oracle on {cores} host threads, batch {args.cpu_batch}")
+    torch.set_num_threads(cores)
+    Bc = args.cpu_batch
+    ep = synth.HamtEpisode(tag="cpu", B=Bc, L=args.L, V=args.V, I=args.I, T=args.T, ragged=False)
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()}
+    opt = torch.optim.AdamW(list(sd.values()), lr=1e-5)
+    et = EpisodeTensors(ep, "cpu")
+    model = HamtOracle(cfg, sd)
+    t0 = time.time()
+    out = run_episode(model, et, keep=False)
+    out["loss"].backward()
+    torch.nn.utils.clip_grad_norm_(list(sd.values()), 40.0)
+    opt.step()
+    dt = time.time() - t0
+    return {"value": Bc / dt, "unit": "episodes/s", "cores": cores, "kind": "port",
+            "sample": f"1 step of {Bc} episodes (same model/T/shapes as the GPU workload, fp32, torch {torch.__version__} CPU, "
+                      f"fwd+bwd+clip+AdamW), {dt:.1f} s wall"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--T", type=int, default=6)
+    ap.add_argument("--L", type=int, default=80)
+    ap.add_argument("--V", type=int, default=37)
+    ap.add_argument("--I", type=int, default=6)
+    ap.add_argument("--freeze", default="none", choices=["none", "shipped"])
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from vln_imagine_amd import ops, synth
+    from vln_imagine_amd.hamt.config import HamtConfig
+    from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+    from vln_imagine_amd.train import FlatTrainer
+
+    shipped = args.freeze == "shipped"
+    cfg = HamtConfig(fix_lang_embedding=shipped, fix_hist_embedding=shipped, update_lang_bert=not shipped)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = make_model(cfg, dtype, dev)
+    trainer = FlatTrainer(model, lr=1e-5)
+    ep = synth.HamtEpisode(tag=f"bench{rank}", B=args.batch, L=args.L, V=args.V, I=args.I, T=args.T, ragged=False)
+    et = EpisodeTensors(ep, dev)
+
+    def step():
+        trainer.zero_grad()
+        out = run_episode(model, et, criterion=ops.cross_entropy_sum, keep=False)
+        out["loss"].backward()
+        trainer.allreduce_grads()
+        trainer.step()
+        return out["loss"]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f"model + episode ready on {dev}; warmup {args.warmup}, steps {args.steps}, dtype {args.dtype}")
+    for i in range(args.warmup):
+        tw = time.perf_counter()
+        loss = step()
+        torch.cuda.synchronize()
+        log(f"warmup {i}: {1e3 * (time.perf_counter() - tw):.1f} ms loss {float(loss):.5f}")
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    ms = dt / args.steps * 1e3
+    log(f"timed: {ms:.2f} ms/step")
+    eps = args.batch * world / (dt / args.steps)
+    flops = episode_flops(cfg, args.batch, args.L, args.V, args.I, args.T, shipped)
+    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # instrumented pass: HIP events (torch.cuda.Event on the launch stream = torch's current stream) around
+        # every vlni_gemm_nt launch of ONE more step; not part of the timed region above.
+        rec = []
+        orig = ops.gemm_nt
+
+        def timed(a, b, *p, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(a, b, *p, **k)
+            e1.record()
+            rec.append((2.0 * a.shape[0] * b.shape[0] * a.shape[1], e0, e1))
+            return r
+
+        ops.gemm_nt = timed
+        try:
+            step()
+            torch.cuda.synchronize()
+        finally:
+            ops.gemm_nt = orig
+        tot_f = sum(f for f, _, _ in rec)
+        tot_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in rec)
+        ach = tot_f / (tot_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % ("__bf16" if args.dtype == "bf16" else "float"),
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "launches_per_step": len(rec), "avg_launch_us": round(tot_ms * 1e3 / len(rec), 2),
+                "avg_gflop_per_launch": round(tot_f / len(rec) / 1e9, 3),
+                "gemm_share_of_step": round(tot_ms / ms, 3),
+                "step_algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+                "step_frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / peak, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, args)
+
+    if rank == 0:
+        line = {
+            "metric": "episodes/sec (fwd+bwd) HAMT-Imagine 9L, batch 64", "value": round(eps, 2), "unit": "episodes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"HAMT-Imagine 9L+4X+2pano, batch {args.batch}/GPU, {args.L} text, {args.V} obs tokens, "
+                                   f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, dropout p=0",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "steps_per_sec": round(args.T * args.batch * world / (dt / args.steps), 1),
+                       "loss": round(float(loss), 5)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,4 +84,25 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
+// bf16 path: Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7, far below bf16 resolution): 1 exp + 1 rcp + 6 fma
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(e, x);
+}
+template <typename T> __device__ __forceinline__ float gelu_t(float x) {
+  if constexpr (sizeof(T) == 2) return x * 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+  else return gelu_erf(x);
+}
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) {
+  if constexpr (sizeof(T) == 2) {
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752f));
+    return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+  } else {
+    return gelu_erf_grad(x);
+  }
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

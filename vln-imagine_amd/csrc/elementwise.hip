@@ -401,7 +401,7 @@ extern "C" int vlni_rowdot_fwd(int dtype, const void* h, long ldh, const float* 
 extern "C" int vlni_rowdot_bwd(int dtype, const float* dl, const void* h, long ldh, const float* w, const unsigned char* mask,
                                void* dh, long lddh, float* dw, float* dbias, int rows, int H, void* stream) {
   VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "rowdot_bwd: rows=%d H=%d", rows, H);
-  dim3 grid(cdiv(H, 256), 1), block(256);   // one row slab: dh rows are written exactly once
+  dim3 grid(cdiv(H, 256), std::max(1, std::min(rows / 4, 128))), block(256);   // rows strided over grid.y: each dh row written once
   BY_DTYPE(dtype, hipLaunchKernelGGL((rowdot_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, dl, (const float*)h, ldh, w, mask, (float*)dh, lddh, dw, dbias, rows, H),
            hipLaunchKernelGGL((rowdot_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, dl, (const __bf16*)h, ldh, w, mask, (__bf16*)dh, lddh, dw, dbias, rows, H));
   VLNI_LAUNCH_CHECK();

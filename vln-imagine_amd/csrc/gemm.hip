@@ -35,6 +35,7 @@ struct GemmP {
   float alpha;
   int atomic_f32;               // C is float, accumulate with atomics (split-K wgrad)
   int kt_per_split;
+  int vec_ok;                   // every epilogue tensor allows 4-element vector accesses
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -79,8 +80,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
   constexpr int ES = sizeof(T);
   constexpr int BK = ROWB / ES;        // elements of K per tile
   constexpr int EPC = 16 / ES;         // elements per 16-B chunk
-  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * ROWB];   // 64 KiB
-  constexpr int STAGE = (BM + BN) * ROWB;   // A tile then B tile
+  // ONE 32-KiB stage (A tile then B tile); the next tile waits in registers. 32 KiB/block + <=128 VGPRs
+  // keeps 4 blocks (16 waves) resident per CU so that blocks hide each other's load latency and epilogues.
+  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
+  char* const As = smem;
+  char* const Bs = smem + BM * ROWB;
 
   // ---- tile assignment: contiguous chunk of the tile list per XCD (bijective for any grid) ----
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -116,11 +120,11 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
       sb[i] = ok ? *(const uint4*)(gb[i] + koff * ES) : make_uint4(0, 0, 0, 0);
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *(uint4*)(smem + buf * STAGE + lds_off(lr + 32 * i, lc)) = sa[i];
-      *(uint4*)(smem + buf * STAGE + BM * ROWB + lds_off(lr + 32 * i, lc)) = sb[i];
+      *(uint4*)(As + lds_off(lr + 32 * i, lc)) = sa[i];
+      *(uint4*)(Bs + lds_off(lr + 32 * i, lc)) = sb[i];
     }
   };
 
@@ -134,50 +138,99 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
 
   if (kt0 < kt1) {
     gload(kt0);
-    lstore(0);
-    __syncthreads();
-    int cur = 0;
     for (int kt = kt0; kt < kt1; ++kt) {
-      const bool more = (kt + 1) < kt1;
-      if (more) gload(kt + 1);                       // issue early: latency hides under the MFMAs below
-#pragma unroll
-      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::step(smem + cur * STAGE, smem + cur * STAGE + BM * ROWB, kk, wr * 64, wc * 64, r, h, acc);
-      if (more) lstore(cur ^ 1);                     // write late: other stage, nobody reads it now
+      lstore();                                      // registers -> LDS (tile kt)
       __syncthreads();
-      cur ^= 1;
+      if (kt + 1 < kt1) gload(kt + 1);               // issue early: in flight under the MFMAs below
+#pragma unroll
+      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::step(As, Bs, kk, wr * 64, wc * 64, r, h, acc);
+      __syncthreads();                               // every wave done reading before the stage is rewritten
     }
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (x&3) + 8*(x>>2) + 4*(lane>>5) ----
-  T* C = (T*)p.C;
-  float* Cf = (float*)p.C;
+  // ---- split-K / wgrad: float32 atomics straight from the accumulators (128 contiguous bytes per half-wave) ----
+  if (p.atomic_f32) {
+    float* Cf = (float*)p.C;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wc * 64 + j * 32 + r;
-    if (col >= p.N) continue;
-    const float bv = p.bias ? p.bias[col] : 0.f;
+    for (int j = 0; j < 2; ++j) {
+      const int col = n0 + wc * 64 + j * 32 + r;
+      if (col >= p.N) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int x = 0; x < 16; ++x) {
-        const int row = m0 + wr * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-        if (row >= p.M) continue;
-        float v = acc[i][j][x] * p.alpha + bv;
-        if (p.atomic_f32) {
-          atomicAdd(&Cf[(long)row * p.ldc + col], v);
-          continue;
+        for (int x = 0; x < 16; ++x) {
+          const int row = m0 + wr * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+          if (row < p.M) atomicAdd(&Cf[(long)row * p.ldc + col], acc[i][j][x] * p.alpha);
         }
-        if (p.preact) DT<T>::st((T*)p.preact + (long)row * p.ldp + col, v);
+    }
+    return;
+  }
+
+  // ---- epilogue through LDS: accumulators (col = lane&31, row = (x&3)+8*(x>>2)+4*(lane>>5)) are laid out as a
+  //      [64][128] float32 half-tile, then every thread handles 4 consecutive columns of a row: bias / act' / act /
+  //      residual with 16-B (8-B bf16) global accesses, 32 threads per 128-column row (full cache lines).
+  float* const e = (float*)smem;
+  const int c4 = (tid & 31) * 4;
+  const int gcol = n0 + c4;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && gcol < p.N) {
+    if (p.vec_ok) bv = *(const f32x4*)(p.bias + gcol);
+    else
+      for (int u = 0; u < 4; ++u) bv[u] = (gcol + u < p.N) ? p.bias[gcol + u] : 0.f;
+  }
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if (wr == half) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int x = 0; x < 16; ++x)
+            e[(i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h) * BN + wc * 64 + j * 32 + r] = acc[i][j][x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int rl = (tid >> 5) + 8 * k;
+      const int grow = m0 + half * 64 + rl;
+      if (grow >= p.M || gcol >= p.N) continue;
+      f32x4 v = *(const f32x4*)(e + rl * BN + c4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = v[u] * p.alpha + bv[u];
+      if (p.vec_ok) {
+        if (p.preact) DT<T>::st4((T*)p.preact + (long)grow * p.ldp + gcol, v);
         if (p.dact) {
-          const float z = DT<T>::ld((const T*)p.dact_src + (long)row * p.ldd + col);
-          v *= (p.dact == 1) ? gelu_erf_grad(z) : (z > 0.f ? 1.f : 0.f);
+          const f32x4 z = DT<T>::ld4((const T*)p.dact_src + (long)grow * p.ldd + gcol);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] *= (p.dact == 1) ? gelu_grad_t<T>(z[u]) : (z[u] > 0.f ? 1.f : 0.f);
         }
-        if (p.act == 1) v = gelu_erf(v);
-        else if (p.act == 2) v = fmaxf(v, 0.f);
-        if (p.residual) v += DT<T>::ld((const T*)p.residual + (long)row * p.ldr + col);
-        DT<T>::st(C + (long)row * p.ldc + col, v);
+        if (p.act == 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = gelu_t<T>(v[u]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+        }
+        if (p.residual) v += DT<T>::ld4((const T*)p.residual + (long)grow * p.ldr + gcol);
+        DT<T>::st4((T*)p.C + (long)grow * p.ldc + gcol, v);
+      } else {
+        for (int u = 0; u < 4 && gcol + u < p.N; ++u) {
+          float w = v[u];
+          const long col = gcol + u;
+          if (p.preact) DT<T>::st((T*)p.preact + (long)grow * p.ldp + col, w);
+          if (p.dact) {
+            const float z = DT<T>::ld((const T*)p.dact_src + (long)grow * p.ldd + col);
+            w *= (p.dact == 1) ? gelu_grad_t<T>(z) : (z > 0.f ? 1.f : 0.f);
+          }
+          if (p.act == 1) w = gelu_t<T>(w);
+          else if (p.act == 2) w = fmaxf(w, 0.f);
+          if (p.residual) w += DT<T>::ld((const T*)p.residual + (long)grow * p.ldr + col);
+          DT<T>::st((T*)p.C + (long)grow * p.ldc + col, w);
+        }
       }
     }
+    __syncthreads();
   }
 }
 
@@ -201,6 +254,12 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.residual = (const char*)residual; p.ldr = ldr;
   p.preact = (char*)preact; p.ldp = ldp; p.dact_src = (const char*)dact_src; p.ldd = ldd; p.dact = dact;
   p.alpha = alpha; p.atomic_f32 = atomic_f32;
+  {
+    const uintptr_t am = (uintptr_t)(4 * es - 1);     // 4 elements: 16 B (f32) / 8 B (bf16)
+    auto okp = [&](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & am) == 0 && ld % 4 == 0); };
+    p.vec_ok = (N % 4 == 0) && okp(C, ldc) && okp(residual, ldr) && okp(preact, ldp) && okp(dact_src, ldd) &&
+               (bias == nullptr || (((uintptr_t)bias) & 15) == 0);
+  }
   const int nkt = cdiv(K, bk);
   p.kt_per_split = cdiv(nkt, split_k);
   const int splits = cdiv(nkt, p.kt_per_split);

@@ -188,13 +188,16 @@ __global__ __launch_bounds__(256) void sum_ln_fwd_kernel(SumP sp, const float* _
 }
 
 int ln_grid(int rows) { return max(1, min(cdiv(rows, WAVES), 2048)); }
+// backward ends with 2*H float atomics per block (dgamma/dbeta): keep the grid at ~2 blocks per CU
+int ln_bwd_grid(int rows) { return max(1, min(cdiv(rows, WAVES), 512)); }
 
 }  // namespace
 
-#define LN_DISPATCH(KERNEL, T, ...)                                                                      \
+#define LN_DISPATCH(KERNEL, T, ...) LN_DISPATCH_G(ln_grid(rows), KERNEL, T, __VA_ARGS__)
+#define LN_DISPATCH_G(GRID, KERNEL, T, ...)                                                                      \
   do {                                                                                                   \
     const int nc = H / 256;                                                                              \
-    dim3 grid(ln_grid(rows)), block(256);                                                                \
+    dim3 grid(GRID), block(256);                                                                         \
     hipStream_t st = (hipStream_t)stream;                                                                \
     if (nc == 3) hipLaunchKernelGGL((KERNEL<T, 3>), grid, block, 0, st, __VA_ARGS__);                    \
     else if (nc == 2) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, st, __VA_ARGS__);               \
@@ -234,11 +237,11 @@ extern "C" int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const vo
   if (dtype == VLNI_F32) {
     using TT = float;
     const float* d = (const float*)dy; const float* xx = (const float*)x; float* o = (float*)dx;
-    LN_DISPATCH(ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows);
+    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows);
   } else {
     using TT = __bf16;
     const __bf16* d = (const __bf16*)dy; const __bf16* xx = (const __bf16*)x; __bf16* o = (__bf16*)dx;
-    LN_DISPATCH(ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows);
+    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows);
   }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;

@@ -160,10 +160,16 @@ class ShadowCache:
 
     def __init__(self):
         self._c = {}
+        self.epoch = 0
+
+    def invalidate(self):
+        """Call after parameters were updated behind autograd's back (the fused AdamW kernel writes the
+        arena through raw pointers, which does not move tensor version counters)."""
+        self.epoch += 1
 
     def get(self, params, dtype, transposed=False):
         key = (tuple(id(p) for p in params), dtype, transposed)
-        ver = tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        ver = (self.epoch,) + tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
         hit = self._c.get(key)
         if hit is not None and hit[0] == ver:
             return hit[1]
@@ -196,6 +202,67 @@ def _split_rows(t, sizes):
     return out
 
 
+# When True (set by train.FlatTrainer) parameter gradients are accumulated by the kernels straight into the
+# pre-allocated `.grad` arena views (wgrad atomics, colsum, LayerNorm dgamma/dbeta, embedding scatter) and the
+# autograd functions return None for them: no zero-filled temporaries, no AccumulateGrad add kernels.
+DIRECT_GRAD = False
+
+
+def _direct(*params):
+    return DIRECT_GRAD and all(p is not None and p.grad is not None for p in params)
+
+
+def _packed_grad(params):
+    """One [sum rows, ...] view over the .grad of parameters that sit back to back in the arena, else None."""
+    g0 = params[0].grad
+    ptr = g0.data_ptr()
+    for p in params:
+        if p.grad.data_ptr() != ptr or not p.grad.is_contiguous():
+            return None
+        ptr += p.grad.numel() * 4
+    rows = sum(p.shape[0] for p in params)
+    return torch.as_strided(g0, (rows,) + tuple(g0.shape[1:]), g0.stride(), g0.storage_offset())
+
+
+def _wgrad_to(params, dy, x):
+    """Weight gradient of a (possibly row-packed) projection. Returns per-parameter grads or Nones (direct mode)."""
+    if _direct(*params):
+        view = _packed_grad(params) if len(params) > 1 else params[0].grad
+        if view is not None:
+            wgrad(dy, x, out=view)
+        else:
+            tmp = wgrad(dy, x)
+            for p, t in zip(params, _split_rows(tmp, [q.shape[0] for q in params])):
+                p.grad.add_(t)
+        return (None,) * len(params)
+    if len(params) == 1:
+        return (wgrad(dy, x),)
+    return tuple(_split_rows(wgrad(dy, x), [q.shape[0] for q in params]))
+
+
+def _bgrad_to(params, dy):
+    if _direct(*params):
+        view = _packed_grad(params) if len(params) > 1 else params[0].grad
+        if view is not None:
+            colsum(dy, out=view)
+        else:
+            tmp = colsum(dy)
+            for p, t in zip(params, _split_rows(tmp, [q.shape[0] for q in params])):
+                p.grad.add_(t)
+        return (None,) * len(params)
+    if len(params) == 1:
+        return (colsum(dy),)
+    return tuple(_split_rows(colsum(dy), [q.shape[0] for q in params]))
+
+
+def _ln_bwd_to(dy, x, g, b, mean, rstd, want):
+    """LayerNorm backward with dgamma/dbeta accumulated in place when possible."""
+    if want and _direct(g, b):
+        dx, _, _ = ln_bwd(dy, x, g, mean, rstd, g.grad, b.grad)
+        return dx, None, None
+    return ln_bwd(dy, x, g, mean, rstd, want_param_grads=want)
+
+
 # =====================================================================================
 #  sublayer autograd functions
 # =====================================================================================
@@ -212,30 +279,31 @@ class _SelfAttBlock(torch.autograd.Function):
         c, lse = attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, S, kmask, bias)
         pre = gemm_nt(c, _w((wo,), dt), bias=bo, residual=x2)
         y, mean, rstd = ln_fwd(pre, g, b, eps)
-        ctx.save_for_backward(x2, qkv, c, lse, pre, mean, rstd, kmask, bias, wq, wk, wv, wo, g)
+        ctx.save_for_backward(x2, qkv, c, lse, pre, mean, rstd, kmask, bias)
+        ctx.P = (wq, bq, wk, bk, wv, bv, wo, bo, g, b)
         ctx.dims = (B, S, H)
         return y.view(B, S, H)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, qkv, c, lse, pre, mean, rstd, kmask, bias, wq, wk, wv, wo, g = ctx.saved_tensors
+        x2, qkv, c, lse, pre, mean, rstd, kmask, bias = ctx.saved_tensors
+        wq, bq, wk, bk, wv, bv, wo, bo, g, b = ctx.P
         B, S, H = ctx.dims
         dt = x2.dtype
         ng = ctx.needs_input_grad
         wparams = any(ng[4:])
-        dy2 = _rows(dy)
-        dpre, dg, db = ln_bwd(dy2, pre, g, mean, rstd, want_param_grads=wparams)
-        dwo = wgrad(dpre, c) if wparams else None
-        dbo = colsum(dpre) if wparams else None
+        dpre, dg, db = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams)
+        dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = None
+        if wparams:
+            (dwo,), (dbo,) = _wgrad_to((wo,), dpre, c), _bgrad_to((bo,), dpre)
         dc = gemm_nt(dpre, _w((wo,), dt, True))
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias) if (bias is not None and ng[2]) else None
         attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], c, dc, lse, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:],
                  B, S, S, kmask, bias, dbias)
-        dwq = dwk = dwv = dbq = dbk = dbv = None
         if wparams:
-            dwq, dwk, dwv = _split_rows(wgrad(dqkv, x2), (H, H, H))
-            dbq, dbk, dbv = _split_rows(colsum(dqkv), (H, H, H))
+            dwq, dwk, dwv = _wgrad_to((wq, wk, wv), dqkv, x2)
+            dbq, dbk, dbv = _bgrad_to((bq, bk, bv), dqkv)
         dx = gemm_nt(dqkv, _w((wq, wk, wv), dt, True), residual=dpre).view(B, S, H) if ng[0] else None
         return dx, None, dbias, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
 
@@ -252,22 +320,25 @@ class _FfnBlock(torch.autograd.Function):
         a = gemm_nt(x2, _w((w1,), dt), bias=b1, act=1, preact=z)
         pre = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2)
         y, mean, rstd = ln_fwd(pre, g, b, eps)
-        ctx.save_for_backward(x2, z, a, pre, mean, rstd, w1, w2, g)
+        ctx.save_for_backward(x2, z, a, pre, mean, rstd)
+        ctx.P = (w1, b1, w2, b2, g, b)
         ctx.shp = shp
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, z, a, pre, mean, rstd, w1, w2, g = ctx.saved_tensors
+        x2, z, a, pre, mean, rstd = ctx.saved_tensors
+        w1, b1, w2, b2, g, b = ctx.P
         dt = x2.dtype
         ng = ctx.needs_input_grad
         wparams = any(ng[2:])
-        dpre, dg, db = ln_bwd(_rows(dy), pre, g, mean, rstd, want_param_grads=wparams)
-        dw2 = wgrad(dpre, a) if wparams else None
-        db2 = colsum(dpre) if wparams else None
+        dpre, dg, db = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams)
+        dw1 = db1 = dw2 = db2 = None
+        if wparams:
+            (dw2,), (db2,) = _wgrad_to((w2,), dpre, a), _bgrad_to((b2,), dpre)
         dz = gemm_nt(dpre, _w((w2,), dt, True), dact_src=z, dact=1)      # GELU' fused in the dgrad epilogue
-        dw1 = wgrad(dz, x2) if wparams else None
-        db1 = colsum(dz) if wparams else None
+        if wparams:
+            (dw1,), (db1,) = _wgrad_to((w1,), dz, x2), _bgrad_to((b1,), dz)
         dx = gemm_nt(dz, _w((w1,), dt, True), residual=dpre).view(ctx.shp) if ng[0] else None
         return dx, None, dw1, db1, dw2, db2, dg, db
 
@@ -294,22 +365,32 @@ class _XAttPairBlock(torch.autograd.Function):
         yl, mean_l, rstd_l = ln_fwd(pre_l, g, b, eps)
         yv, mean_v, rstd_v = ln_fwd(pre_v, g, b, eps)
         ctx.save_for_backward(l2, v2, ql, qv, cl, cv, lse_l, lse_v, pre_l, pre_v, mean_l, rstd_l, mean_v, rstd_v,
-                              mask_l, mask_v, wq, wk, wv, wo, g)
+                              mask_l, mask_v)
+        ctx.P = (wq, bq, wk, bk, wv, bv, wo, bo, g, b)
         ctx.dims = (B, Sl, Sv, H)
         return yl.view(B, Sl, H), yv.view(B, Sv, H)
 
     @staticmethod
     def backward(ctx, dyl, dyv):
         (l2, v2, ql, qv, cl, cv, lse_l, lse_v, pre_l, pre_v, mean_l, rstd_l, mean_v, rstd_v,
-         mask_l, mask_v, wq, wk, wv, wo, g) = ctx.saved_tensors
+         mask_l, mask_v) = ctx.saved_tensors
+        wq, bq, wk, bk, wv, bv, wo, bo, g, b = ctx.P
         B, Sl, Sv, H = ctx.dims
         dt = l2.dtype
         ng = ctx.needs_input_grad
         wparams = any(ng[5:])
-        dpl, dg, db = ln_bwd(_rows(dyl), pre_l, g, mean_l, rstd_l, want_param_grads=wparams)
-        dpv, dg, db = ln_bwd(_rows(dyv), pre_v, g, mean_v, rstd_v, dg, db, want_param_grads=wparams)
-        dwo = dbo = None
-        if wparams:
+        direct = wparams and _direct(wq, bq, wk, bk, wv, bv, wo, bo, g, b)
+        dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = dg = db = None
+        if direct or not wparams:
+            dpl, _, _ = _ln_bwd_to(_rows(dyl), pre_l, g, b, mean_l, rstd_l, wparams)
+            dpv, _, _ = _ln_bwd_to(_rows(dyv), pre_v, g, b, mean_v, rstd_v, wparams)
+        else:
+            dpl, dg, db = ln_bwd(_rows(dyl), pre_l, g, mean_l, rstd_l)
+            dpv, dg, db = ln_bwd(_rows(dyv), pre_v, g, mean_v, rstd_v, dg, db)
+        if direct:
+            _wgrad_to((wo,), dpl, cl); _wgrad_to((wo,), dpv, cv)
+            _bgrad_to((bo,), dpl); _bgrad_to((bo,), dpv)
+        elif wparams:
             dwo = wgrad(dpv, cv, wgrad(dpl, cl))
             dbo = colsum(dpv, colsum(dpl))
         wot = _w((wo,), dt, True)
@@ -319,8 +400,10 @@ class _XAttPairBlock(torch.autograd.Function):
                  B, Sl, Sv, mask_v)
         attn_bwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], cv, dcv, lse_v, dqv[:, :H], dql[:, H:2 * H], dql[:, 2 * H:],
                  B, Sv, Sl, mask_l)
-        dwq = dwk = dwv = dbq = dbk = dbv = None
-        if wparams:
+        if direct:
+            _wgrad_to((wq, wk, wv), dql, l2); _wgrad_to((wq, wk, wv), dqv, v2)
+            _bgrad_to((bq, bk, bv), dql); _bgrad_to((bq, bk, bv), dqv)
+        elif wparams:
             dwq, dwk, dwv = _split_rows(wgrad(dqv, v2, wgrad(dql, l2)), (H, H, H))
             dbq, dbk, dbv = _split_rows(colsum(dqv, colsum(dql)), (H, H, H))
         wt = _w((wq, wk, wv), dt, True)
@@ -344,28 +427,30 @@ class _XAttBlock(torch.autograd.Function):
         a, lse = attn_fwd(q, kv[:, :H], kv[:, H:], B, Sq, Sk, mask_c)
         pre = gemm_nt(a, _w((wo,), dt), bias=bo, residual=x2)
         y, mean, rstd = ln_fwd(pre, g, b, eps)
-        ctx.save_for_backward(x2, c2, q, kv, a, lse, pre, mean, rstd, mask_c, wq, wk, wv, wo, g)
+        ctx.save_for_backward(x2, c2, q, kv, a, lse, pre, mean, rstd, mask_c)
+        ctx.P = (wq, bq, wk, bk, wv, bv, wo, bo, g, b)
         ctx.dims = (B, Sq, Sk, H)
         return y.view(B, Sq, H)
 
     @staticmethod
     def backward(ctx, dy):
-        x2, c2, q, kv, a, lse, pre, mean, rstd, mask_c, wq, wk, wv, wo, g = ctx.saved_tensors
+        x2, c2, q, kv, a, lse, pre, mean, rstd, mask_c = ctx.saved_tensors
+        wq, bq, wk, bk, wv, bv, wo, bo, g, b = ctx.P
         B, Sq, Sk, H = ctx.dims
         dt = x2.dtype
         ng = ctx.needs_input_grad
         wparams = any(ng[4:])
-        dpre, dg, db = ln_bwd(_rows(dy), pre, g, mean, rstd, want_param_grads=wparams)
-        dwo = wgrad(dpre, a) if wparams else None
-        dbo = colsum(dpre) if wparams else None
+        dpre, dg, db = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams)
+        dwo = dbo = dwq = dbq = dwk = dwv = dbk = dbv = None
+        if wparams:
+            (dwo,), (dbo,) = _wgrad_to((wo,), dpre, a), _bgrad_to((bo,), dpre)
         da = gemm_nt(dpre, _w((wo,), dt, True))
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         attn_bwd(q, kv[:, :H], kv[:, H:], a, da, lse, dq, dkv[:, :H], dkv[:, H:], B, Sq, Sk, mask_c)
-        dwq = dbq = dwk = dwv = dbk = dbv = None
         if wparams:
-            dwq, dbq = wgrad(dq, x2), colsum(dq)
-            dwk, dwv = _split_rows(wgrad(dkv, c2), (H, H))
-            dbk, dbv = _split_rows(colsum(dkv), (H, H))
+            (dwq,), (dbq,) = _wgrad_to((wq,), dq, x2), _bgrad_to((bq,), dq)
+            dwk, dwv = _wgrad_to((wk, wv), dkv, c2)
+            dbk, dbv = _bgrad_to((bk, bv), dkv)
         dx = gemm_nt(dq, _w((wq,), dt, True), residual=dpre).view(B, Sq, H) if ng[0] else None
         dc = gemm_nt(dkv, _w((wk, wv), dt, True)).view(B, Sk, H) if ng[1] else None
         return dx, dc, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
@@ -387,7 +472,7 @@ class _Linear(torch.autograd.Function):
         z = torch.empty((x2.shape[0], w.shape[0]), dtype=dt, device=x.device) if act else None
         y = gemm_nt(x2, _w((w,), dt), bias=b, act=act, preact=z)
         ctx.save_for_backward(x2, z, w)
-        ctx.act, ctx.shp, ctx.in_dtype = act, shp, x.dtype
+        ctx.act, ctx.shp, ctx.in_dtype, ctx.b = act, shp, x.dtype, b
         return y.view(shp[:-1] + (w.shape[0],))
 
     @staticmethod
@@ -400,8 +485,8 @@ class _Linear(torch.autograd.Function):
             dz = torch.empty_like(dy2)
             _lib.call("vlni_act_bwd", _dt(dy2), ctx.act, dy2.data_ptr(), z.data_ptr(), dz.data_ptr(), dy2.numel(), _st())
             dy2 = dz
-        dw = wgrad(dy2, x2) if ng[1] else None
-        db = colsum(dy2) if ng[2] else None
+        dw = _wgrad_to((w,), dy2, x2)[0] if ng[1] else None
+        db = _bgrad_to((ctx.b,), dy2)[0] if ng[2] else None
         dx = None
         if ng[0]:
             dx = gemm_nt(dy2, _w((w,), dt, True))
@@ -418,14 +503,14 @@ class _LayerNorm(torch.autograd.Function):
         x2 = _rows(_chk(x, "x"))
         y, mean, rstd = ln_fwd(x2, g, b, eps)
         ctx.save_for_backward(x2, g, mean, rstd)
-        ctx.shp = shp
+        ctx.shp, ctx.b = shp, b
         return y.view(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, g, mean, rstd = ctx.saved_tensors
         wp = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
-        dx, dg, db = ln_bwd(_rows(dy), x2, g, mean, rstd, want_param_grads=wp)
+        dx, dg, db = _ln_bwd_to(_rows(dy), x2, g, ctx.b, mean, rstd, wp)
         return dx.view(ctx.shp), dg, db, None
 
 
@@ -489,6 +574,7 @@ class _SumLayerNorm(torch.autograd.Function):
         ctx.save_for_backward(xs, g, mean, rstd, *[i for i in idxs if i is not None])
         ctx.spec, ctx.idx_pos = spec, [k for k, i in enumerate(idxs) if i is not None]
         ctx.shapes = [(s.shape, s.dtype) for s in srcs]
+        ctx.b, ctx.tables = b, [s if k == "gather" else None for s, (k, _) in zip(srcs, spec)]
         return y
 
     @staticmethod
@@ -496,7 +582,7 @@ class _SumLayerNorm(torch.autograd.Function):
         xs, g, mean, rstd, *idl = ctx.saved_tensors
         idxs = dict(zip(ctx.idx_pos, idl))
         ng = ctx.needs_input_grad
-        dsum, dg, db = ln_bwd(_rows(dy), xs, g, mean, rstd, want_param_grads=ng[5] or ng[6])
+        dsum, dg, db = _ln_bwd_to(_rows(dy), xs, g, ctx.b, mean, rstd, ng[5] or ng[6])
         rows, H = dsum.shape
         grads = []
         for k, ((kind, _), (shape, dtype)) in enumerate(zip(ctx.spec, ctx.shapes)):
@@ -507,10 +593,12 @@ class _SumLayerNorm(torch.autograd.Function):
             elif kind == "bcast":
                 grads.append(colsum(dsum).view(shape).to(dtype))
             else:
-                tg = torch.zeros(shape, dtype=torch.float32, device=dsum.device)
+                tab = ctx.tables[k]
+                direct = _direct(tab) and tab.grad.is_contiguous()
+                tg = tab.grad if direct else torch.zeros(shape, dtype=torch.float32, device=dsum.device)
                 _lib.call("vlni_scatter_add_rows", _dt(dsum), dsum.data_ptr(), dsum.stride(0), idxs[k].data_ptr(),
                           tg.data_ptr(), rows, H, _st())
-                grads.append(tg)
+                grads.append(None if direct else tg)
         return (None, None, None, None, None, dg, db) + tuple(grads)
 
 

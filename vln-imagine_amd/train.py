@@ -1,0 +1,83 @@
+"""Optimizer side of the measured step, MI355X-first: all trainable parameters and their gradients
+live in two flat float32 arenas (one memset to zero the grads, one fused clip+AdamW kernel over
+everything, gradient all-reduce over RCCL in a few large chunks instead of per-tensor buckets).
+
+Restates the tail of Seq2SeqCMTAgent.train (VLN-HAMT/finetune_src/r2r/agent_cmt.py:809-832):
+zero_grad, backward, clip_grad_norm_(40.), AdamW step; and DDP's gradient averaging (:61-63)."""
+import torch
+import torch.distributed as dist
+
+from . import _lib, ops
+
+
+class FlatTrainer:
+    def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=40.0,
+                 chunk_mb=128):
+        self.model = model
+        # arena order: the q/k/v projections of every attention module sit back to back (weights, then biases), so
+        # the packed [2304,768] QKV gradient is ONE wgrad GEMM into a contiguous view (ops._packed_grad)
+        order, seen = [], set()
+        for mod in model.modules():
+            if all(hasattr(mod, n) for n in ("query", "key", "value")):
+                for attr in ("weight", "bias"):
+                    for n in ("query", "key", "value"):
+                        p = getattr(getattr(mod, n), attr)
+                        if p is not None and p.requires_grad and id(p) not in seen:
+                            order.append(p); seen.add(id(p))
+        for p in model.parameters():
+            if p.requires_grad and id(p) not in seen:
+                order.append(p); seen.add(id(p))
+        self.params = order
+        dev = self.params[0].device
+        assert dev.type == "cuda", "FlatTrainer needs the model on the GPU"
+        offs, n = [], 0
+        for p in self.params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4              # 16-byte aligned slots
+        self.n = n
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, offs):
+                self.flat_p[o:o + p.numel()].copy_(p.data.reshape(-1))
+                p.data = self.flat_p[o:o + p.numel()].view(p.shape)
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self.hp = (lr, betas[0], betas[1], eps, weight_decay)
+        self.max_norm = max_norm
+        self.step_no = 0
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.coef = torch.ones(1, dtype=torch.float32, device=dev)
+        self.chunk = chunk_mb * (1 << 20) // 4
+        ops.SHADOWS.invalidate()
+        ops.DIRECT_GRAD = True
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def allreduce_grads(self):
+        """Mean of gradients over the data-parallel group: RCCL all-reduce on the flat arena in large chunks."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        ws = dist.get_world_size()
+        works = []
+        for o in range(0, self.n, self.chunk):
+            works.append(dist.all_reduce(self.flat_g[o:o + self.chunk], op=dist.ReduceOp.SUM, async_op=True))
+        for w in works:
+            w.wait()
+        self.flat_g.mul_(1.0 / ws)
+
+    def step(self):
+        st = torch.cuda.current_stream().cuda_stream
+        self.step_no += 1
+        lr, b1, b2, eps, wd = self.hp
+        self.sumsq.zero_()
+        _lib.call("vlni_sumsq", self.flat_g.data_ptr(), self.n, self.sumsq.data_ptr(), st)
+        _lib.call("vlni_clip_coef", self.sumsq.data_ptr(), self.max_norm, self.coef.data_ptr(), st)
+        _lib.call("vlni_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                  0, self.n, lr, b1, b2, eps, wd, self.step_no, self.coef.data_ptr(), st)
+        ops.SHADOWS.invalidate()
+
+    def grad_norm(self):
+        return float(self.sumsq.sqrt())
