@@ -35,6 +35,11 @@ int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, vo
                  const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
                  const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32, void* stream);
 
+/* Weight gradient without transposes: C[N,K] += A[M,N]^T B[M,K] (bf16 in, float32 atomics out, split over M rows);
+ * colsum[N] (optional) += column sums of A = bias gradient. Autograd of nn.Linear (R:101-103,...). */
+int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                      float* colsum, int split, void* stream);
+
 /* Fused masked attention, head dim 64, heads packed along the row (head h at column h*64), Sk <= 128.
  * kmask [B,Sk] additive float32 ((1-m)*-10000, R:1010-1012) or NULL; bias [B,Sq,Sk] additive float32
  * shared by all heads (graph_sprels, D:1145-1147) or NULL; lse [B,nh,Sq] float32.

@@ -331,3 +331,22 @@ def test_adamw_and_clip(ops):
                   1e-8, 0.01, step, coef.data_ptr(), st)
         assert _err(p, pr.detach()) < 1e-5, step
     assert _err(sh.float(), p) < 2e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (148, 768, 768), (5504, 768, 768), (333, 3072, 768), (70, 768, 3072), (2431, 1536, 768)])
+def test_wgrad_tn_bf16_exact_and_random(ops, M, N, K):
+    """transposing-read TN kernel: exact on small integers (catches any tr-read lane/row slip), close on random data,
+    fused bias gradient, accumulation into an existing buffer."""
+    g = torch.Generator().manual_seed(7)
+    dyi = torch.randint(-2, 3, (M, N), generator=g).float()
+    xi = torch.randint(-2, 3, (M, K), generator=g).float()
+    out, cs = ops.wgrad(dyi.bfloat16().cuda(), xi.bfloat16().cuda(), want_colsum=True)
+    assert torch.equal(out.cpu(), dyi.t() @ xi), "integer wgrad mismatch"
+    assert torch.equal(cs.cpu(), dyi.sum(0))
+    dy, x = _rand((M, N), torch.bfloat16, 5, 0.1), _rand((M, K), torch.bfloat16, 6, 0.5)
+    ref = dy.double().t() @ x.double()
+    out = ops.wgrad(dy, x)
+    assert _err(out, ref) < 2e-3 * max(1.0, ref.abs().max().item())
+    out2, cs2 = ops.wgrad(dy, x, out=out, want_colsum=True)
+    assert _err(out2, 2 * ref) < 4e-3 * max(1.0, ref.abs().max().item())
+    assert _err(cs2, dy.double().sum(0)) < 2e-3 * max(1.0, dy.double().sum(0).abs().max().item())

@@ -234,6 +234,130 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient without transposes:  C[N,K] += A[M,N]^T * B[M,K]   (bf16 in, float32 atomics out)
+//   A = dY (rows = tokens, N contiguous), B = X (rows = tokens, K contiguous); the reduction runs over ROWS,
+//   so both MFMA operands are needed "k-major". The tiles are staged exactly as they lie in memory
+//   ([64 rows][128 cols] = 256-byte rows, 16-byte chunks XOR-swizzled) and the fragments are fetched with the
+//   gfx950 transposing LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group, column-major to the
+//   lanes): two reads give a lane the 8 consecutive reduction indices of its output row/column.
+//   Swizzle = guide image (b): chunk ^ (((row&3)<<2) | ((row>>2)&3)) -> conflict-free for the 32x32x16 tr reads.
+//   Optionally the k-tile-0 blocks also reduce the columns of A (bias gradient), so no separate colsum pass.
+struct TnP {
+  const __bf16* A; long lda;
+  const __bf16* B; long ldb;
+  float* C; long ldc;
+  int M, N, K;
+  int mt_per_split;
+  float* colsum;
+};
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int tr_off(int row, int ch) { return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row_lo, int ch, int half8) {
+  using lds_ptr = __attribute__((address_space(3))) s16x4*;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + tr_off(row_lo, ch) + half8));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + tr_off(row_lo + 4, ch) + half8));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
+  constexpr int BR = 64;                                   // reduction rows per stage
+  __shared__ __attribute__((aligned(16))) char smem[2 * BR * 256];
+  char* const As = smem;
+  char* const Bs = smem + BR * 256;
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int ntk = (p.K + BN - 1) / BN;
+  const int n0 = (wgid / ntk) * BM, k0 = (wgid % ntk) * BN;
+  const int nmt = (p.M + BR - 1) / BR;
+  const int mt0 = blockIdx.z * p.mt_per_split, mt1 = min(nmt, mt0 + p.mt_per_split);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  const int ch = tid & 15, lr = tid >> 4;                  // staging: 16 chunks per 256-byte row, 16 rows per pass
+  const bool a_ok = (n0 + ch * 8) < p.N, b_ok = (k0 + ch * 8) < p.K;   // N, K multiples of 8
+  const __bf16* ga = p.A + n0 + ch * 8;
+  const __bf16* gb = p.B + k0 + ch * 8;
+  uint4 sa[4], sb[4];
+  auto gload = [&](int mt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = mt * BR + lr + 16 * i;
+      const bool ok = row < p.M;
+      sa[i] = (ok && a_ok) ? *(const uint4*)(ga + (long)row * p.lda) : make_uint4(0, 0, 0, 0);
+      sb[i] = (ok && b_ok) ? *(const uint4*)(gb + (long)row * p.ldb) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(uint4*)(As + tr_off(lr + 16 * i, ch)) = sa[i];
+      *(uint4*)(Bs + tr_off(lr + 16 * i, ch)) = sb[i];
+    }
+  };
+  // fragment addressing: 16-lane group g = lane>>4 -> (h = g>>1, column block cb = g&1); lane 4q+p of the group
+  // addresses row q, columns 4p..4p+3 of the 4x16 block
+  const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
+  const int frow = 8 * h + qq;                             // + 16*kk (+4 for the second read)
+  const int half8 = 8 * (pp & 1);
+  const int cha = (wr * 64 + 16 * cb) / 8 + (pp >> 1);     // + 4*i  (32 columns = 4 chunks)
+  const int chb = (wc * 64 + 16 * cb) / 8 + (pp >> 1);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+  const bool do_cs = p.colsum != nullptr && k0 == 0 && tid < BM;
+  float cs = 0.f;
+
+  if (mt0 < mt1) {
+    gload(mt0);
+    for (int mt = mt0; mt < mt1; ++mt) {
+      lstore();
+      __syncthreads();
+      if (mt + 1 < mt1) gload(mt + 1);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = tr_frag(As, 16 * kk + frow, cha + 4 * i, half8);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = tr_frag(Bs, 16 * kk + frow, chb + 4 * j, half8);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      if (do_cs) {
+#pragma unroll 8
+        for (int row = 0; row < BR; ++row) cs += (float)*(const __bf16*)(As + tr_off(row, tid >> 3) + (tid & 7) * 2);
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = k0 + wc * 64 + j * 32 + r;
+    if (col >= p.K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int row = n0 + wr * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+        if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
+      }
+  }
+  if (do_cs && n0 + tid < p.N) atomicAdd(p.colsum + n0 + tid, cs);
+}
+
 }  // namespace
 
 extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
@@ -268,6 +392,24 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
     hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, p);
   else
     hipLaunchKernelGGL(gemm_nt_kernel<__bf16>, grid, dim3(NT), 0, (hipStream_t)stream, p);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// C[N,K] += A[M,N]^T B[M,K] (bf16 operands as they lie in memory, float32 atomic accumulation, split over M);
+// colsum (optional, [N]) += column sums of A (the bias gradient). Replaces autograd's weight-gradient matmuls.
+extern "C" int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                                 float* colsum, int split, void* stream) {
+  VLNI_CHECK(M > 0 && N > 0 && K > 0 && split >= 1, VLNI_EINVAL, "gemm_tn: bad problem %d %d %d split %d", M, N, K, split);
+  VLNI_CHECK(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, VLNI_EINVAL, "gemm_tn: N/K/lda/ldb multiples of 8");
+  VLNI_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, VLNI_EINVAL, "gemm_tn: A/B must be 16-B aligned");
+  TnP p;
+  p.A = (const __bf16*)A; p.lda = lda; p.B = (const __bf16*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.colsum = colsum;
+  const int nmt = cdiv(M, 64);
+  p.mt_per_split = cdiv(nmt, split);
+  dim3 grid(cdiv(N, BM) * cdiv(K, BN), 1, cdiv(nmt, p.mt_per_split));
+  hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(NT), 0, (hipStream_t)stream, p);
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

@@ -74,21 +74,33 @@ def transpose_pad(x, rpad, dtype=None):
     return out
 
 
-def wgrad(dy, x, out=None):
-    """dW[N,K] (+)= dy[M,N]^T @ x[M,K], float32, split over rows with atomics."""
+def wgrad(dy, x, out=None, colsum_out=None, want_colsum=False):
+    """dW[N,K] (+)= dy[M,N]^T @ x[M,K] in float32 (atomics, split over rows); optionally also the bias gradient
+    db[N] (+)= column sums of dy. bf16: transposing-read TN kernel straight on dy / x (colsum fused);
+    fp32 (parity path): explicit transposes + the NT kernel + a colsum pass. Returns dW or (dW, db)."""
     M, N = dy.shape
     K = x.shape[1]
-    mp = (M + 63) // 64 * 64
-    dyt = transpose_pad(dy, mp)
-    xt = transpose_pad(x, mp)
+    dev = dy.device
     if out is None:
-        out = torch.zeros((N, K), dtype=torch.float32, device=dy.device)
+        out = torch.zeros((N, K), dtype=torch.float32, device=dev)
+    if (want_colsum or colsum_out is not None) and colsum_out is None:
+        colsum_out = torch.zeros((N,), dtype=torch.float32, device=dev)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    bk = 64 if dy.dtype == torch.bfloat16 else 32
-    nkt = (mp + bk - 1) // bk
-    split = max(1, min(nkt, 512 // tiles))
-    gemm_nt(dyt, xt, out=out, split_k=split, atomic=True)
-    return out
+    if dy.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
+        split = max(1, min((M + 63) // 64, 8, round(512 / tiles)))
+        _lib.call("vlni_gemm_tn_bf16", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
+                  M, N, K, _p(colsum_out), split, _st())
+    else:
+        mp = (M + 63) // 64 * 64
+        dyt = transpose_pad(dy, mp)
+        xt = transpose_pad(x, mp)
+        bk = 64 if dy.dtype == torch.bfloat16 else 32
+        nkt = (mp + bk - 1) // bk
+        split = max(1, min(nkt, 8, round(512 / tiles)))
+        gemm_nt(dyt, xt, out=out, split_k=split, atomic=True)
+        if colsum_out is not None:
+            colsum(dy, out=colsum_out)
+    return (out, colsum_out) if colsum_out is not None else out
 
 
 def colsum(x, out=None):
@@ -255,6 +267,25 @@ def _bgrad_to(params, dy):
     return tuple(_split_rows(colsum(dy), [q.shape[0] for q in params]))
 
 
+def _wb_grad_to(ws, bs, dy, x):
+    """Weight + bias gradients of one (possibly row-packed) projection in a single pass over dy / x."""
+    rows = [w.shape[0] for w in ws]
+    if _direct(*ws, *bs):
+        wv = _packed_grad(ws) if len(ws) > 1 else ws[0].grad
+        bv = _packed_grad(bs) if len(bs) > 1 else bs[0].grad
+        if wv is not None and bv is not None:
+            wgrad(dy, x, out=wv, colsum_out=bv)
+        else:
+            gw, gb = wgrad(dy, x, want_colsum=True)
+            for prm, t in zip(ws, _split_rows(gw, rows)):
+                prm.grad.add_(t)
+            for prm, t in zip(bs, _split_rows(gb, rows)):
+                prm.grad.add_(t)
+        return (None,) * len(ws), (None,) * len(bs)
+    gw, gb = wgrad(dy, x, want_colsum=True)
+    return tuple(_split_rows(gw, rows)), tuple(_split_rows(gb, rows))
+
+
 def _ln_bwd_to(dy, x, g, b, mean, rstd, want):
     """LayerNorm backward with dgamma/dbeta accumulated in place when possible."""
     if want and _direct(g, b):
@@ -295,15 +326,14 @@ class _SelfAttBlock(torch.autograd.Function):
         dpre, dg, db = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams)
         dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = None
         if wparams:
-            (dwo,), (dbo,) = _wgrad_to((wo,), dpre, c), _bgrad_to((bo,), dpre)
+            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dpre, c)
         dc = gemm_nt(dpre, _w((wo,), dt, True))
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias) if (bias is not None and ng[2]) else None
         attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], c, dc, lse, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:],
                  B, S, S, kmask, bias, dbias)
         if wparams:
-            dwq, dwk, dwv = _wgrad_to((wq, wk, wv), dqkv, x2)
-            dbq, dbk, dbv = _bgrad_to((bq, bk, bv), dqkv)
+            (dwq, dwk, dwv), (dbq, dbk, dbv) = _wb_grad_to((wq, wk, wv), (bq, bk, bv), dqkv, x2)
         dx = gemm_nt(dqkv, _w((wq, wk, wv), dt, True), residual=dpre).view(B, S, H) if ng[0] else None
         return dx, None, dbias, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
 
@@ -335,10 +365,10 @@ class _FfnBlock(torch.autograd.Function):
         dpre, dg, db = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams)
         dw1 = db1 = dw2 = db2 = None
         if wparams:
-            (dw2,), (db2,) = _wgrad_to((w2,), dpre, a), _bgrad_to((b2,), dpre)
+            (dw2,), (db2,) = _wb_grad_to((w2,), (b2,), dpre, a)
         dz = gemm_nt(dpre, _w((w2,), dt, True), dact_src=z, dact=1)      # GELU' fused in the dgrad epilogue
         if wparams:
-            (dw1,), (db1,) = _wgrad_to((w1,), dz, x2), _bgrad_to((b1,), dz)
+            (dw1,), (db1,) = _wb_grad_to((w1,), (b1,), dz, x2)
         dx = gemm_nt(dz, _w((w1,), dt, True), residual=dpre).view(ctx.shp) if ng[0] else None
         return dx, None, dw1, db1, dw2, db2, dg, db
 
@@ -388,8 +418,7 @@ class _XAttPairBlock(torch.autograd.Function):
             dpl, dg, db = ln_bwd(_rows(dyl), pre_l, g, mean_l, rstd_l)
             dpv, dg, db = ln_bwd(_rows(dyv), pre_v, g, mean_v, rstd_v, dg, db)
         if direct:
-            _wgrad_to((wo,), dpl, cl); _wgrad_to((wo,), dpv, cv)
-            _bgrad_to((bo,), dpl); _bgrad_to((bo,), dpv)
+            _wb_grad_to((wo,), (bo,), dpl, cl); _wb_grad_to((wo,), (bo,), dpv, cv)
         elif wparams:
             dwo = wgrad(dpv, cv, wgrad(dpl, cl))
             dbo = colsum(dpv, colsum(dpl))
@@ -401,8 +430,7 @@ class _XAttPairBlock(torch.autograd.Function):
         attn_bwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], cv, dcv, lse_v, dqv[:, :H], dql[:, H:2 * H], dql[:, 2 * H:],
                  B, Sv, Sl, mask_l)
         if direct:
-            _wgrad_to((wq, wk, wv), dql, l2); _wgrad_to((wq, wk, wv), dqv, v2)
-            _bgrad_to((bq, bk, bv), dql); _bgrad_to((bq, bk, bv), dqv)
+            _wb_grad_to((wq, wk, wv), (bq, bk, bv), dql, l2); _wb_grad_to((wq, wk, wv), (bq, bk, bv), dqv, v2)
         elif wparams:
             dwq, dwk, dwv = _split_rows(wgrad(dqv, v2, wgrad(dql, l2)), (H, H, H))
             dbq, dbk, dbv = _split_rows(colsum(dqv, colsum(dql)), (H, H, H))
@@ -443,14 +471,13 @@ class _XAttBlock(torch.autograd.Function):
         dpre, dg, db = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams)
         dwo = dbo = dwq = dbq = dwk = dwv = dbk = dbv = None
         if wparams:
-            (dwo,), (dbo,) = _wgrad_to((wo,), dpre, a), _bgrad_to((bo,), dpre)
+            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dpre, a)
         da = gemm_nt(dpre, _w((wo,), dt, True))
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
         attn_bwd(q, kv[:, :H], kv[:, H:], a, da, lse, dq, dkv[:, :H], dkv[:, H:], B, Sq, Sk, mask_c)
         if wparams:
-            (dwq,), (dbq,) = _wgrad_to((wq,), dq, x2), _bgrad_to((bq,), dq)
-            dwk, dwv = _wgrad_to((wk, wv), dkv, c2)
-            dbk, dbv = _bgrad_to((bk, bv), dkv)
+            (dwq,), (dbq,) = _wb_grad_to((wq,), (bq,), dq, x2)
+            (dwk, dwv), (dbk, dbv) = _wb_grad_to((wk, wv), (bk, bv), dkv, c2)
         dx = gemm_nt(dq, _w((wq,), dt, True), residual=dpre).view(B, Sq, H) if ng[0] else None
         dc = gemm_nt(dkv, _w((wk, wv), dt, True)).view(B, Sk, H) if ng[1] else None
         return dx, dc, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
@@ -485,8 +512,13 @@ class _Linear(torch.autograd.Function):
             dz = torch.empty_like(dy2)
             _lib.call("vlni_act_bwd", _dt(dy2), ctx.act, dy2.data_ptr(), z.data_ptr(), dz.data_ptr(), dy2.numel(), _st())
             dy2 = dz
-        dw = _wgrad_to((w,), dy2, x2)[0] if ng[1] else None
-        db = _bgrad_to((ctx.b,), dy2)[0] if ng[2] else None
+        dw = db = None
+        if ng[1] and ng[2]:
+            (dw,), (db,) = _wb_grad_to((w,), (ctx.b,), dy2, x2)
+        elif ng[1]:
+            dw = _wgrad_to((w,), dy2, x2)[0]
+        elif ng[2]:
+            db = _bgrad_to((ctx.b,), dy2)[0]
         dx = None
         if ng[0]:
             dx = gemm_nt(dy2, _w((w,), dt, True))
