@@ -24,3 +24,24 @@ def hamt_variant_setup(name):
     kw = dict(HAMT_EP)
     kw.update(epkw)
     return cfg, synth.HamtEpisode(**kw)
+
+# ---- DUET -----------------------------------------------------------------------------------------
+from vln_imagine_amd.duet.config import DuetConfig  # noqa: E402
+
+DUET_VARIANTS = {
+    "c1_shipped": (dict(), dict()),                                  # sprels + dynamic fusion + aux (txt detached)
+    "c1_nofuse_nosprel": (dict(glocal_fuse=False, graph_sprels=False, fix_lang_inside_cosine_model=False), dict()),
+    "c1_T3_dense": (dict(), dict(T=3, ragged=False)),
+    "c1_infonce": (dict(aux_loss_type="contrastive-InfoNCE"), dict()),
+    "c1_fixlang": (dict(fix_lang_embedding=True, update_lang_bert=False), dict()),
+}
+DUET_C1 = dict(num_l_layers=2, num_pano_layers=2, num_x_layers=2)
+DUET_EP = dict(tag="golden", B=4, L=80, V=36, I=4, T=2, ragged=True)
+
+
+def duet_variant_setup(name):
+    over, epkw = DUET_VARIANTS[name]
+    cfg = DuetConfig(**DUET_C1, **over)
+    kw = dict(DUET_EP)
+    kw.update(epkw)
+    return cfg, synth.DuetEpisode(**kw)

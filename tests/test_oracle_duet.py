@@ -1,0 +1,57 @@
+"""CPU: the DUET oracle (oracle/duet_oracle.py) against the golden vectors the reference produced."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.duet_oracle import DuetOracle
+from tests.golden.variants import DUET_VARIANTS, duet_variant_setup
+from tests.test_oracle_hamt import _close
+from vln_imagine_amd import synth
+from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode
+from vln_imagine_amd.duet.spec import param_shapes
+
+
+def frozen_names(cfg, names):
+    """DUET freezes by requires_grad (vilmodel.py:1059-1073), not only by detach."""
+    fr = set()
+    for n in names:
+        if (cfg.fix_lang_embedding or cfg.fix_local_branch) and (n.startswith("embeddings.") or n.startswith("lang_encoder.")):
+            fr.add(n)
+        if (cfg.fix_pano_embedding or cfg.fix_local_branch) and n.startswith("img_embeddings."):
+            fr.add(n)
+        if cfg.fix_local_branch and (n.startswith("local_encoder.") or n.startswith("local_sap_head.")):
+            fr.add(n)
+    return fr
+
+
+@pytest.mark.parametrize("name", list(DUET_VARIANTS))
+def test_oracle_matches_reference_golden(name, golden_dir):
+    g = np.load(os.path.join(golden_dir, f"duet_{name}.npz"))
+    cfg, ep = duet_variant_setup(name)
+    shapes = param_shapes(cfg)
+    assert list(shapes) == g["grad_names"].tolist()               # state_dict ABI incl. registration order
+    fr = frozen_names(cfg, shapes)
+    sd = {k: torch.from_numpy(v).requires_grad_(k not in fr) for k, v in synth.fill_state_dict(shapes.items()).items()}
+    torch.set_num_threads(8)
+    out = run_episode(DuetOracle(cfg, sd), DuetEpisodeTensors(ep))
+    out["loss"].backward()
+    _close(out["loss"].item(), g["loss"], what="loss")
+    _close(out["aux"].item(), g["aux"], what="aux")
+    _close(out["imagine_embeds"].detach(), g["imagine_embeds"], what="imagine_embeds")
+    for t in range(ep.T):
+        for nm in ("fused", "global", "local"):
+            _close(out[nm][t].detach(), g[f"{nm}{t}"], what=f"{nm}{t}")
+        for nm in ("pano", "gmap", "vp"):
+            _close(synth.probe(out[nm][t].detach().numpy())["samples"], g[f"{nm}{t}.samples"], what=f"{nm}{t}")
+    for i, n in enumerate(g["grad_names"].tolist()):
+        gr = sd[n].grad
+        if g["grad_norms"][i] < 0:
+            assert gr is None or float(gr.abs().max()) == 0.0, n
+            continue
+        assert gr is not None, n
+        ref_norm = g["grad_norms"][i]
+        assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * max(ref_norm, 1e-3), (n, float(gr.double().norm()), ref_norm)
+        head = gr.reshape(-1)[:8].numpy()
+        _close(head, g["grad_heads"][i][:head.size], tol=1e-4, what=f"grad {n}")

@@ -1,0 +1,70 @@
+"""state_dict key -> shape table of DUET's GlocalTextPathNavCMT in the reference's registration order
+(VLN-DUET/map_nav_src/models/vilmodel.py:1022-1056). Key names are checkpoint ABI (r2r/agent_base.py:250-282)."""
+from collections import OrderedDict
+
+from vln_imagine_amd.hamt.spec import _bert_attention, _bert_layer, _lin, _ln
+
+
+def _graph_x_layer(d, p, h, ff):
+    _bert_attention(d, p + ".visn_self_att", h)
+    _lin(d, p + ".visn_inter.dense", ff, h)
+    _lin(d, p + ".visn_output.dense", h, ff)
+    _ln(d, p + ".visn_output.LayerNorm", h)
+    _bert_attention(d, p + ".visual_attention", h, att="att")
+
+
+def _cls(d, p, h, i=None):
+    _lin(d, p + ".net.0", h, i or h)
+    _ln(d, p + ".net.2", h)
+    _lin(d, p + ".net.3", 1, h)
+
+
+def param_shapes(cfg):
+    h, ff = cfg.hidden_size, cfg.intermediate_size
+    d = OrderedDict()
+    d["embeddings.word_embeddings.weight"] = (cfg.vocab_size, h)
+    d["embeddings.position_embeddings.weight"] = (cfg.max_position_embeddings, h)
+    d["embeddings.token_type_embeddings.weight"] = (cfg.type_vocab_size, h)
+    _ln(d, "embeddings.LayerNorm", h)
+    for i in range(cfg.num_l_layers):
+        _bert_layer(d, f"lang_encoder.layer.{i}", h, ff)
+    p = "img_embeddings"
+    _lin(d, p + ".img_linear", h, cfg.image_feat_size); _ln(d, p + ".img_layer_norm", h)
+    _lin(d, p + ".loc_linear", h, cfg.angle_feat_size + 3); _ln(d, p + ".loc_layer_norm", h)
+    d[p + ".nav_type_embedding.weight"] = (3, h)
+    _ln(d, p + ".layer_norm", h)
+    for i in range(cfg.num_pano_layers):
+        q = f"{p}.pano_encoder.layers.{i}"
+        d[q + ".self_attn.in_proj_weight"] = (3 * h, h)
+        d[q + ".self_attn.in_proj_bias"] = (3 * h,)
+        _lin(d, q + ".self_attn.out_proj", h, h)
+        _lin(d, q + ".linear1", ff, h)
+        _lin(d, q + ".linear2", h, ff)
+        _ln(d, q + ".norm1", h)
+        _ln(d, q + ".norm2", h)
+    if cfg.num_pano_layers > 0:
+        _ln(d, p + ".pano_encoder.norm", h)
+    _lin(d, "local_encoder.vp_pos_embeddings.0", h, cfg.angle_feat_size * 2 + 6)
+    _ln(d, "local_encoder.vp_pos_embeddings.1", h)
+    for i in range(cfg.num_x_layers):
+        _graph_x_layer(d, f"local_encoder.encoder.x_layers.{i}", h, ff)
+    _lin(d, "global_encoder.gmap_pos_embeddings.0", h, cfg.angle_feat_size + 3)
+    _ln(d, "global_encoder.gmap_pos_embeddings.1", h)
+    d["global_encoder.gmap_step_embeddings.weight"] = (cfg.max_action_steps, h)
+    for i in range(cfg.num_x_layers):
+        _graph_x_layer(d, f"global_encoder.encoder.x_layers.{i}", h, ff)
+    if cfg.graph_sprels:
+        _lin(d, "global_encoder.sprel_linear", 1, 1)
+    _cls(d, "global_sap_head", h)
+    _cls(d, "local_sap_head", h)
+    if cfg.glocal_fuse:
+        _cls(d, "sap_fuse_linear", h, 2 * h)
+    if cfg.imagine_enc_pano:
+        if cfg.bypass_imag_encoder:
+            d["imagine_embeddings.type_embedding.weight"] = (1, h)
+        if cfg.use_cosine_aux_loss or cfg.no_loss_test:
+            q = "contrastive_alignment_model.image_proj"
+            _lin(d, q + ".fc1", 512, 768, bias=False)
+            _lin(d, q + ".fc2", 512, 512, bias=False)
+            _lin(d, q + ".fc3", h, 512, bias=False)
+    return d

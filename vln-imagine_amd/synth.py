@@ -77,6 +77,60 @@ def angle_feat(name: str, shape_prefix):
     return np.stack([np.sin(h), np.cos(h), np.sin(e), np.cos(e)], -1).astype(np.float32)
 
 
+def _build_text_imagine(self, tag, B, L, I, ragged, feat=768, vocab=30522):
+    """Instruction tokens, imagination features and the sub-instruction / noun-phrase annotation shared by the
+    HAMT and DUET synthetic episodes (reference builders: r2r/agent_cmt.py:247-313, r2r/data_utils.py:119-450)."""
+    k = lambda s: f"{tag}/{s}"
+    # ---- text
+    if ragged:
+        lens = det_randint(k("txt_len"), (B,), max(8, L // 2), L + 1)
+        lens[0] = L
+    else:
+        lens = np.full((B,), L, np.int64)
+    self.txt_lens = lens
+    ids = det_randint(k("txt_ids"), (B, L), 1, vocab)
+    pos = np.arange(L)[None, :]
+    self.txt_masks = pos < lens[:, None]
+    self.txt_ids = np.where(self.txt_masks, ids, 0).astype(np.int64)
+    # ---- imaginations + sub-instruction / noun-phrase annotation
+    self.imagine_feats = det_uniform(k("imag"), (B, I, feat), -0.5, 0.5)
+    valid = np.ones((B, I), bool)
+    if ragged:
+        valid = det_randint(k("imag_valid"), (B, I), 0, 5) > 0   # 80 % valid
+        valid[0, :] = True
+        if B > 1:
+            valid[B - 1, :] = False                                # an all-False sample
+    self.imagine_masks = valid
+    self.imagine_feats = self.imagine_feats * valid[..., None]
+    self.sub_instr_segs, self.sub_instr_imag_flag, self.noun_phrase_segs = [], [], []
+    for b in range(B):
+        n_tok = int(lens[b]) - 2                # tokens 1..len-2 are partitioned
+        cuts = np.linspace(1, 1 + n_tok, I + 1).astype(int)
+        segs, flags, nps = [], [], []
+        for i in range(I):
+            s, e = int(cuts[i]), int(max(cuts[i], cuts[i + 1] - 1))
+            segs.append([s, e])
+            flags.append("True" if valid[b, i] else "False")
+            n_np = int(det_randint(k(f"nnp{b}_{i}"), (1,), 0, 3)[0])
+            if ragged and b == 0 and i == 1:
+                n_np = 0                        # flag-True slot with no noun phrase
+            if b == 0 and i == 0:
+                n_np = 2                        # multi-phrase slot
+            cur, lst = s, []
+            for j in range(n_np):
+                ln = int(det_randint(k(f"npl{b}_{i}_{j}"), (1,), 1, 4)[0])
+                a = cur
+                z = min(e, a + ln - 1)
+                if a > e:
+                    break
+                lst.append([a, z])
+                cur = z + 2
+            nps.append(lst)
+        self.sub_instr_segs.append(segs)
+        self.sub_instr_imag_flag.append(flags)
+        self.noun_phrase_segs.append(nps)
+
+
 class HamtEpisode:
     """Synthetic HAMT episode inputs (numpy), SURVEY.md section 8(d).
 
@@ -91,54 +145,8 @@ class HamtEpisode:
                  feat=768, ang=4, pano=36, vocab=30522):
         self.B, self.L, self.V, self.I, self.T = B, L, V, I, T
         k = lambda s: f"{tag}/{s}"
-        # ---- text
-        if ragged:
-            lens = det_randint(k("txt_len"), (B,), max(8, L // 2), L + 1)
-            lens[0] = L
-        else:
-            lens = np.full((B,), L, np.int64)
-        self.txt_lens = lens
-        ids = det_randint(k("txt_ids"), (B, L), 1, vocab)
-        pos = np.arange(L)[None, :]
-        self.txt_masks = pos < lens[:, None]
-        self.txt_ids = np.where(self.txt_masks, ids, 0).astype(np.int64)
-        # ---- imaginations + sub-instruction / noun-phrase annotation
-        self.imagine_feats = det_uniform(k("imag"), (B, I, feat), -0.5, 0.5)
-        valid = np.ones((B, I), bool)
-        if ragged:
-            valid = det_randint(k("imag_valid"), (B, I), 0, 5) > 0   # 80 % valid
-            valid[0, :] = True
-            if B > 1:
-                valid[B - 1, :] = False                                # an all-False sample
-        self.imagine_masks = valid
-        self.imagine_feats = self.imagine_feats * valid[..., None]
-        self.sub_instr_segs, self.sub_instr_imag_flag, self.noun_phrase_segs = [], [], []
-        for b in range(B):
-            n_tok = int(lens[b]) - 2                # tokens 1..len-2 are partitioned
-            cuts = np.linspace(1, 1 + n_tok, I + 1).astype(int)
-            segs, flags, nps = [], [], []
-            for i in range(I):
-                s, e = int(cuts[i]), int(max(cuts[i], cuts[i + 1] - 1))
-                segs.append([s, e])
-                flags.append("True" if valid[b, i] else "False")
-                n_np = int(det_randint(k(f"nnp{b}_{i}"), (1,), 0, 3)[0])
-                if ragged and b == 0 and i == 1:
-                    n_np = 0                        # flag-True slot with no noun phrase
-                if b == 0 and i == 0:
-                    n_np = 2                        # multi-phrase slot
-                cur, lst = s, []
-                for j in range(n_np):
-                    ln = int(det_randint(k(f"npl{b}_{i}_{j}"), (1,), 1, 4)[0])
-                    a = cur
-                    z = min(e, a + ln - 1)
-                    if a > e:
-                        break
-                    lst.append([a, z])
-                    cur = z + 2
-                nps.append(lst)
-            self.sub_instr_segs.append(segs)
-            self.sub_instr_imag_flag.append(flags)
-            self.noun_phrase_segs.append(nps)
+        _build_text_imagine(self, tag, B, L, I, ragged, feat, vocab)
+        lens, valid = self.txt_lens, self.imagine_masks
         # ---- per-step observations / history / targets
         self.steps = []
         for t in range(T):
@@ -183,3 +191,79 @@ def probe(x: np.ndarray, n: int = 512):
     stride = max(1, f.size // n)
     return dict(samples=f[::stride][:n].astype(np.float32), sum=np.float64(f.sum()),
                 asum=np.float64(np.abs(f).sum()), shape=np.array(x.shape, np.int64))
+
+
+class DuetEpisode:
+    """Synthetic DUET episode: per step a 36-view panorama and a growing topological map
+    (G_t = 1 [STOP] + (t+1) visited + (3+2t) frontier nodes), restating the host-side builders
+    VLN-DUET/map_nav_src/r2r/agent.py:67-207 (_panorama_feature_variable, _nav_gmap_variable, _nav_vp_variable).
+
+    Node images are tied to panorama outputs exactly like the agent does: a visited node = masked mean of that
+    step's panorama embeddings (agent.py:468-479), a frontier node = one candidate view embedding of the step that
+    first saw it. `node_src[t][b]` lists, per map node j >= 1, ("avg", step) or ("view", step, view_index)."""
+
+    def __init__(self, tag="ep0", B=4, L=80, V=36, I=4, T=2, ragged=True, feat=768, vocab=30522):
+        self.B, self.L, self.V, self.I, self.T = B, L, V, I, T
+        _build_text_imagine(self, tag, B, L, I, ragged, feat, vocab)
+        k = lambda s: f"{tag}/{s}"
+        self.steps = []
+        for t in range(T):
+            kk = lambda s: k(f"t{t}/{s}")
+            ncand = det_randint(kk("ncand"), (B,), 3, 7)                 # >= 3: one backtrack + new frontier nodes
+            view_lens = det_randint(kk("vlen"), (B,), V - 8, V + 1) if ragged else np.full((B,), V, np.int64)
+            view_lens[0] = V
+            vmask = np.arange(V)[None, :] < view_lens[:, None]
+            nav = np.zeros((B, V), np.int64)
+            for b in range(B):
+                nav[b, :ncand[b]] = 1
+            G = 1 + (t + 1) + (3 + 2 * t)
+            glens = np.full((B,), G, np.int64)
+            if ragged and B > 1:
+                glens[1] = G - 1                                          # one sample with a smaller map
+            gmap_vpids, visited, step_ids, node_src, cand_vpids = [], [], [], [], []
+            for b in range(B):
+                g = int(glens[b])
+                vis = [f"v{s}" for s in range(t + 1)]                     # visited viewpoints, step order
+                fro = [f"f{j}" for j in range(g - 1 - len(vis))]          # frontier nodes
+                gmap_vpids.append([None] + vis + fro)
+                visited.append([0] + [1] * len(vis) + [0] * len(fro))
+                step_ids.append([0] + [s + 1 for s in range(t + 1)] + [0] * len(fro))
+                src = [("avg", s) for s in range(t + 1)]
+                for j in range(len(fro)):
+                    s = min(t, j // 2)                                    # the step that first saw this frontier node
+                    src.append(("view", s, j % 3))
+                node_src.append(src)
+                # candidates of the current panorama: first a visited one (backtrack branch) if t > 0, then frontier nodes
+                cands = ([vis[-2]] if t > 0 else []) + fro[::-1]
+                cand_vpids.append(cands[:int(ncand[b])])
+                ncand[b] = len(cand_vpids[-1])
+                nav[b] = 0
+                nav[b, :ncand[b]] = 1
+            gm = np.arange(G)[None, :] < glens[:, None]
+            pd = det_uniform(kk("pair"), (B, G, G), 0.0, 30.0)
+            pd = np.triu(pd, 1)
+            pd = pd + pd.transpose(0, 2, 1)
+            pd[:, 0, :] = 0
+            pd[:, :, 0] = 0
+            pd = pd * (gm[:, :, None] & gm[:, None, :])
+            vis_m = np.zeros((B, G), bool)
+            sid = np.zeros((B, G), np.int64)
+            for b in range(B):
+                vis_m[b, :glens[b]] = np.array(visited[b], bool)
+                sid[b, :glens[b]] = step_ids[b]
+            # teacher action: STOP or an unvisited node of the map
+            target = np.zeros((B,), np.int64)
+            for b in range(B):
+                opts = [0] + [j for j in range(1, int(glens[b])) if not visited[b][j]]
+                target[b] = opts[int(det_randint(kk(f"tgt{b}"), (1,), 0, len(opts))[0])]
+            if ragged and t == T - 1 and B > 2:
+                target[2] = -100
+            self.steps.append(dict(
+                view_img_fts=(det_uniform(kk("view"), (B, V, feat), -0.5, 0.5) * vmask[..., None]).astype(np.float32),
+                loc_fts=(det_uniform(kk("loc"), (B, V, 7), -0.6, 0.6) * vmask[..., None]).astype(np.float32),
+                nav_types=nav, view_lens=view_lens,
+                gmap_vpids=gmap_vpids, gmap_lens=glens, gmap_masks=gm, gmap_step_ids=sid,
+                gmap_pos_fts=(det_uniform(kk("gpos"), (B, G, 7), -0.6, 0.6) * gm[..., None]).astype(np.float32),
+                gmap_pair_dists=pd.astype(np.float32), gmap_visited_masks=vis_m, node_src=node_src,
+                vp_pos_fts=det_uniform(kk("vppos"), (B, V + 1, 14), -0.6, 0.6).astype(np.float32),
+                vp_cand_vpids=[[None] + c for c in cand_vpids], target=target))
