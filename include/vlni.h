@@ -58,7 +58,7 @@ int vlni_layernorm_fwd(int dtype, const void* x, long ldx, const float* gamma, c
                        long ldy, float* mean, float* rstd, int rows, int H, void* stream);
 int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const float* gamma,
                        const float* mean, const float* rstd, void* dx, long lddx, float* dgamma, float* dbeta, int rows,
-                       int H, void* stream);
+                       int H, const void* dres /* optional: dx += dres (pre-norm residual path) */, long lddres, void* stream);
 /* y = LayerNorm(sum_k src_k), 1..4 sources, each dense / broadcast row (ld 0) / gathered by int64 row index,
  * float32 (parameter tables) or activation dtype; xsum (optional) keeps the pre-norm sum for backward.
  * Replaces BertEmbeddings R:58-73, ImageEmbeddings R:535-544, HistoryEmbeddings R:576-618, D:1087-1131. */

@@ -1,0 +1,66 @@
+"""GPU parity gate for DUET: the HIP GlocalTextPathNavCMT (fp32 compute) against the reference's golden vectors;
+tolerance 1e-4 on logits and losses. bf16 path reported against fp32 (loose)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden.variants import DUET_VARIANTS, duet_variant_setup
+from tests.test_hamt_gpu import _close
+from vln_imagine_amd import synth
+from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode
+from vln_imagine_amd.duet.spec import param_shapes
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def build_product(cfg, dtype=torch.float32):
+    from vln_imagine_amd.duet.models.vilmodel import GlocalTextPathNavCMT
+    m = GlocalTextPathNavCMT(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()})
+    return m.cuda().eval().set_compute_dtype(dtype)
+
+
+@pytest.mark.parametrize("name", list(DUET_VARIANTS))
+def test_product_fp32_matches_reference_golden(name, golden_dir):
+    from vln_imagine_amd import ops
+    g = np.load(os.path.join(golden_dir, f"duet_{name}.npz"))
+    cfg, ep = duet_variant_setup(name)
+    model = build_product(cfg)
+    out = run_episode(model, DuetEpisodeTensors(ep, "cuda"), criterion=ops.cross_entropy_sum)
+    out["loss"].backward()
+    c = lambda t: t.detach().float().cpu().numpy()
+    _close(out["loss"].item(), g["loss"], TOL, "loss")
+    _close(out["aux"].item(), g["aux"], TOL, "aux")
+    _close(c(out["imagine_embeds"]), g["imagine_embeds"], TOL, "imagine_embeds")
+    for t in range(ep.T):
+        for nm in ("fused", "global", "local"):
+            _close(c(out[nm][t]), g[f"{nm}{t}"], TOL, f"{nm}{t}")
+        for nm in ("pano", "gmap", "vp"):
+            _close(synth.probe(c(out[nm][t]))["samples"], g[f"{nm}{t}.samples"], TOL, f"{nm}{t}")
+    params = dict(model.named_parameters())
+    for i, n in enumerate(g["grad_names"].tolist()):
+        gr, ref_norm = params[n].grad, g["grad_norms"][i]
+        if ref_norm < 0:
+            assert gr is None or float(gr.abs().max()) == 0.0, n
+            continue
+        assert gr is not None, n
+        nrm = float(gr.double().norm())
+        assert abs(nrm - ref_norm) <= max(2e-4 * ref_norm, 2e-5), (n, nrm, ref_norm)   # 2e-5 abs: scalar grads that sum thousands of cancelling terms
+        head = gr.reshape(-1)[:8].cpu().numpy()
+        _close(head, g["grad_heads"][i][:head.size], 2e-4, f"grad {n}")
+
+
+def test_product_bf16_tracks_fp32():
+    cfg, ep = duet_variant_setup("c1_shipped")
+    et = DuetEpisodeTensors(ep, "cuda")
+    o32 = run_episode(build_product(cfg), et)
+    o16 = run_episode(build_product(cfg, torch.bfloat16), et)
+    assert abs(o16["loss"].item() - o32["loss"].item()) < 3e-2
+    for t in range(ep.T):
+        a, b = o16["fused"][t].float(), o32["fused"][t].float()
+        fin = torch.isfinite(b)
+        assert (torch.isfinite(a) == fin).all()
+        assert (a[fin] - b[fin]).abs().max().item() < 0.15

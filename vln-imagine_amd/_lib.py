@@ -22,7 +22,7 @@ SIGNATURES = {
     "vlni_attn_fwd": [I, P, L, P, L, P, L, P, P, P, L, P, I, I, I, I, F, P],
     "vlni_attn_bwd": [I, P, L, P, L, P, L, P, P, P, L, P, L, P, P, L, P, L, P, L, P, I, I, I, I, F, P],
     "vlni_layernorm_fwd": [I, P, L, P, P, F, P, L, P, P, I, I, P],
-    "vlni_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, P, I, I, P],
+    "vlni_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, P, I, I, P, L, P],
     "vlni_sum_layernorm_fwd": [I, I, P, P, P, P, P, P, F, P, L, P, L, P, P, I, I, P],
     "vlni_cast": [I, I, P, P, L, P],
     "vlni_transpose": [I, I, P, L, P, L, I, I, I, P],

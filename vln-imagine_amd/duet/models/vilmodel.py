@@ -1,0 +1,297 @@
+"""MI355X-native DUET `GlocalTextPathNavCMT` (drop-in for VLN-DUET/map_nav_src/models/vilmodel.py:1022-1288).
+
+Same forward(mode, batch) contract, output dict and state_dict keys as the reference. Modules are parameter
+holders; arithmetic runs in the fused HIP sublayer operators of vln_imagine_amd.ops:
+  language   BertEmbeddings (sum+LN kernel) + 9 fused BertLayers
+  panorama   LN(Linear(img)) + LN(Linear(loc, K=7)) + nav-type + token-type -> LN -> 2 PRE-norm encoder layers
+             (packed in_proj, -inf key padding, eps 1e-5; transformer.py:170-182) -> LN(1e-12)
+  navigation per branch 4 x [cross-attention visn<-text|imagination, self-attention (+ graph_sprels bias on the
+             global map), FFN]; SAP heads, dynamic fusion; the reference's per-element Python fusion loop
+             (:1200-1217) becomes index tensors built once on the host + three scatter/gather ops.
+"""
+import os
+
+import torch
+from torch import nn
+
+from vln_imagine_amd import ops
+from vln_imagine_amd.hamt.models.vilmodel_cmt import (HID_EPS, AlignWithContrastiveLoss, BertAttention, BertEmbeddings,
+                                                     BertIntermediate, BertLayer, BertOutput, BertXAttention,
+                                                     BypassImagineEmbeddings, _att, _ffn)
+from .transformer import TransformerEncoder
+
+
+class GraphLXRTXLayer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        if c.use_lang2visn_attn:
+            raise NotImplementedError("use_lang2visn_attn is False in every DUET fine-tuning run (vlnbert_init.py:57)")
+        self.visn_self_att = BertAttention(c)
+        self.visn_inter = BertIntermediate(c)
+        self.visn_output = BertOutput(c)
+        self.visual_attention = BertXAttention(c)
+
+    def forward(self, lang, lang_mask, visn, visn_mask, graph_sprels=None):
+        visn = ops.xatt_block(visn, lang, lang_mask, _att(self.visual_attention))
+        visn = ops.self_att_block(visn, visn_mask, _att(self.visn_self_att), bias=graph_sprels)
+        return ops.ffn_block(visn, _ffn(self.visn_inter, self.visn_output))
+
+
+class LanguageEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.update_lang_bert = c.update_lang_bert
+        self.layer = nn.ModuleList([BertLayer(c) for _ in range(c.num_l_layers)])
+        if not c.update_lang_bert:
+            for p in self.layer.parameters():
+                p.requires_grad = False
+
+
+class CrossmodalEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.x_layers = nn.ModuleList([GraphLXRTXLayer(c) for _ in range(c.num_x_layers)])
+
+    def forward(self, txt, txt_add_mask, visn, visn_add_mask, graph_sprels=None):
+        for l in self.x_layers:
+            visn = l(txt, txt_add_mask, visn, visn_add_mask, graph_sprels)
+        return visn
+
+
+class ImageEmbeddings(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        h = c.hidden_size
+        self.img_linear = nn.Linear(c.image_feat_size, h)
+        self.img_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.loc_linear = nn.Linear(c.angle_feat_size + 3, h)
+        self.loc_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        if c.obj_feat_size > 0:
+            raise NotImplementedError("object features (REVERIE / SOON) are outside the R2R hot path")
+        self.nav_type_embedding = nn.Embedding(3, h)
+        self.layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.pano_encoder = TransformerEncoder(c, c.num_pano_layers) if c.num_pano_layers > 0 else None
+
+
+class _PosEmbed(nn.Sequential):
+    """Sequential(Linear(K, 768), LayerNorm) holder, K <= 16 (7-d / 14-d position features)."""
+
+    def __init__(self, k, h):
+        super().__init__(nn.Linear(k, h), nn.LayerNorm(h, eps=HID_EPS))
+
+    def embed(self, x, dt):
+        return ops.layer_norm(ops.smallk_linear(x, self[0].weight, self[0].bias, dt), self[1].weight, self[1].bias, HID_EPS)
+
+
+class LocalVPEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.vp_pos_embeddings = _PosEmbed(c.angle_feat_size * 2 + 6, c.hidden_size)
+        self.encoder = CrossmodalEncoder(c)
+
+
+class GlobalMapEncoder(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.gmap_pos_embeddings = _PosEmbed(c.angle_feat_size + 3, c.hidden_size)
+        self.gmap_step_embeddings = nn.Embedding(c.max_action_steps, c.hidden_size)
+        self.encoder = CrossmodalEncoder(c)
+        self.sprel_linear = nn.Linear(1, 1) if c.graph_sprels else None
+
+
+class ClsPrediction(nn.Module):
+    def __init__(self, hidden, input_size=None):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(input_size or hidden, hidden), nn.ReLU(), nn.LayerNorm(hidden, eps=HID_EPS),
+                                 nn.Linear(hidden, 1))
+
+    def forward(self, x):
+        n = self.net
+        h = ops.layer_norm(ops.linear(x, n[0].weight, n[0].bias, act=2), n[2].weight, n[2].bias, HID_EPS)
+        return ops.row_dot(h, n[3].weight, n[3].bias, None)
+
+
+def _cfg(config):
+    from vln_imagine_amd.duet.config import DuetConfig
+    if isinstance(config, DuetConfig):
+        return config
+    d = config.to_dict() if hasattr(config, "to_dict") else dict(config.__dict__)
+    known = set(DuetConfig().__dict__)
+    return DuetConfig(**{k: v for k, v in d.items() if k in known})
+
+
+class GlocalTextPathNavCMT(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        c = self.config = _cfg(config)
+        self.embeddings = BertEmbeddings(c)
+        self.lang_encoder = LanguageEncoder(c)
+        self.img_embeddings = ImageEmbeddings(c)
+        self.local_encoder = LocalVPEncoder(c)
+        self.global_encoder = GlobalMapEncoder(c)
+        self.global_sap_head = ClsPrediction(c.hidden_size)
+        self.local_sap_head = ClsPrediction(c.hidden_size)
+        self.sap_fuse_linear = ClsPrediction(c.hidden_size, input_size=c.hidden_size * 2) if c.glocal_fuse else None
+        if c.imagine_enc_pano:
+            if c.bypass_imag_encoder:
+                self.imagine_embeddings = BypassImagineEmbeddings(c)
+            if c.use_cosine_aux_loss or c.no_loss_test:
+                if c.dataset == "reverie":
+                    raise NotImplementedError("REVERIE whole-instruction alignment (vilmodel.py:781-888) is a 'next' row")
+                self.contrastive_alignment_model = AlignWithContrastiveLoss(c)
+        from vln_imagine_amd.hamt.models.vilmodel_cmt import NavCMT
+        self.apply(NavCMT._init_weights)
+        if c.fix_lang_embedding or c.fix_local_branch:
+            for m in (self.embeddings, self.lang_encoder):
+                for p in m.parameters():
+                    p.requires_grad = False
+        if c.fix_pano_embedding or c.fix_local_branch:
+            for p in self.img_embeddings.parameters():
+                p.requires_grad = False
+        if c.fix_local_branch:
+            for m in (self.local_encoder, self.local_sap_head):
+                for p in m.parameters():
+                    p.requires_grad = False
+        self.compute_dtype = torch.bfloat16 if os.environ.get("VLNI_DTYPE", "fp32").lower() in ("bf16", "bfloat16") \
+            else torch.float32
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None):
+        m = cls(config)
+        if state_dict:
+            m.load_state_dict({(k[5:] if k.startswith("bert.") else k): v for k, v in state_dict.items()}, strict=False)
+        return m
+
+    def set_compute_dtype(self, dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    @property
+    def device(self):
+        return self.global_sap_head.net[0].weight.device
+
+    # ---- modes ---------------------------------------------------------------------------------
+    def forward_text(self, txt_ids, txt_masks):
+        dt, e = self.compute_dtype, self.embeddings
+        B, L = txt_ids.shape
+        pos = torch.arange(L, device=txt_ids.device).repeat(B)
+        srcs = [(e.word_embeddings.weight, "gather", txt_ids.reshape(-1).contiguous()),
+                (e.position_embeddings.weight, "gather", pos), (e.token_type_embeddings.weight[0], "bcast", None)]
+        x = ops.sum_layer_norm(srcs, e.LayerNorm.weight, e.LayerNorm.bias, B * L, dt, HID_EPS).view(B, L, -1)
+        km = ops.additive_mask(txt_masks)
+        for layer in self.lang_encoder.layer:
+            x = layer(x, km)
+        return x if self.lang_encoder.update_lang_bert else x.detach()
+
+    def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
+        if obj_img_fts is not None:
+            raise NotImplementedError("object features (REVERIE / SOON) are outside the R2R hot path")
+        dt, ie = self.compute_dtype, self.img_embeddings
+        B, S, _ = view_img_fts.shape
+        ti = ops.layer_norm(ops.linear(view_img_fts, ie.img_linear.weight, ie.img_linear.bias, out_dtype=dt),
+                            ie.img_layer_norm.weight, ie.img_layer_norm.bias, HID_EPS)
+        tl = ops.layer_norm(ops.smallk_linear(loc_fts, ie.loc_linear.weight, ie.loc_linear.bias, dt),
+                            ie.loc_layer_norm.weight, ie.loc_layer_norm.bias, HID_EPS)
+        srcs = [(ti, "dense", None), (tl, "dense", None),
+                (ie.nav_type_embedding.weight, "gather", nav_types.reshape(-1).contiguous()),
+                (self.embeddings.token_type_embeddings.weight[1], "bcast", None)]
+        x = ops.sum_layer_norm(srcs, ie.layer_norm.weight, ie.layer_norm.bias, B * S, dt, HID_EPS).view(B, S, -1)
+        masks = torch.arange(S, device=x.device)[None, :] < view_lens[:, None]          # gen_seq_masks
+        if ie.pano_encoder is not None:
+            x = ie.pano_encoder(x, masks)
+        return x, masks
+
+    def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
+                                    gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
+                                    vp_nav_masks, vp_obj_masks, vp_cand_vpids, imagine_embeds=None, imagine_masks=None):
+        c, dt = self.config, self.compute_dtype
+        ge, le = self.global_encoder, self.local_encoder
+        B, G = gmap_masks.shape
+        gmap = gmap_img_embeds.to(dt) + ge.gmap_step_embeddings.weight[gmap_step_ids].to(dt) \
+            + ge.gmap_pos_embeddings.embed(gmap_pos_fts, dt)
+        sprels = None
+        if ge.sprel_linear is not None:                                                     # reference :1145-1147
+            sprels = (gmap_pair_dists * ge.sprel_linear.weight[0, 0] + ge.sprel_linear.bias[0]).contiguous()
+        vp = vp_img_embeds.to(dt) + le.vp_pos_embeddings.embed(vp_pos_fts, dt)
+        txt, tm = txt_embeds.to(dt), txt_masks
+        if c.imagine_enc_pano and c.concat_imagine_with == "language":
+            assert imagine_embeds is not None and imagine_masks is not None
+            txt, tm = torch.cat([txt, imagine_embeds.to(dt)], 1), torch.cat([tm, imagine_masks], 1)
+        else:
+            assert not c.imagine_enc_pano
+        lm = ops.additive_mask(tm).contiguous()
+        gmap = ge.encoder(txt.contiguous(), lm, gmap.contiguous(), ops.additive_mask(gmap_masks), sprels)
+        vp = le.encoder(txt, lm, vp.contiguous(), ops.additive_mask(vp_masks))
+        if self.sap_fuse_linear is None:
+            fuse = 0.5
+        else:
+            fuse = torch.sigmoid(self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1).contiguous()))[:, None]
+        ninf = -float("inf")
+        global_logits = (self.global_sap_head(gmap) * fuse).masked_fill(gmap_visited_masks | ~gmap_masks, ninf)
+        local_logits = (self.local_sap_head(vp) * (1 - fuse)).masked_fill(~vp_nav_masks, ninf)
+        fused_logits = self._fuse(global_logits, local_logits, gmap_vpids, gmap_visited_masks, vp_cand_vpids)
+        return {"gmap_embeds": gmap, "vp_embeds": vp, "global_logits": global_logits, "local_logits": local_logits,
+                "fused_logits": fused_logits, "obj_logits": None}
+
+    @staticmethod
+    def _fuse(gl, ll, gmap_vpids, visited_masks, vp_cand_vpids):
+        """fused[i,0] = g+l (stop); an unvisited map node takes the local logit of the candidate that IS that node,
+        otherwise the summed local logits of the already-visited candidates (backtrack) -- reference :1198-1217."""
+        B, G = gl.shape
+        dev = gl.device
+        vm = visited_masks.tolist()
+        bi, gj, lj, bw_b, bw_l, bwn_b, bwn_g = [], [], [], [], [], [], []
+        for i in range(B):
+            visited = {vp for vp, m in zip(gmap_vpids[i], vm[i]) if m}
+            cand = {}
+            for j, cv in enumerate(vp_cand_vpids[i]):
+                if j > 0:
+                    if cv in visited:
+                        bw_b.append(i); bw_l.append(j)
+                    else:
+                        cand[cv] = j
+            for j, vp in enumerate(gmap_vpids[i]):
+                if j > 0 and vp not in visited:
+                    if vp in cand:
+                        bi.append(i); gj.append(j); lj.append(cand[vp])
+                    else:
+                        bwn_b.append(i); bwn_g.append(j)
+        t = lambda v: torch.tensor(v, dtype=torch.long, device=dev)
+        add = torch.zeros_like(gl)
+        add[:, 0] = ll[:, 0]
+        if bi:
+            add = add.index_put((t(bi), t(gj)), ll[t(bi), t(lj)], accumulate=True)
+        if bwn_b:
+            bw = torch.zeros(B, dtype=gl.dtype, device=dev)
+            if bw_b:
+                bw = bw.index_put((t(bw_b),), ll[t(bw_b), t(bw_l)], accumulate=True)
+            add = add.index_put((t(bwn_b), t(bwn_g)), bw[t(bwn_b)], accumulate=True)
+        return gl + add
+
+    def forward(self, mode, batch, **kwargs):
+        c = self.config
+        if mode == "language":
+            return self.forward_text(batch["txt_ids"], batch["txt_masks"])
+        if mode == "imagine":
+            assert c.imagine_enc_pano and batch["imagine_feats"] is not None
+            return self.imagine_embeddings(batch["imagine_feats"], batch["imagine_masks"], self.compute_dtype)
+        if mode == "align_with_contrastive_loss":
+            assert c.imagine_enc_pano
+            txt = batch["align_txt_embeds"]
+            return self.contrastive_alignment_model(
+                align_txt_embeds=txt.detach() if c.fix_lang_inside_cosine_model else txt, txt_masks=batch["txt_masks"],
+                align_imagine_embeds=batch["align_imagine_embeds"], imagine_masks=batch["imagine_masks"],
+                sub_instr_segs=batch["sub_instr_segs"], sub_instr_imag_flag=batch["sub_instr_imag_flag"],
+                noun_phrase_segs=batch["noun_phrase_segs"], obs_instr_ids=batch.get("obs_instr_ids"))
+        if mode == "panorama":
+            return self.forward_panorama_per_step(batch["view_img_fts"], batch.get("obj_img_fts"), batch["loc_fts"],
+                                                  batch["nav_types"], batch["view_lens"], batch.get("obj_lens"))
+        if mode == "navigation":
+            return self.forward_navigation_per_step(
+                batch["txt_embeds"], batch["txt_masks"], batch["gmap_img_embeds"], batch["gmap_step_ids"],
+                batch["gmap_pos_fts"], batch["gmap_masks"], batch["gmap_pair_dists"], batch["gmap_visited_masks"],
+                batch["gmap_vpids"], batch["vp_img_embeds"], batch["vp_pos_fts"], batch["vp_masks"], batch["vp_nav_masks"],
+                batch.get("vp_obj_masks"), batch["vp_cand_vpids"], imagine_embeds=batch.get("imagine_embeds"),
+                imagine_masks=batch.get("imagine_masks"))
+        raise NotImplementedError("wrong mode: %s" % mode)

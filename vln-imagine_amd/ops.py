@@ -121,14 +121,15 @@ def ln_fwd(x, gamma, beta, eps):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, want_param_grads=True):
+def ln_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, want_param_grads=True, dres=None):
     rows, H = x.shape
     dx = torch.empty((rows, H), dtype=x.dtype, device=x.device)
     if want_param_grads and dgamma is None:
         dgamma = torch.zeros((H,), dtype=torch.float32, device=x.device)
         dbeta = torch.zeros((H,), dtype=torch.float32, device=x.device)
     _lib.call("vlni_layernorm_bwd", _dt(x), dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
-              mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), rows, H, _st())
+              mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), rows, H,
+              _p(dres), dres.stride(0) if dres is not None else 0, _st())
     return dx, dgamma, dbeta
 
 
@@ -286,12 +287,12 @@ def _wb_grad_to(ws, bs, dy, x):
     return tuple(_split_rows(gw, rows)), tuple(_split_rows(gb, rows))
 
 
-def _ln_bwd_to(dy, x, g, b, mean, rstd, want):
+def _ln_bwd_to(dy, x, g, b, mean, rstd, want, dres=None):
     """LayerNorm backward with dgamma/dbeta accumulated in place when possible."""
     if want and _direct(g, b):
-        dx, _, _ = ln_bwd(dy, x, g, mean, rstd, g.grad, b.grad)
+        dx, _, _ = ln_bwd(dy, x, g, mean, rstd, g.grad, b.grad, dres=dres)
         return dx, None, None
-    return ln_bwd(dy, x, g, mean, rstd, want_param_grads=want)
+    return ln_bwd(dy, x, g, mean, rstd, want_param_grads=want, dres=dres)
 
 
 # =====================================================================================
@@ -481,6 +482,81 @@ class _XAttBlock(torch.autograd.Function):
         dx = gemm_nt(dq, _w((wq,), dt, True), residual=dpre).view(B, Sq, H) if ng[0] else None
         dc = gemm_nt(dkv, _w((wk, wv), dt, True)).view(B, Sk, H) if ng[1] else None
         return dx, dc, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
+
+
+class _PreNormAttBlock(torch.autograd.Function):
+    """y = x + out_proj(attn(in_proj(LN(x)))) with a packed [2304,768] in_proj and a key-padding mask (-inf):
+    TransformerEncoderLayer.forward_pre, first half (VLN-DUET models/transformer.py:170-177)."""
+
+    @staticmethod
+    def forward(ctx, x, kmask, eps, g, b, win, bin_, wo, bo):
+        B, S, H = x.shape
+        x2 = _rows(_chk(x, "x"))
+        dt = x.dtype
+        xn, mean, rstd = ln_fwd(x2, g, b, eps)
+        qkv = gemm_nt(xn, _w((win,), dt), bias=bin_)
+        c, lse = attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, S, kmask)
+        y = gemm_nt(c, _w((wo,), dt), bias=bo, residual=x2)
+        ctx.save_for_backward(x2, xn, qkv, c, lse, mean, rstd, kmask)
+        ctx.P, ctx.dims = (g, b, win, bin_, wo, bo), (B, S, H)
+        return y.view(B, S, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xn, qkv, c, lse, mean, rstd, kmask = ctx.saved_tensors
+        g, b, win, bin_, wo, bo = ctx.P
+        B, S, H = ctx.dims
+        dt = x2.dtype
+        ng = ctx.needs_input_grad
+        wparams = any(ng[3:])
+        dy2 = _rows(dy)
+        dwo = dbo = dwin = dbin = None
+        if wparams:
+            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dy2, c)
+        dc = gemm_nt(dy2, _w((wo,), dt, True))
+        dqkv = torch.empty_like(qkv)
+        attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], c, dc, lse, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:],
+                 B, S, S, kmask)
+        if wparams:
+            (dwin,), (dbin,) = _wb_grad_to((win,), (bin_,), dqkv, xn)
+        dxn = gemm_nt(dqkv, _w((win,), dt, True))
+        dx, dg, db = _ln_bwd_to(dxn, x2, g, b, mean, rstd, wparams, dres=dy2)
+        return dx.view(B, S, H), None, None, dg, db, dwin, dbin, dwo, dbo
+
+
+class _PreNormFfnBlock(torch.autograd.Function):
+    """y = x + W2 gelu(W1 LN(x) + b1) + b2: forward_pre, second half (transformer.py:178-181)."""
+
+    @staticmethod
+    def forward(ctx, x, eps, g, b, w1, b1, w2, b2):
+        shp = x.shape
+        x2 = _rows(_chk(x, "x"))
+        dt = x.dtype
+        xn, mean, rstd = ln_fwd(x2, g, b, eps)
+        z = torch.empty((x2.shape[0], w1.shape[0]), dtype=dt, device=x.device)
+        a = gemm_nt(xn, _w((w1,), dt), bias=b1, act=1, preact=z)
+        y = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2)
+        ctx.save_for_backward(x2, xn, z, a, mean, rstd)
+        ctx.P, ctx.shp = (g, b, w1, b1, w2, b2), shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, xn, z, a, mean, rstd = ctx.saved_tensors
+        g, b, w1, b1, w2, b2 = ctx.P
+        dt = x2.dtype
+        ng = ctx.needs_input_grad
+        wparams = any(ng[2:])
+        dy2 = _rows(dy)
+        dw1 = db1 = dw2 = db2 = None
+        if wparams:
+            (dw2,), (db2,) = _wb_grad_to((w2,), (b2,), dy2, a)
+        dz = gemm_nt(dy2, _w((w2,), dt, True), dact_src=z, dact=1)
+        if wparams:
+            (dw1,), (db1,) = _wb_grad_to((w1,), (b1,), dz, xn)
+        dxn = gemm_nt(dz, _w((w1,), dt, True))
+        dx, dg, db = _ln_bwd_to(dxn, x2, g, b, mean, rstd, wparams, dres=dy2)
+        return dx.view(ctx.shp), None, dg, db, dw1, db1, dw2, db2
 
 
 # =====================================================================================
@@ -768,6 +844,14 @@ def xatt_pair_block(lang, visn, mask_l, mask_v, p, eps=1e-12):
 
 def xatt_block(x, c_in, mask_c, p, eps=1e-12):
     return _XAttBlock.apply(x, c_in, mask_c, eps, *p)
+
+
+def prenorm_att_block(x, kmask, p, eps=1e-5):
+    return _PreNormAttBlock.apply(x, kmask, eps, *p)
+
+
+def prenorm_ffn_block(x, p, eps=1e-5):
+    return _PreNormFfnBlock.apply(x, eps, *p)
 
 
 def linear(x, w, b=None, act=0, out_dtype=None):
