@@ -112,7 +112,7 @@ def main():
     ap.add_argument("--V", type=int, default=37)
     ap.add_argument("--I", type=int, default=6)
     ap.add_argument("--freeze", default="none", choices=["none", "shipped"])
-    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

@@ -10,6 +10,20 @@ import torch.distributed as dist
 from . import _lib, ops
 
 
+def allreduce_mean_(flat, chunk_elems):
+    """In-place mean over the data-parallel group (DDP's gradient averaging, r2r/agent_cmt.py:61-63) on ONE flat
+    buffer: a handful of large all-reduces (RCCL over xGMI on the GPU box, gloo in the CPU tests) instead of
+    per-tensor buckets. No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return flat
+    ws = dist.get_world_size()
+    works = [dist.all_reduce(flat[o:o + chunk_elems], op=dist.ReduceOp.SUM, async_op=True)
+             for o in range(0, flat.numel(), chunk_elems)]
+    for w in works:
+        w.wait()
+    return flat.mul_(1.0 / ws)
+
+
 class FlatTrainer:
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=40.0,
                  chunk_mb=128):
@@ -57,16 +71,7 @@ class FlatTrainer:
         self.flat_g.zero_()
 
     def allreduce_grads(self):
-        """Mean of gradients over the data-parallel group: RCCL all-reduce on the flat arena in large chunks."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        ws = dist.get_world_size()
-        works = []
-        for o in range(0, self.n, self.chunk):
-            works.append(dist.all_reduce(self.flat_g[o:o + self.chunk], op=dist.ReduceOp.SUM, async_op=True))
-        for w in works:
-            w.wait()
-        self.flat_g.mul_(1.0 / ws)
+        allreduce_mean_(self.flat_g, self.chunk)
 
     def step(self):
         st = torch.cuda.current_stream().cuda_stream
