@@ -15,6 +15,8 @@
 // 16-B slots of the 256-B bank row; two LDS stages, next tile's global loads issued before the MFMAs
 // of the current one (issue-early / write-late), one barrier per k-tile. Tiles are dealt to XCDs in
 // contiguous chunks (bijective remap) so the N-tiles sharing an A row-panel hit one L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -76,78 +78,8 @@ template <> struct Mma<float> {
 };
 
 template <typename T>
-__global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
-  constexpr int ES = sizeof(T);
-  constexpr int BK = ROWB / ES;        // elements of K per tile
-  constexpr int EPC = 16 / ES;         // elements per 16-B chunk
-  // ONE 32-KiB stage (A tile then B tile); the next tile waits in registers. 32 KiB/block + <=128 VGPRs
-  // keeps 4 blocks (16 waves) resident per CU so that blocks hide each other's load latency and epilogues.
-  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
-  char* const As = smem;
-  char* const Bs = smem + BM * ROWB;
-
-  // ---- tile assignment: contiguous chunk of the tile list per XCD (bijective for any grid) ----
-  const int nwg = gridDim.x, bid = blockIdx.x;
-  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-  const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-  const int ntn = (p.N + BN - 1) / BN;
-  const int m0 = (wgid / ntn) * BM, n0 = (wgid % ntn) * BN;
-
-  const int nkt = (p.K + BK - 1) / BK;
-  const int kt0 = blockIdx.z * p.kt_per_split;
-  const int kt1 = min(nkt, kt0 + p.kt_per_split);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
-  const int lc = tid & 7, lr = tid >> 3;       // staging: chunk column, first row
-
-  // per-thread global row pointers (rows clamped: out-of-range rows load valid memory, never stored)
-  const char* ga[4];
-  const char* gb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = min(m0 + lr + 32 * i, p.M - 1), rb = min(n0 + lr + 32 * i, p.N - 1);
-    ga[i] = p.A + ((long)ra * p.lda + lc * EPC) * ES;
-    gb[i] = p.B + ((long)rb * p.ldb + lc * EPC) * ES;
-  }
-  uint4 sa[4], sb[4];
-  auto gload = [&](int kt) {
-    const long koff = (long)kt * BK;
-    const bool ok = (koff + lc * EPC) < p.K;   // K is a multiple of EPC: a chunk is all-in or all-out
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      sa[i] = ok ? *(const uint4*)(ga[i] + koff * ES) : make_uint4(0, 0, 0, 0);
-      sb[i] = ok ? *(const uint4*)(gb[i] + koff * ES) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto lstore = [&]() {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *(uint4*)(As + lds_off(lr + 32 * i, lc)) = sa[i];
-      *(uint4*)(Bs + lds_off(lr + 32 * i, lc)) = sb[i];
-    }
-  };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
-
-  if (kt0 < kt1) {
-    gload(kt0);
-    for (int kt = kt0; kt < kt1; ++kt) {
-      lstore();                                      // registers -> LDS (tile kt)
-      __syncthreads();
-      if (kt + 1 < kt1) gload(kt + 1);               // issue early: in flight under the MFMAs below
-#pragma unroll
-      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::step(As, Bs, kk, wr * 64, wc * 64, r, h, acc);
-      __syncthreads();                               // every wave done reading before the stage is rewritten
-    }
-  }
-
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16 (&acc)[2][2], int m0, int n0, int tid, int wr,
+                                              int wc, int r, int h) {
   // ---- split-K / wgrad: float32 atomics straight from the accumulators (128 contiguous bytes per half-wave) ----
   if (p.atomic_f32) {
     float* Cf = (float*)p.C;
@@ -234,6 +166,154 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
+  constexpr int ES = sizeof(T);
+  constexpr int BK = ROWB / ES;        // elements of K per tile
+  constexpr int EPC = 16 / ES;         // elements per 16-B chunk
+  // ONE 32-KiB stage (A tile then B tile); the next tile waits in registers. 32 KiB/block + <=128 VGPRs
+  // keeps 4 blocks (16 waves) resident per CU so that blocks hide each other's load latency and epilogues.
+  __shared__ __attribute__((aligned(16))) char smem[(BM + BN) * ROWB];
+  char* const As = smem;
+  char* const Bs = smem + BM * ROWB;
+
+  // ---- tile assignment: contiguous chunk of the tile list per XCD (bijective for any grid) ----
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int m0 = (wgid / ntn) * BM, n0 = (wgid % ntn) * BN;
+
+  const int nkt = (p.K + BK - 1) / BK;
+  const int kt0 = blockIdx.z * p.kt_per_split;
+  const int kt1 = min(nkt, kt0 + p.kt_per_split);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  const int lc = tid & 7, lr = tid >> 3;       // staging: chunk column, first row
+
+  // per-thread global row pointers (rows clamped: out-of-range rows load valid memory, never stored)
+  const char* ga[4];
+  const char* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ra = min(m0 + lr + 32 * i, p.M - 1), rb = min(n0 + lr + 32 * i, p.N - 1);
+    ga[i] = p.A + ((long)ra * p.lda + lc * EPC) * ES;
+    gb[i] = p.B + ((long)rb * p.ldb + lc * EPC) * ES;
+  }
+  uint4 sa[4], sb[4];
+  auto gload = [&](int kt) {
+    const long koff = (long)kt * BK;
+    const bool ok = (koff + lc * EPC) < p.K;   // K is a multiple of EPC: a chunk is all-in or all-out
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sa[i] = ok ? *(const uint4*)(ga[i] + koff * ES) : make_uint4(0, 0, 0, 0);
+      sb[i] = ok ? *(const uint4*)(gb[i] + koff * ES) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *(uint4*)(As + lds_off(lr + 32 * i, lc)) = sa[i];
+      *(uint4*)(Bs + lds_off(lr + 32 * i, lc)) = sb[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+
+  if (kt0 < kt1) {
+    gload(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+      lstore();                                      // registers -> LDS (tile kt)
+      __syncthreads();
+      if (kt + 1 < kt1) gload(kt + 1);               // issue early: in flight under the MFMAs below
+#pragma unroll
+      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::step(As, Bs, kk, wr * 64, wc * 64, r, h, acc);
+      __syncthreads();                               // every wave done reading before the stage is rewritten
+    }
+  }
+
+  gemm_epilogue<T>(p, smem, acc, m0, n0, tid, wr, wc, r, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Same contraction with a DEEPER pipeline: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR
+// staging, no ds_write), three 32-KiB stages, two k-tiles in flight under the MFMAs of the current one, ONE raw
+// s_barrier per k-tile behind a counted s_waitcnt vmcnt(8) (8 = LDS-DMA instructions per thread per tile; never
+// __syncthreads(), which would drain the queue). The LDS image is lane-linear per wave-instruction (1 KiB = 8 rows
+// of 128 B), so the XOR swizzle is applied to the per-lane SOURCE chunk; reads use the same lds_off().
+// Used when K is a multiple of the k-tile and rows need no zero fill (M/N edges are clamped, never stored).
+template <typename T>
+__global__ __launch_bounds__(NT) void gemm_nt_glds_kernel(GemmP p) {
+  constexpr int ES = sizeof(T);
+  constexpr int NST = 3, STAGE = (BM + BN) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int ntn = (p.N + BN - 1) / BN;
+  const int m0 = (wgid / ntn) * BM, n0 = (wgid % ntn) * BN;
+  constexpr int BK = ROWB / ES;
+  const int nkt = p.K / BK;
+  const int kt0 = blockIdx.z * p.kt_per_split;
+  const int nk = min(nkt, kt0 + p.kt_per_split) - kt0;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+
+  const char* ga[4];
+  const char* gb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);                       // logical chunk this LDS slot must hold
+    ga[i] = p.A + ((long)min(m0 + row, p.M - 1) * p.lda) * ES + c * 16 + (long)kt0 * ROWB;
+    gb[i] = p.B + ((long)min(n0 + row, p.N - 1) * p.ldb) * ES + c * 16 + (long)kt0 * ROWB;
+  }
+  using gptr = const __attribute__((address_space(1))) void*;
+  using lptr = __attribute__((address_space(3))) void*;
+  auto issue = [&](int t, int stage) {
+    char* sa = dsmem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr)(ga[i] + (long)t * ROWB), (lptr)(sa + i * 4096), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(gb[i] + (long)t * ROWB), (lptr)(sa + BM * ROWB + i * 4096), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+
+  if (nk > 0) {
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+      if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave); tile t+1 may still fly
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                                       // every wave's part of tile t landed; stage (t-1)%3 is free
+      if (t + 2 < nk) issue(t + 2, stage == 0 ? 2 : stage - 1);           // (t+2)%3 == (t-1)%3
+      const char* As = dsmem + stage * STAGE;
+#pragma unroll
+      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::step(As, As + BM * ROWB, kk, wr * 64, wc * 64, r, h, acc);
+      stage = stage == NST - 1 ? 0 : stage + 1;
+    }
+  }
+  __syncthreads();                                                        // all reads done before the epilogue reuses stage 0
+  gemm_epilogue<T>(p, dsmem, acc, m0, n0, tid, wr, wc, r, h);
+}
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient without transposes:  C[N,K] += A[M,N]^T * B[M,K]   (bf16 in, float32 atomics out)
@@ -388,10 +468,27 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
   p.kt_per_split = cdiv(nkt, split_k);
   const int splits = cdiv(nkt, p.kt_per_split);
   dim3 grid(cdiv(M, BM) * cdiv(N, BN), 1, splits);
-  if (dtype == VLNI_F32)
+  static const bool no_glds = getenv("VLNI_NO_GLDS") != nullptr;
+  // the 96-KiB deep-pipeline kernel runs ONE block per CU: it wins when the launch cannot fill the chip anyway
+  // (<= 256 tiles: latency-bound k-loop), the 32-KiB kernel (4 blocks/CU) wins when blocks can cover each other
+  const bool glds = !no_glds && (K % bk == 0) && p.kt_per_split >= 3 && (long)grid.x * grid.z <= 256;
+  if (glds) {
+    constexpr int LDS = 3 * (BM + BN) * ROWB;
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      attr = true;
+    }
+    if (dtype == VLNI_F32)
+      hipLaunchKernelGGL(gemm_nt_glds_kernel<float>, grid, dim3(NT), LDS, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL(gemm_nt_glds_kernel<__bf16>, grid, dim3(NT), LDS, (hipStream_t)stream, p);
+  } else if (dtype == VLNI_F32) {
     hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, p);
-  else
+  } else {
     hipLaunchKernelGGL(gemm_nt_kernel<__bf16>, grid, dim3(NT), 0, (hipStream_t)stream, p);
+  }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
