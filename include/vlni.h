@@ -40,6 +40,11 @@ int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, vo
 int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
                       float* colsum, int split, void* stream);
 
+/* Grouped form: up to 16 row segments (A_s [M_s,N], B_s [M_s,K], common lda/ldb) reduced into the same C: the deferred
+ * weight gradient of one parameter over all T steps of an episode in ONE launch. */
+int vlni_gemm_tn_bf16_grouped(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb, float* C,
+                              long ldc, int N, int K, float* colsum, int split, void* stream);
+
 /* Fused masked attention, head dim 64, heads packed along the row (head h at column h*64), Sk <= 128.
  * kmask [B,Sk] additive float32 ((1-m)*-10000, R:1010-1012) or NULL; bias [B,Sq,Sk] additive float32
  * shared by all heads (graph_sprels, D:1145-1147) or NULL; lse [B,nh,Sq] float32.

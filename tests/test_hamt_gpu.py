@@ -133,6 +133,7 @@ def test_flat_trainer_direct_grads_match_autograd():
         tr.zero_grad()
         for _ in range(2):
             run_episode(m, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+        tr.flush()
         for n, p in m.named_parameters():
             d = (p.grad - ref_g[n]).abs().max().item()
             assert d <= 2e-5 * max(1.0, ref_g[n].abs().max().item()), (n, d)
@@ -140,4 +141,29 @@ def test_flat_trainer_direct_grads_match_autograd():
         for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
             assert (p - q).abs().max().item() < 1e-4, n      # lr 1e-3: elements with ~0 gradient have a noisy Adam direction
     finally:
-        ops.DIRECT_GRAD = False
+        ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
+
+
+def test_deferred_grouped_wgrad_bf16_matches_immediate():
+    """bf16: queued (dY, X) pairs reduced by ONE grouped TN launch per parameter == per-step launches."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_T3_dense")
+    et = EpisodeTensors(ep, "cuda")
+    try:
+        grads = []
+        for defer in (False, True):
+            m = build_product(cfg, torch.bfloat16)
+            tr = FlatTrainer(m)
+            ops.DEFER_WGRAD = defer
+            tr.zero_grad()
+            run_episode(m, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+            assert bool(ops._WQ) == defer
+            tr.flush()
+            assert not ops._WQ
+            grads.append(tr.flat_g.clone())
+        rel = ((grads[0] - grads[1]).norm() / grads[0].norm()).item()
+        assert rel < 1e-4, rel
+    finally:
+        ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
+        ops._WQ.clear()

@@ -324,11 +324,18 @@ __global__ __launch_bounds__(NT) void gemm_nt_glds_kernel(GemmP p) {
 //   lanes): two reads give a lane the 8 consecutive reduction indices of its output row/column.
 //   Swizzle = guide image (b): chunk ^ (((row&3)<<2) | ((row>>2)&3)) -> conflict-free for the 32x32x16 tr reads.
 //   Optionally the k-tile-0 blocks also reduce the columns of A (bias gradient), so no separate colsum pass.
+constexpr int TN_MAXSEG = 16;
 struct TnP {
-  const __bf16* A; long lda;
-  const __bf16* B; long ldb;
+  // up to 16 row segments (A_s [M_s,N], B_s [M_s,K]) reduced into the same C: the deferred weight gradient of one
+  // parameter over all steps of an episode is ONE launch with a long reduction instead of one short launch per step
+  const __bf16* A[TN_MAXSEG];
+  const __bf16* B[TN_MAXSEG];
+  int segM[TN_MAXSEG];
+  int mt_start[TN_MAXSEG + 1];    // prefix sums of 64-row tiles
+  int nseg;
+  long lda, ldb;
   float* C; long ldc;
-  int M, N, K;
+  int N, K;
   int mt_per_split;
   float* colsum;
 };
@@ -354,21 +361,24 @@ __global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
   const int wgid = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
   const int ntk = (p.K + BN - 1) / BN;
   const int n0 = (wgid / ntk) * BM, k0 = (wgid % ntk) * BN;
-  const int nmt = (p.M + BR - 1) / BR;
+  const int nmt = p.mt_start[p.nseg];
   const int mt0 = blockIdx.z * p.mt_per_split, mt1 = min(nmt, mt0 + p.mt_per_split);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
   const int ch = tid & 15, lr = tid >> 4;                  // staging: 16 chunks per 256-byte row, 16 rows per pass
   const bool a_ok = (n0 + ch * 8) < p.N, b_ok = (k0 + ch * 8) < p.K;   // N, K multiples of 8
-  const __bf16* ga = p.A + n0 + ch * 8;
-  const __bf16* gb = p.B + k0 + ch * 8;
   uint4 sa[4], sb[4];
+  int seg = 0;
   auto gload = [&](int mt) {
+    while (mt >= p.mt_start[seg + 1]) ++seg;                 // tiles are visited in increasing order
+    const __bf16* ga = p.A[seg] + n0 + ch * 8;
+    const __bf16* gb = p.B[seg] + k0 + ch * 8;
+    const int segM = p.segM[seg], r0 = (mt - p.mt_start[seg]) * BR;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = mt * BR + lr + 16 * i;
-      const bool ok = row < p.M;
+      const int row = r0 + lr + 16 * i;
+      const bool ok = row < segM;
       sa[i] = (ok && a_ok) ? *(const uint4*)(ga + (long)row * p.lda) : make_uint4(0, 0, 0, 0);
       sb[i] = (ok && b_ok) ? *(const uint4*)(gb + (long)row * p.ldb) : make_uint4(0, 0, 0, 0);
     }
@@ -493,20 +503,33 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
   return VLNI_OK;
 }
 
-// C[N,K] += A[M,N]^T B[M,K] (bf16 operands as they lie in memory, float32 atomic accumulation, split over M);
-// colsum (optional, [N]) += column sums of A (the bias gradient). Replaces autograd's weight-gradient matmuls.
-extern "C" int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
-                                 float* colsum, int split, void* stream) {
-  VLNI_CHECK(M > 0 && N > 0 && K > 0 && split >= 1, VLNI_EINVAL, "gemm_tn: bad problem %d %d %d split %d", M, N, K, split);
+// C[N,K] += sum_s A_s[M_s,N]^T B_s[M_s,K] (bf16 operands as they lie in memory, float32 atomic accumulation, split over
+// rows); colsum (optional, [N]) += column sums of all A_s (the bias gradient). nseg <= 16 row segments share lda/ldb.
+// Replaces autograd's weight-gradient matmuls (one launch per parameter per episode when the segments are the T steps).
+extern "C" int vlni_gemm_tn_bf16_grouped(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
+                                         float* C, long ldc, int N, int K, float* colsum, int split, void* stream) {
+  VLNI_CHECK(nseg >= 1 && nseg <= TN_MAXSEG, VLNI_EINVAL, "gemm_tn: nseg=%d not in 1..%d", nseg, TN_MAXSEG);
+  VLNI_CHECK(N > 0 && K > 0 && split >= 1, VLNI_EINVAL, "gemm_tn: bad problem N=%d K=%d split=%d", N, K, split);
   VLNI_CHECK(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, VLNI_EINVAL, "gemm_tn: N/K/lda/ldb multiples of 8");
-  VLNI_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, VLNI_EINVAL, "gemm_tn: A/B must be 16-B aligned");
   TnP p;
-  p.A = (const __bf16*)A; p.lda = lda; p.B = (const __bf16*)B; p.ldb = ldb; p.C = C; p.ldc = ldc;
-  p.M = M; p.N = N; p.K = K; p.colsum = colsum;
-  const int nmt = cdiv(M, 64);
+  p.nseg = nseg; p.lda = lda; p.ldb = ldb; p.C = C; p.ldc = ldc; p.N = N; p.K = K; p.colsum = colsum;
+  p.mt_start[0] = 0;
+  for (int s = 0; s < nseg; ++s) {
+    VLNI_CHECK(M[s] > 0, VLNI_EINVAL, "gemm_tn: empty segment %d", s);
+    VLNI_CHECK(((uintptr_t)A[s] & 15) == 0 && ((uintptr_t)B[s] & 15) == 0, VLNI_EINVAL, "gemm_tn: A/B must be 16-B aligned");
+    p.A[s] = (const __bf16*)A[s]; p.B[s] = (const __bf16*)B[s]; p.segM[s] = M[s];
+    p.mt_start[s + 1] = p.mt_start[s] + cdiv(M[s], 64);
+  }
+  for (int s = nseg; s < TN_MAXSEG; ++s) { p.A[s] = nullptr; p.B[s] = nullptr; p.segM[s] = 0; p.mt_start[s + 1] = p.mt_start[nseg]; }
+  const int nmt = p.mt_start[nseg];
   p.mt_per_split = cdiv(nmt, split);
   dim3 grid(cdiv(N, BM) * cdiv(K, BN), 1, cdiv(nmt, p.mt_per_split));
   hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(NT), 0, (hipStream_t)stream, p);
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
+}
+
+extern "C" int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,
+                                 float* colsum, int split, void* stream) {
+  return vlni_gemm_tn_bf16_grouped(1, &A, &B, &M, lda, ldb, C, ldc, N, K, colsum, split, stream);
 }

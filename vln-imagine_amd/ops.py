@@ -268,6 +268,31 @@ def _bgrad_to(params, dy):
     return tuple(_split_rows(colsum(dy), [q.shape[0] for q in params]))
 
 
+# Deferred weight gradients (set by train.FlatTrainer together with DIRECT_GRAD): the (dY, X) pairs of a parameter are
+# queued during backward and reduced by ONE grouped transposing-read GEMM per parameter at flush time, i.e. one launch
+# with a T-times longer reduction instead of T short split-K launches. 288 GB of HBM make keeping dY alive free.
+DEFER_WGRAD = False
+_WQ = {}
+
+
+def flush_wgrads():
+    """Runs the queued weight/bias gradient reductions (must precede any read of the .grad arena)."""
+    for wv, bv, segs in _WQ.values():
+        for c in range(0, len(segs), 16):
+            chunk = segs[c:c + 16]
+            n = len(chunk)
+            N, K = chunk[0][0].shape[1], chunk[0][1].shape[1]
+            pa = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
+            pb = (ctypes.c_void_p * n)(*[x.data_ptr() for _, x in chunk])
+            pm = (ctypes.c_int * n)(*[d.shape[0] for d, _ in chunk])
+            tiles = ((N + 127) // 128) * ((K + 127) // 128)
+            nmt = sum((d.shape[0] + 63) // 64 for d, _ in chunk)
+            split = max(1, min(nmt, 16, round(768 / tiles)))
+            _lib.call("vlni_gemm_tn_bf16_grouped", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
+                      split, _st())
+    _WQ.clear()
+
+
 def _wb_grad_to(ws, bs, dy, x):
     """Weight + bias gradients of one (possibly row-packed) projection in a single pass over dy / x."""
     rows = [w.shape[0] for w in ws]
@@ -275,7 +300,14 @@ def _wb_grad_to(ws, bs, dy, x):
         wv = _packed_grad(ws) if len(ws) > 1 else ws[0].grad
         bv = _packed_grad(bs) if len(bs) > 1 else bs[0].grad
         if wv is not None and bv is not None:
-            wgrad(dy, x, out=wv, colsum_out=bv)
+            if DEFER_WGRAD and dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() \
+                    and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
+                ent = _WQ.get(wv.data_ptr())
+                if ent is None:
+                    ent = _WQ[wv.data_ptr()] = (wv, bv, [])
+                ent[2].append((dy, x))            # reduced later by flush_wgrads(): one grouped launch per parameter
+            else:
+                wgrad(dy, x, out=wv, colsum_out=bv)
         else:
             gw, gb = wgrad(dy, x, want_colsum=True)
             for prm, t in zip(ws, _split_rows(gw, rows)):

@@ -66,14 +66,22 @@ class FlatTrainer:
         self.chunk = chunk_mb * (1 << 20) // 4
         ops.SHADOWS.invalidate()
         ops.DIRECT_GRAD = True
+        ops.DEFER_WGRAD = True
 
     def zero_grad(self):
+        ops._WQ.clear()
         self.flat_g.zero_()
 
+    def flush(self):
+        """Completes the gradient arena (deferred grouped weight-gradient GEMMs)."""
+        ops.flush_wgrads()
+
     def allreduce_grads(self):
+        self.flush()
         allreduce_mean_(self.flat_g, self.chunk)
 
     def step(self):
+        self.flush()
         st = torch.cuda.current_stream().cuda_stream
         self.step_no += 1
         lr, b1, b2, eps, wd = self.hp
