@@ -14,6 +14,8 @@
 // 16*NKT in-register ops + one 32-lane wavefront shuffle, and P^T is already the B operand of the
 // P V product (no LDS round trip for P). In the backward pass keys sit on the lanes (S = Q K^T), so
 // P and dS feed dV^T and dK^T straight from registers and only dS crosses LDS once, for dQ.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -273,6 +275,280 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   }
 }
 
+// ================================================================================================
+// bf16 data path (throughput): same algorithms on v_mfma_f32_32x32x16_bf16 (16x the fp32 matrix rate).
+// K, V, Q, dO tiles sit in LDS as bf16 rows of 128 bytes, 16-byte chunks XOR-swizzled with
+//     f(row) = (((row>>1)&1)<<2) | ((row>>2)&3)
+// which makes BOTH access kinds of the one image conflict-free: ds_read_b128 row fragments (32 lanes = 32 rows,
+// same chunk) and ds_read_b64_tr_b16 transposed fragments (4 rows x 64 bytes per 32-lane half).
+// Forward: S^T = K Q^T (lane owns a query row), softmax in registers, P^T converted pairwise to bf16 is already the
+// B operand of O^T = V^T P^T (k order 16s + 8(j>>2) + 4h + (j&3), matched by the transposed V reads).
+// Backward: keys on lanes; P and dS feed dV^T / dK^T from registers, dS crosses LDS once (bf16) for dQ.
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef short s16x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ int boff(int row, int ch) { return row * 128 + ((ch ^ ((((row >> 1) & 1) << 2) | ((row >> 2) & 3))) << 4); }
+__device__ __forceinline__ bf16x8 ld_row(const char* tile, int row, int ch) { return *(const bf16x8*)(tile + boff(row, ch)); }
+// transposed fragment: rows r0..r0+3 and r1..r1+3 (this lane addresses row +qq), 16 columns starting at chunk ch (+half8)
+__device__ __forceinline__ bf16x8 ld_tr(const char* tile, int r0, int r1, int ch, int half8) {
+  using lds_ptr = __attribute__((address_space(3))) s16x4v*;
+  const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + boff(r0, ch) + half8));
+  const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + boff(r1, ch) + half8));
+  const s16x8v v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int base) {
+  bf16x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = (__bf16)a[base + j];
+  return v;
+}
+// rows [row0, row0+nvalid) of a [*, ld] bf16 matrix (64 columns at `src`) -> swizzled LDS tile of ntile rows, zero padded
+__device__ __forceinline__ void stage_bf16(char* dst, const __bf16* src, long ld, int row0, int nvalid, int ntile, int tid,
+                                           int nthreads) {
+  for (int i = tid; i < ntile * 8; i += nthreads) {
+    const int row = i >> 3, ch = i & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < nvalid) v = *(const uint4*)(src + (long)(row0 + row) * ld + ch * 8);
+    *(uint4*)(dst + boff(row, ch)) = v;
+  }
+}
+
+// forward: block = 4 waves x 32 query rows; grid = (ceil(Sq/128), B*nh)
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
+  constexpr int SKP = NKT * 32;
+  __shared__ __attribute__((aligned(16))) char smem[2 * SKP * 128];
+  char* Ks = smem;
+  char* Vs = smem + SKP * 128;
+  const int bh = blockIdx.y, b = bh / p.nh, hd = bh % p.nh;
+  const int q0 = blockIdx.x * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  stage_bf16(Ks, (const __bf16*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, 256);
+  stage_bf16(Vs, (const __bf16*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, 256);
+  const int qg = q0 + wave * 32 + r;
+  bf16x8 qf[4];
+  {
+    const __bf16* qp = (const __bf16*)p.q + ((long)b * p.Sq + min(qg, p.Sq - 1)) * p.ldq + hd * 64 + 8 * hh;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
+  }
+  __syncthreads();
+  if (q0 + wave * 32 >= p.Sq) return;                 // whole wave beyond the last query row (no barrier after this point)
+
+  f32x16 s[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x) s[kt][x] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Ks, kt * 32 + r, 2 * kk + hh), qf[kk], s[kt], 0, 0, 0);
+  }
+  const float* km = p.kmask ? p.kmask + (long)b * p.Sk : nullptr;
+  const float* bs = (p.bias && qg < p.Sq) ? p.bias + ((long)b * p.Sq + qg) * p.Sk : nullptr;
+  float m = -INFINITY;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int key = kt * 32 + acc_row(x, hh);
+      float v = s[kt][x] * p.scale;
+      if (key < p.Sk) {
+        if (km) v += km[key];
+        if (bs) v += bs[key];
+      } else {
+        v = -INFINITY;
+      }
+      s[kt][x] = v;
+      m = fmaxf(m, v);
+    }
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  float l = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const float e = __expf(s[kt][x] - m);
+      s[kt][x] = e;
+      l += e;
+    }
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+
+  const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
+  __bf16* out = (__bf16*)p.out + ((long)b * p.Sq + qg) * p.ldo + hd * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt) {
+    f32x16 o;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) o[x] = 0.f;
+    const int ch = dt * 4 + 2 * cb + (pp >> 1), half8 = 8 * (pp & 1);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int r0 = kt * 32 + 16 * s2 + 4 * hh + qq;
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Vs, r0, r0 + 8, ch, half8), pack8(s[kt], 8 * s2), o, 0, 0, 0);
+      }
+    if (qg < p.Sq) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
+        DT<__bf16>::st4(out + dt * 32 + 8 * g + 4 * hh, v);
+      }
+    }
+  }
+  if (p.lse && hh == 0 && qg < p.Sq) p.lse[((long)b * p.nh + hd) * p.Sq + qg] = m + __logf(l);
+}
+
+// backward: block = 4 waves; wave w owns key tile w; grid = B*nh; query rows in chunks of 64
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(AttnP p) {
+  constexpr int SKP = NKT * 32, DSS = SKP * 2 + 16;       // dS row stride in bytes (odd number of 16-B slots)
+  __shared__ __attribute__((aligned(16))) char smem[2 * SKP * 128 + 2 * 64 * 128 + 64 * DSS + 2 * 64 * 4];
+  char* Ks = smem;
+  char* Vs = Ks + SKP * 128;
+  char* Qs = Vs + SKP * 128;
+  char* dOs = Qs + 64 * 128;
+  char* dSs = dOs + 64 * 128;
+  float* lse_s = (float*)(dSs + 64 * DSS);
+  float* del_s = lse_s + 64;
+  const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1, half8 = 8 * (pp & 1);
+  stage_bf16(Ks, (const __bf16*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, 256);
+  stage_bf16(Vs, (const __bf16*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, 256);
+  __syncthreads();
+  const bool owner = wave < NKT;
+  const int key = wave * 32 + r;
+  bf16x8 kf[4], vf[4];
+  if (owner) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      kf[kk] = ld_row(Ks, key, 2 * kk + hh);
+      vf[kk] = ld_row(Vs, key, 2 * kk + hh);
+    }
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) { dk[dt][x] = 0.f; dv[dt][x] = 0.f; }
+  const float kmv = (p.kmask && key < p.Sk) ? p.kmask[(long)b * p.Sk + key] : 0.f;
+
+  for (int q0 = 0; q0 < p.Sq; q0 += 64) {
+    const int nq = min(64, p.Sq - q0);
+    stage_bf16(Qs, (const __bf16*)p.q + (long)b * p.Sq * p.ldq + hd * 64, p.ldq, q0, nq, 64, tid, 256);
+    stage_bf16(dOs, (const __bf16*)p.dout + (long)b * p.Sq * p.lddo + hd * 64, p.lddo, q0, nq, 64, tid, 256);
+    for (int row = wave; row < 64; row += 4) {
+      float dl = 0.f;
+      if (row < nq) {
+        const long qrow = (long)b * p.Sq + q0 + row;
+        dl = (float)((const __bf16*)p.dout)[qrow * p.lddo + hd * 64 + lane] * (float)((const __bf16*)p.out)[qrow * p.ldo + hd * 64 + lane];
+      }
+      dl = wave_sum(dl);
+      if (lane == 0) {
+        del_s[row] = dl;
+        lse_s[row] = row < nq ? p.lse[((long)b * p.nh + hd) * p.Sq + q0 + row] : 0.f;
+      }
+    }
+    __syncthreads();
+
+    if (owner) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) { s[x] = 0.f; dp[x] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(Qs, qt * 32 + r, 2 * kk + hh), kf[kk], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_row(dOs, qt * 32 + r, 2 * kk + hh), vf[kk], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+          const int ql = qt * 32 + acc_row(x, hh);
+          float pv = 0.f, ds = 0.f;
+          if (key < p.Sk && ql < nq) {
+            float sv = s[x] * p.scale + kmv;
+            if (p.bias) sv += p.bias[((long)b * p.Sq + q0 + ql) * p.Sk + key];
+            pv = __expf(sv - lse_s[ql]);
+            ds = pv * (dp[x] - del_s[ql]);
+            if (p.dbias) atomicAdd(p.dbias + ((long)b * p.Sq + q0 + ql) * p.Sk + key, ds);
+          }
+          s[x] = pv;
+          dp[x] = ds * p.scale;
+          *(__bf16*)(dSs + ql * DSS + key * 2) = (__bf16)dp[x];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pb = pack8(s, 8 * s2), db = pack8(dp, 8 * s2);
+          const int r0 = qt * 32 + 16 * s2 + 4 * hh + qq;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int ch = dt * 4 + 2 * cb + (pp >> 1);
+            dv[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(dOs, r0, r0 + 8, ch, half8), pb, dv[dt], 0, 0, 0);
+            dk[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Qs, r0, r0 + 8, ch, half8), db, dk[dt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const int qt = wave >> 1, dt = wave & 1;
+      const int ch = dt * 4 + 2 * cb + (pp >> 1);
+      f32x16 dq;
+#pragma unroll
+      for (int x = 0; x < 16; ++x) dq[x] = 0.f;
+#pragma unroll
+      for (int kk = 0; kk < SKP / 16; ++kk) {
+        const int r0 = 16 * kk + 8 * hh + qq;
+        const bf16x8 bfrag = *(const bf16x8*)(dSs + (qt * 32 + r) * DSS + (16 * kk + 8 * hh) * 2);
+        dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ld_tr(Ks, r0, r0 + 4, ch, half8), bfrag, dq, 0, 0, 0);
+      }
+      const int ql = qt * 32 + r;
+      if (ql < nq) {
+        __bf16* o = (__bf16*)p.dq + ((long)b * p.Sq + q0 + ql) * p.lddq + hd * 64 + dt * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v = {dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]};
+          DT<__bf16>::st4(o + 8 * g + 4 * hh, v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (owner && key < p.Sk) {
+    __bf16* ok = (__bf16*)p.dk + ((long)b * p.Sk + key) * p.lddk + hd * 64;
+    __bf16* ov = (__bf16*)p.dv + ((long)b * p.Sk + key) * p.lddv + hd * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 a = {dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]};
+        f32x4 c = {dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]};
+        DT<__bf16>::st4(ok + dt * 32 + 8 * g + 4 * hh, a);
+        DT<__bf16>::st4(ov + dt * 32 + 8 * g + 4 * hh, c);
+      }
+  }
+}
+
+template <int NKT>
+int launch_bf16(const AttnP& p, bool bwd, hipStream_t st) {
+  if (bwd) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT>), dim3(p.B * p.nh), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((attn_fwd_bf16_kernel<NKT>), dim3(cdiv(p.Sq, 128), p.B * p.nh), dim3(256), 0, st, p);
+  return 0;
+}
+int dispatch_bf16(const AttnP& p, bool bwd, hipStream_t st) {
+  switch (cdiv(p.Sk, 32)) {
+    case 1: return launch_bf16<1>(p, bwd, st);
+    case 2: return launch_bf16<2>(p, bwd, st);
+    case 3: return launch_bf16<3>(p, bwd, st);
+    case 4: return launch_bf16<4>(p, bwd, st);
+  }
+  return -1;
+}
+
 template <typename T, int NKT>
 int launch_fwd(const AttnP& p, hipStream_t st) {
   const size_t lds = (size_t)(2 * NKT * 32 * LD + 64 * LD) * sizeof(float);
@@ -329,7 +605,11 @@ extern "C" int vlni_attn_fwd(int dtype, const void* q, long ldq, const void* k, 
   p.out = out; p.ldo = ldo; p.lse = lse; p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
   int rc = check_common("attn_fwd", dtype, p);
   if (rc) return rc;
-  rc = dtype == VLNI_F32 ? dispatch<float>(p, false, (hipStream_t)stream) : dispatch<__bf16>(p, false, (hipStream_t)stream);
+  static const bool f32mfma = getenv("VLNI_ATTN_F32MFMA") != nullptr;
+  const bool fast = dtype == VLNI_BF16 && !f32mfma && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 &&
+                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) == 0;
+  rc = fast ? dispatch_bf16(p, false, (hipStream_t)stream)
+            : (dtype == VLNI_F32 ? dispatch<float>(p, false, (hipStream_t)stream) : dispatch<__bf16>(p, false, (hipStream_t)stream));
   VLNI_CHECK(rc == 0, VLNI_EUNSUP, "attn_fwd: no kernel for Sk=%d", Sk);
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
@@ -347,7 +627,11 @@ extern "C" int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, 
   if (rc) return rc;
   VLNI_CHECK(lddo % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, VLNI_EINVAL, "attn_bwd: grad strides");
   VLNI_CHECK(lse != nullptr, VLNI_EINVAL, "attn_bwd: lse required");
-  rc = dtype == VLNI_F32 ? dispatch<float>(p, true, (hipStream_t)stream) : dispatch<__bf16>(p, true, (hipStream_t)stream);
+  static const bool f32mfma = getenv("VLNI_ATTN_F32MFMA") != nullptr;
+  const bool fast = dtype == VLNI_BF16 && !f32mfma && ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && lddo % 8 == 0 &&
+                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)dout) & 15) == 0;
+  rc = fast ? dispatch_bf16(p, true, (hipStream_t)stream)
+            : (dtype == VLNI_F32 ? dispatch<float>(p, true, (hipStream_t)stream) : dispatch<__bf16>(p, true, (hipStream_t)stream));
   VLNI_CHECK(rc == 0, VLNI_EUNSUP, "attn_bwd: no kernel for Sk=%d", Sk);
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
