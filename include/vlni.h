@@ -35,6 +35,12 @@ int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, vo
                  const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
                  const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32, void* stream);
 
+/* Same with an explicit kernel variant (0 auto, 1 register-staged 32 KiB, 2 LDS-DMA 2-stage, 3 LDS-DMA 3-stage); results identical. */
+int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
+                   const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
+                   const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32, int variant,
+                   void* stream);
+
 /* Weight gradient without transposes: C[N,K] += A[M,N]^T B[M,K] (bf16 in, float32 atomics out, split over M rows);
  * colsum[N] (optional) += column sums of A = bias gradient. Autograd of nn.Linear (R:101-103,...). */
 int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,

@@ -18,6 +18,7 @@ P, L, I, F = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
 # name -> argtypes, in the order of include/vlni.h
 SIGNATURES = {
     "vlni_gemm_nt": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, P],
+    "vlni_gemm_nt_v": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, I, P],
     "vlni_gemm_tn_bf16": [P, L, P, L, P, L, I, I, I, P, I, P],
     "vlni_gemm_tn_bf16_grouped": [I, P, P, P, L, L, P, L, I, I, P, I, P],
     "vlni_attn_fwd": [I, P, L, P, L, P, L, P, P, P, L, P, I, I, I, I, F, P],

@@ -440,17 +440,22 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(AttnP p) {
     const int nq = min(64, p.Sq - q0);
     stage_bf16(Qs, (const __bf16*)p.q + (long)b * p.Sq * p.ldq + hd * 64, p.ldq, q0, nq, 64, tid, 256);
     stage_bf16(dOs, (const __bf16*)p.dout + (long)b * p.Sq * p.lddo + hd * 64, p.lddo, q0, nq, 64, tid, 256);
-    for (int row = wave; row < 64; row += 4) {
-      float dl = 0.f;
-      if (row < nq) {
-        const long qrow = (long)b * p.Sq + q0 + row;
-        dl = (float)((const __bf16*)p.dout)[qrow * p.lddo + hd * 64 + lane] * (float)((const __bf16*)p.out)[qrow * p.ldo + hd * 64 + lane];
+    {
+      // delta[q] = <dO[q], O[q]>: 16 rows per wave, all loads issued before the first reduction
+      float dl[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = wave + 4 * i;
+        const long qrow = (long)b * p.Sq + q0 + min(row, nq - 1);
+        dl[i] = (float)((const __bf16*)p.dout)[qrow * p.lddo + hd * 64 + lane] * (float)((const __bf16*)p.out)[qrow * p.ldo + hd * 64 + lane];
       }
-      dl = wave_sum(dl);
-      if (lane == 0) {
-        del_s[row] = dl;
-        lse_s[row] = row < nq ? p.lse[((long)b * p.nh + hd) * p.Sq + q0 + row] : 0.f;
+      const float lv = (lane < 16 && wave + 4 * lane < nq) ? p.lse[((long)b * p.nh + hd) * p.Sq + q0 + wave + 4 * lane] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float t = wave_sum(dl[i]);
+        if (lane == 0) del_s[wave + 4 * i] = (wave + 4 * i < nq) ? t : 0.f;
       }
+      if (lane < 16) lse_s[wave + 4 * lane] = lv;
     }
     __syncthreads();
 

@@ -249,10 +249,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
 // __syncthreads(), which would drain the queue). The LDS image is lane-linear per wave-instruction (1 KiB = 8 rows
 // of 128 B), so the XOR swizzle is applied to the per-lane SOURCE chunk; reads use the same lds_off().
 // Used when K is a multiple of the k-tile and rows need no zero fill (M/N edges are clamped, never stored).
-template <typename T>
+template <typename T, int NST>     // NST stages = NST-1 k-tiles in flight (3: 96 KiB, 1 block/CU; 2: 64 KiB, 2 blocks/CU)
 __global__ __launch_bounds__(NT) void gemm_nt_glds_kernel(GemmP p) {
   constexpr int ES = sizeof(T);
-  constexpr int NST = 3, STAGE = (BM + BN) * ROWB;
+  constexpr int STAGE = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
@@ -298,13 +298,13 @@ __global__ __launch_bounds__(NT) void gemm_nt_glds_kernel(GemmP p) {
 
   if (nk > 0) {
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
+    if (NST == 3 && nk > 1) issue(1, 1);
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
-      if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave); tile t+1 may still fly
+      if (NST == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave); t+1 may still fly
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                                       // every wave's part of tile t landed; stage (t-1)%3 is free
-      if (t + 2 < nk) issue(t + 2, stage == 0 ? 2 : stage - 1);           // (t+2)%3 == (t-1)%3
+      __builtin_amdgcn_s_barrier();                                       // every wave's part of tile t landed; stage (t-1)%NST is free
+      if (t + NST - 1 < nk) issue(t + NST - 1, stage == 0 ? NST - 1 : stage - 1);   // (t+NST-1)%NST == (t-1)%NST
       const char* As = dsmem + stage * STAGE;
 #pragma unroll
       for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::step(As, As + BM * ROWB, kk, wr * 64, wc * 64, r, h, acc);
@@ -450,10 +450,12 @@ __global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
 
 }  // namespace
 
-extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
-                            int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
-                            const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,
-                            void* stream) {
+// variant: 0 = choose by shape, 1 = register-staged 32-KiB kernel (4 blocks/CU), 2 = LDS-DMA 2-stage (64 KiB),
+// 3 = LDS-DMA 3-stage (96 KiB). All variants compute the same result; the host side may time them once per shape.
+extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
+                              int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
+                              const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,
+                              int variant, void* stream) {
   VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt: bad dtype %d", dtype);
   VLNI_CHECK(M > 0 && N > 0 && K > 0, VLNI_EINVAL, "gemm_nt: empty problem %d %d %d", M, N, K);
   const int es = dtype == VLNI_F32 ? 4 : 2, epc = 16 / es, bk = ROWB / es;
@@ -481,19 +483,28 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
   static const bool no_glds = getenv("VLNI_NO_GLDS") != nullptr;
   // the 96-KiB deep-pipeline kernel runs ONE block per CU: it wins when the launch cannot fill the chip anyway
   // (<= 256 tiles: latency-bound k-loop), the 32-KiB kernel (4 blocks/CU) wins when blocks can cover each other
-  const bool glds = !no_glds && (K % bk == 0) && p.kt_per_split >= 3 && (long)grid.x * grid.z <= 256;
-  if (glds) {
-    constexpr int LDS = 3 * (BM + BN) * ROWB;
+  const bool glds_ok = !no_glds && (K % bk == 0) && p.kt_per_split >= 3;
+  if (variant == 0) variant = (glds_ok && (long)grid.x * grid.z <= 256) ? 3 : 1;
+  if (!glds_ok) variant = 1;
+  const bool deep = variant == 3;
+  if (variant >= 2) {
+    constexpr int ST = (BM + BN) * ROWB;
     static bool attr = false;
     if (!attr) {
-      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
+      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<__bf16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
+      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
+      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<__bf16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
       attr = true;
     }
-    if (dtype == VLNI_F32)
-      hipLaunchKernelGGL(gemm_nt_glds_kernel<float>, grid, dim3(NT), LDS, (hipStream_t)stream, p);
-    else
-      hipLaunchKernelGGL(gemm_nt_glds_kernel<__bf16>, grid, dim3(NT), LDS, (hipStream_t)stream, p);
+    hipStream_t st = (hipStream_t)stream;
+    if (deep) {
+      if (dtype == VLNI_F32) hipLaunchKernelGGL((gemm_nt_glds_kernel<float, 3>), grid, dim3(NT), 3 * ST, st, p);
+      else hipLaunchKernelGGL((gemm_nt_glds_kernel<__bf16, 3>), grid, dim3(NT), 3 * ST, st, p);
+    } else {
+      if (dtype == VLNI_F32) hipLaunchKernelGGL((gemm_nt_glds_kernel<float, 2>), grid, dim3(NT), 2 * ST, st, p);
+      else hipLaunchKernelGGL((gemm_nt_glds_kernel<__bf16, 2>), grid, dim3(NT), 2 * ST, st, p);
+    }
   } else if (dtype == VLNI_F32) {
     hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, p);
   } else {
@@ -501,6 +512,14 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
   }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
+}
+
+extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
+                            int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
+                            const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,
+                            void* stream) {
+  return vlni_gemm_nt_v(dtype, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, preact, ldp, dact_src, ldd, dact,
+                        alpha, split_k, atomic_f32, 0, stream);
 }
 
 // C[N,K] += sum_s A_s[M_s,N]^T B_s[M_s,K] (bf16 operands as they lie in memory, float32 atomic accumulation, split over

@@ -50,6 +50,20 @@ def _rows(t):
 # =====================================================================================
 #  raw kernel wrappers (no autograd)
 # =====================================================================================
+# Per-shape kernel choice: the three GEMM pipelines (register-staged 4 blocks/CU, LDS-DMA 2-stage, LDS-DMA 3-stage)
+# compute identical results; which is fastest depends on how the tile count fills 256 CUs. The first call of a shape
+# times each once with HIP events (a few hundred microseconds) and the winner is cached for the life of the process.
+AUTOTUNE = True
+_GEMM_BEST = {}
+
+
+def _gemm_call(variant, a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K):
+    _lib.call("vlni_gemm_nt_v", _dt(a), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
+              out.stride(0), M, N, K, _p(bias), act, _p(residual), residual.stride(0) if residual is not None else 0,
+              _p(preact), preact.stride(0) if preact is not None else 0, _p(dact_src),
+              dact_src.stride(0) if dact_src is not None else 0, dact, alpha, split_k, 1 if atomic else 0, variant, _st())
+
+
 def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_src=None, dact=0,
             alpha=1.0, split_k=1, atomic=False, out_dtype=None):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T); a, b same dtype, K-contiguous."""
@@ -58,10 +72,23 @@ def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_s
     assert b.shape[1] == K and a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32 if atomic else a.dtype, device=a.device)
-    _lib.call("vlni_gemm_nt", _dt(a), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
-              out.stride(0), M, N, K, _p(bias), act, _p(residual), residual.stride(0) if residual is not None else 0,
-              _p(preact), preact.stride(0) if preact is not None else 0, _p(dact_src),
-              dact_src.stride(0) if dact_src is not None else 0, dact, alpha, split_k, 1 if atomic else 0, _st())
+    args = (a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K)
+    variant = 0
+    if AUTOTUNE and not atomic and M >= 512 and not torch.cuda.is_current_stream_capturing():
+        key = (a.dtype, M, N, K, act, dact, residual is not None, preact is not None)
+        variant = _GEMM_BEST.get(key)
+        if variant is None:
+            best = (float("inf"), 0)
+            for v in (1, 2, 3):
+                _gemm_call(v, *args)                                    # warm
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _gemm_call(v, *args); _gemm_call(v, *args)
+                e1.record()
+                e1.synchronize()
+                best = min(best, (e0.elapsed_time(e1), v))
+            variant = _GEMM_BEST[key] = best[1]
+    _gemm_call(variant, *args)
     return out
 
 
