@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--V", type=int, default=37)
     ap.add_argument("--I", type=int, default=6)
     ap.add_argument("--freeze", default="none", choices=["none", "shipped"])
+    ap.add_argument("--model", default="hamt", choices=["hamt", "duet"],
+                    help="hamt = BASELINE.json configs[1] (the metric's config); duet = configs[3] (batch 32)")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -136,12 +138,27 @@ def main():
     from vln_imagine_amd.train import FlatTrainer
 
     shipped = args.freeze == "shipped"
-    cfg = HamtConfig(fix_lang_embedding=shipped, fix_hist_embedding=shipped, update_lang_bert=not shipped)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = make_model(cfg, dtype, dev)
+    if args.model == "duet":
+        from vln_imagine_amd.duet.config import DuetConfig
+        from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode as duet_run
+        from vln_imagine_amd.duet.models.vilmodel import GlocalTextPathNavCMT
+        from vln_imagine_amd.duet.spec import param_shapes as duet_shapes
+        if args.batch == 64:
+            args.batch = 32                                  # BASELINE.json configs[3]
+        cfg = DuetConfig(fix_lang_embedding=shipped, update_lang_bert=not shipped)
+        model = GlocalTextPathNavCMT(cfg)
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(duet_shapes(cfg).items()).items()})
+        model = model.to(dev).eval().set_compute_dtype(dtype)
+        ep = synth.DuetEpisode(tag=f"bench{rank}", B=args.batch, L=args.L, V=36, I=args.I, T=args.T, ragged=False)
+        et = DuetEpisodeTensors(ep, dev)
+        run_episode = duet_run
+    else:
+        cfg = HamtConfig(fix_lang_embedding=shipped, fix_hist_embedding=shipped, update_lang_bert=not shipped)
+        model = make_model(cfg, dtype, dev)
+        ep = synth.HamtEpisode(tag=f"bench{rank}", B=args.batch, L=args.L, V=args.V, I=args.I, T=args.T, ragged=False)
+        et = EpisodeTensors(ep, dev)
     trainer = FlatTrainer(model, lr=1e-5)
-    ep = synth.HamtEpisode(tag=f"bench{rank}", B=args.batch, L=args.L, V=args.V, I=args.I, T=args.T, ragged=False)
-    et = EpisodeTensors(ep, dev)
 
     def step():
         trainer.zero_grad()
@@ -176,7 +193,8 @@ def main():
     ms = dt / args.steps * 1e3
     log(f"timed: {ms:.2f} ms/step")
     eps = args.batch * world / (dt / args.steps)
-    flops = episode_flops(cfg, args.batch, args.L, args.V, args.I, args.T, shipped)
+    flops = episode_flops(cfg, args.batch, args.L, args.V, args.I, args.T, shipped) if args.model == "hamt" \
+        else 150e9 * args.batch * args.T / 6.0          # DUET episode T=6 all-trainable ~150 GF/sample
     peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
 
     roof = None
@@ -212,15 +230,16 @@ def main():
                 "step_frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / peak, 4)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "hamt":
         cpu = cpu_baseline(cfg, args)
 
     if rank == 0:
         line = {
-            "metric": "episodes/sec (fwd+bwd) HAMT-Imagine 9L, batch 64", "value": round(eps, 2), "unit": "episodes/s",
+            "metric": "episodes/sec (fwd+bwd) HAMT-Imagine 9L, batch 64" if args.model == "hamt"
+            else "episodes/sec (fwd+bwd) DUET-Imagine 9L+2pano+4+4X, batch 32", "value": round(eps, 2), "unit": "episodes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"HAMT-Imagine 9L+4X+2pano, batch {args.batch}/GPU, {args.L} text, {args.V} obs tokens, "
+            "config": {"workload": f"{'HAMT-Imagine 9L+4X+2pano' if args.model == 'hamt' else 'DUET-Imagine 9L+2pano+4global+4local X, map 5+3t nodes'}, batch {args.batch}/GPU, {args.L} text, {args.V} obs tokens, "
                                    f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, dropout p=0",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "steps_per_sec": round(args.T * args.batch * world / (dt / args.steps), 1),

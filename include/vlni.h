@@ -39,6 +39,7 @@ int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, vo
 int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                    const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
                    const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32, int variant,
+                   float drop_p, unsigned drop_seed /* dropout after act, before residual; mask = f(seed, row*N+col) */,
                    void* stream);
 
 /* Weight gradient without transposes: C[N,K] += A[M,N]^T B[M,K] (bf16 in, float32 atomics out, split over M rows);
@@ -57,11 +58,11 @@ int vlni_gemm_tn_bf16_grouped(int nseg, const void* const* A, const void* const*
  * Replaces BertSelfAttention.forward R:100-134 and BertOutAttention.forward R:326-353. */
 int vlni_attn_fwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                   const float* kmask, const float* bias, void* out, long ldo, float* lse, int B, int nh, int Sq, int Sk,
-                  float scale, void* stream);
+                  float scale, float drop_p, unsigned drop_seed /* attention-prob dropout, R:120 */, void* stream);
 int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                   const float* kmask, const float* bias, const void* out, long ldo, const void* dout, long lddo,
                   const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* dbias, int B,
-                  int nh, int Sq, int Sk, float scale, void* stream);
+                  int nh, int Sq, int Sk, float scale, float drop_p, unsigned drop_seed, void* stream);
 
 /* LayerNorm over the last dim H in {256,512,768} (BertLayerNorm R:22; eps 1e-12, T:170-182 eps 1e-5).
  * bwd accumulates (+=) into dgamma/dbeta (float32; both NULL to skip). */
@@ -69,7 +70,9 @@ int vlni_layernorm_fwd(int dtype, const void* x, long ldx, const float* gamma, c
                        long ldy, float* mean, float* rstd, int rows, int H, void* stream);
 int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const float* gamma,
                        const float* mean, const float* rstd, void* dx, long lddx, float* dgamma, float* dbeta, int rows,
-                       int H, const void* dres /* optional: dx += dres (pre-norm residual path) */, long lddres, void* stream);
+                       int H, const void* dres /* optional: dx += dres (pre-norm residual path) */, long lddres,
+                       void* dx_drop /* optional second output dx*mask/(1-p): grad of the dropped dense output (R:146-147) */,
+                       long lddxd, float drop_p, unsigned drop_seed, void* stream);
 /* y = LayerNorm(sum_k src_k), 1..4 sources, each dense / broadcast row (ld 0) / gathered by int64 row index,
  * float32 (parameter tables) or activation dtype; xsum (optional) keeps the pre-norm sum for backward.
  * Replaces BertEmbeddings R:58-73, ImageEmbeddings R:535-544, HistoryEmbeddings R:576-618, D:1087-1131. */
@@ -112,6 +115,8 @@ int vlni_cosine_fwd(int dtype, const void* x, const void* y, float eps, float* c
                     void* stream);
 int vlni_cosine_bwd(int dtype, const void* x, const void* y, const float* gcos, const float* cosv, const float* nx,
                     const float* ny, void* dx, void* dy, int rows, int H, void* stream);
+/* y = x * mask/(1-p), counter-based mask f(seed, linear index); x NULL writes the scaled mask */
+int vlni_dropout(int dtype, const void* x, void* y, long n, float p, unsigned seed, void* stream);
 /* dz = da * act'(z), act 1 gelu-erf / 2 relu (n multiple of 4) */
 int vlni_act_bwd(int dtype, int act, const void* da, const void* z, void* dz, long n, void* stream);
 /* optimizer side of the measured step (r2r/agent_cmt.py:827-832): clip_grad_norm_ + AdamW over a flat arena */

@@ -1,0 +1,119 @@
+"""GPU: train-mode dropout inside the fused kernels. The mask is a pure function of (seed, element index), exported by
+vlni_dropout, so a torch fp64 reference with the SAME masks must match forward and backward."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _mask(ops, shape, p, seed):
+    from vln_imagine_amd import _lib
+    m = torch.empty(shape, dtype=torch.float32, device="cuda")
+    _lib.call("vlni_dropout", 0, 0, m.data_ptr(), m.numel(), p, seed, torch.cuda.current_stream().cuda_stream)
+    return m.double()
+
+
+def _err(a, b):
+    return (a.double() - b.double()).abs().max().item()
+
+
+def test_mask_statistics_and_determinism():
+    from vln_imagine_amd import ops
+    m = _mask(ops, (1 << 20,), 0.1, 1234)
+    keep = (m > 0).double().mean().item()
+    assert abs(keep - 0.9) < 2e-3 and abs(m.max().item() - 1 / 0.9) < 1e-6
+    assert torch.equal(m, _mask(ops, (1 << 20,), 0.1, 1234)) and not torch.equal(m, _mask(ops, (1 << 20,), 0.1, 1235))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_blocks_with_dropout_match_torch_with_same_masks(dtype):
+    from vln_imagine_amd import ops
+    torch.manual_seed(0)
+    B, S, Sv, H, FF, nh = 2, 40, 21, 768, 3072, 12
+    pa, ph, seed = 0.1, 0.2, 777
+    mk = lambda *s, sc=0.04: (torch.randn(*s) * sc).cuda().requires_grad_(True)
+    att = [mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1)]
+    g = (1 + 0.1 * torch.randn(H)).cuda().requires_grad_(True)
+    b = (0.1 * torch.randn(H)).cuda().requires_grad_(True)
+    ffn = [mk(FF, H), mk(FF, sc=0.1), mk(H, FF, sc=0.02), mk(H, sc=0.1)]
+    params = att + [g, b] + ffn
+    x = torch.randn(B, S, H).cuda().to(dtype)
+    ctxt = torch.randn(B, Sv, H).cuda().to(dtype)
+    km = ((torch.rand(B, S) > 0.2).float())
+    km[:, 0] = 1
+    akm = ((1 - km) * -10000.0).cuda()
+    akv = torch.zeros(B, Sv).cuda()
+
+    def ref_att(xq, c, mask, pmask, hmask):
+        wq, bq, wk, bk, wv, bv, wo, bo = [w.double() for w in att]
+        Bq, Sq, _ = xq.shape
+        Sk = c.shape[1]
+        q = F.linear(xq, wq, bq).view(Bq, Sq, nh, 64).transpose(1, 2)
+        k = F.linear(c, wk, bk).view(Bq, Sk, nh, 64).transpose(1, 2)
+        v = F.linear(c, wv, bv).view(Bq, Sk, nh, 64).transpose(1, 2)
+        pr = torch.softmax(q @ k.transpose(-1, -2) / 8 + mask.double()[:, None, None, :], -1) * pmask
+        a = (pr @ v).transpose(1, 2).reshape(Bq, Sq, H)
+        return F.layer_norm(F.linear(a, wo, bo) * hmask + xq, (H,), g.double(), b.double(), 1e-12)
+
+    def ref_ffn(xx, hmask):
+        w1, b1, w2, b2 = [w.double() for w in ffn]
+        return F.layer_norm(F.linear(F.gelu(F.linear(xx, w1, b1)), w2, b2) * hmask + xx, (H,), g.double(), b.double(), 1e-12)
+
+    tol = 1e-4 if dtype == torch.float32 else 6e-2
+    gs = 1.0 if dtype == torch.float32 else 40.0
+
+    def run(prod, ref, inputs):
+        xp = [t.detach().clone().requires_grad_(True) for t in inputs]
+        xr = [t.detach().double().requires_grad_(True) for t in inputs]
+        for prm in params:
+            prm.grad = None
+        op, orr = prod(*xp), ref(*xr)
+        assert _err(op, orr) < tol, ("fwd", _err(op, orr))
+        w = torch.randn_like(orr)
+        (op.double() * w).sum().backward()
+        gp = [prm.grad.clone() for prm in params if prm.grad is not None]
+        gx = [t.grad.clone() for t in xp]
+        for prm in params:
+            prm.grad = None
+        (orr * w).sum().backward()
+        gr = [prm.grad.clone() for prm in params if prm.grad is not None]
+        for a_, r_ in zip(gx, [t.grad for t in xr]):
+            assert _err(a_, r_) < tol * gs * max(1.0, r_.abs().max().item()), ("dx", _err(a_, r_))
+        assert len(gp) == len(gr)
+        for a_, r_ in zip(gp, gr):
+            assert _err(a_, r_) < tol * gs * max(1.0, r_.abs().max().item()), ("dparam", _err(a_, r_))
+
+    P = tuple(att) + (g, b)
+    PF = tuple(ffn) + (g, b)
+    run(lambda t: ops.self_att_block(t, akm, P, drop=(pa, ph, seed)),
+        lambda t: ref_att(t, t, akm, _mask(ops, (B, nh, S, S), pa, seed), _mask(ops, (B, S, H), ph, seed + 1)), [x])
+    run(lambda t: ops.ffn_block(t, PF, drop=(0.0, ph, seed)), lambda t: ref_ffn(t, _mask(ops, (B, S, H), ph, seed)), [x])
+    run(lambda t, c: ops.xatt_block(t, c, akv, P, drop=(pa, ph, seed)),
+        lambda t, c: ref_att(t, c, akv, _mask(ops, (B, nh, S, Sv), pa, seed), _mask(ops, (B, S, H), ph, seed + 1)), [x, ctxt])
+
+
+def test_models_train_mode_runs_and_is_reproducible():
+    from tests.golden.variants import duet_variant_setup, hamt_variant_setup
+    from tests.test_duet_gpu import build_product as build_duet
+    from tests.test_hamt_gpu import build_product as build_hamt
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode as run_duet
+    from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode as run_hamt
+    for build, setup, name, run, ET in ((build_hamt, hamt_variant_setup, "c1_language", run_hamt, EpisodeTensors),
+                                        (build_duet, duet_variant_setup, "c1_shipped", run_duet, DuetEpisodeTensors)):
+        cfg, ep = setup(name)
+        et = ET(ep, "cuda")
+        losses = []
+        for rep in range(2):
+            m = build(cfg).train()
+            torch.manual_seed(5); ops.reseed(99)
+            out = run(m, et)
+            out["loss"].backward()
+            assert torch.isfinite(out["loss"])
+            gn = sum(float(p.grad.double().pow(2).sum()) for p in m.parameters() if p.grad is not None)
+            assert gn > 0 and gn == gn
+            losses.append(out["loss"].item())
+        assert losses[0] == losses[1], losses                 # same seeds -> same masks -> same loss
+        m.eval()
+        assert abs(run(m, et)["loss"].item() - losses[0]) > 1e-4      # dropout really was active in train mode

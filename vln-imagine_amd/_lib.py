@@ -13,18 +13,18 @@ import torch  # noqa: F401  MUST precede the dlopen below: libvlni.so needs liba
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlni.so")
 
-P, L, I, F = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float
+P, L, I, F, U = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_uint
 
 # name -> argtypes, in the order of include/vlni.h
 SIGNATURES = {
     "vlni_gemm_nt": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, P],
-    "vlni_gemm_nt_v": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, I, P],
+    "vlni_gemm_nt_v": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, I, F, U, P],
     "vlni_gemm_tn_bf16": [P, L, P, L, P, L, I, I, I, P, I, P],
     "vlni_gemm_tn_bf16_grouped": [I, P, P, P, L, L, P, L, I, I, P, I, P],
-    "vlni_attn_fwd": [I, P, L, P, L, P, L, P, P, P, L, P, I, I, I, I, F, P],
-    "vlni_attn_bwd": [I, P, L, P, L, P, L, P, P, P, L, P, L, P, P, L, P, L, P, L, P, I, I, I, I, F, P],
+    "vlni_attn_fwd": [I, P, L, P, L, P, L, P, P, P, L, P, I, I, I, I, F, F, U, P],
+    "vlni_attn_bwd": [I, P, L, P, L, P, L, P, P, P, L, P, L, P, P, L, P, L, P, L, P, I, I, I, I, F, F, U, P],
     "vlni_layernorm_fwd": [I, P, L, P, P, F, P, L, P, P, I, I, P],
-    "vlni_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, P, I, I, P, L, P],
+    "vlni_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, P, I, I, P, L, P, L, F, U, P],
     "vlni_sum_layernorm_fwd": [I, I, P, P, P, P, P, P, F, P, L, P, L, P, P, I, I, P],
     "vlni_cast": [I, I, P, P, L, P],
     "vlni_transpose": [I, I, P, L, P, L, I, I, I, P],
@@ -41,6 +41,7 @@ SIGNATURES = {
     "vlni_segment_mean_bwd": [I, P, P, P, P, I, I, P],
     "vlni_cosine_fwd": [I, P, P, F, P, P, P, I, I, P],
     "vlni_cosine_bwd": [I, P, P, P, P, P, P, P, P, I, I, P],
+    "vlni_dropout": [I, P, P, L, F, U, P],
     "vlni_act_bwd": [I, I, P, P, P, L, P],
     "vlni_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, P],
     "vlni_sumsq": [P, L, P, P],

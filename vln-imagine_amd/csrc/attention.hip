@@ -46,6 +46,7 @@ struct AttnP {
   float* lse;           // [B, nh, Sq]
   int B, nh, Sq, Sk;
   float scale;
+  unsigned drop_thr, drop_seed; float drop_inv;   // attention-probability dropout (idx = ((b*nh+h)*Sq+q)*Sk+key)
   // backward only
   const void* dout; long lddo;
   void *dq, *dk, *dv;
@@ -117,6 +118,13 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(AttnP p) {
     }
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
+  if (p.drop_thr) {                                   // dropout on the probabilities (the row sum above stays un-dropped)
+    const unsigned base = (unsigned)((b * p.nh + hd) * p.Sq + qg) * (unsigned)p.Sk;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) s[kt][x] *= drop_scale(base + kt * 32 + acc_row(x, hh), p.drop_seed, p.drop_thr, p.drop_inv);
+  }
 
   T* out = (T*)p.out + ((long)b * p.Sq + qg) * p.ldo + hd * 64;
 #pragma unroll
@@ -213,15 +221,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
           const int ql = qt * 32 + acc_row(x, hh);
-          float pv = 0.f, ds = 0.f;
+          float pv = 0.f, ds = 0.f, pdrop = 0.f;
           if (key < p.Sk && ql < nq) {
             float sv = s[x] * p.scale + kmv;
             if (p.bias) sv += p.bias[((long)b * p.Sq + q0 + ql) * p.Sk + key];
             pv = __expf(sv - lse_s[ql]);
-            ds = pv * (dp[x] - del_s[ql]);
+            float dpx = dp[x];
+            if (p.drop_thr) {
+              const float ms = drop_scale((unsigned)((b * p.nh + hd) * p.Sq + q0 + ql) * (unsigned)p.Sk + key, p.drop_seed,
+                                          p.drop_thr, p.drop_inv);
+              dpx *= ms;                      // dP = dP_dropped * mask / keep
+              pdrop = pv * ms;                // dV uses the dropped probabilities
+            } else {
+              pdrop = pv;
+            }
+            ds = pv * (dpx - del_s[ql]);
             if (p.dbias) atomicAdd(p.dbias + ((long)b * p.Sq + q0 + ql) * p.Sk + key, ds);
           }
-          s[x] = pv;
+          s[x] = pdrop;
           dp[x] = ds * p.scale;
           dSs[ql * LDS_S + key] = dp[x];
         }
@@ -374,6 +391,13 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
     }
   l += __shfl_xor(l, 32, 64);
   const float inv = 1.0f / l;
+  if (p.drop_thr) {                                   // dropout on the probabilities (the row sum above stays un-dropped)
+    const unsigned base = (unsigned)((b * p.nh + hd) * p.Sq + qg) * (unsigned)p.Sk;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) s[kt][x] *= drop_scale(base + kt * 32 + acc_row(x, hh), p.drop_seed, p.drop_thr, p.drop_inv);
+  }
 
   const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
   __bf16* out = (__bf16*)p.out + ((long)b * p.Sq + qg) * p.ldo + hd * 64;
@@ -473,15 +497,24 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(AttnP p) {
 #pragma unroll
         for (int x = 0; x < 16; ++x) {
           const int ql = qt * 32 + acc_row(x, hh);
-          float pv = 0.f, ds = 0.f;
+          float pv = 0.f, ds = 0.f, pdrop = 0.f;
           if (key < p.Sk && ql < nq) {
             float sv = s[x] * p.scale + kmv;
             if (p.bias) sv += p.bias[((long)b * p.Sq + q0 + ql) * p.Sk + key];
             pv = __expf(sv - lse_s[ql]);
-            ds = pv * (dp[x] - del_s[ql]);
+            float dpx = dp[x];
+            if (p.drop_thr) {
+              const float ms = drop_scale((unsigned)((b * p.nh + hd) * p.Sq + q0 + ql) * (unsigned)p.Sk + key, p.drop_seed,
+                                          p.drop_thr, p.drop_inv);
+              dpx *= ms;                      // dP = dP_dropped * mask / keep
+              pdrop = pv * ms;                // dV uses the dropped probabilities
+            } else {
+              pdrop = pv;
+            }
+            ds = pv * (dpx - del_s[ql]);
             if (p.dbias) atomicAdd(p.dbias + ((long)b * p.Sq + q0 + ql) * p.Sk + key, ds);
           }
-          s[x] = pv;
+          s[x] = pdrop;
           dp[x] = ds * p.scale;
           *(__bf16*)(dSs + ql * DSS + key * 2) = (__bf16)dp[x];
         }
@@ -604,10 +637,11 @@ int check_common(const char* who, int dtype, const AttnP& p) {
 
 extern "C" int vlni_attn_fwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                              const float* kmask, const float* bias, void* out, long ldo, float* lse, int B, int nh, int Sq,
-                             int Sk, float scale, void* stream) {
+                             int Sk, float scale, float drop_p, unsigned drop_seed, void* stream) {
   AttnP p = {};
   p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kmask = kmask; p.bias = bias;
   p.out = out; p.ldo = ldo; p.lse = lse; p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p);
   int rc = check_common("attn_fwd", dtype, p);
   if (rc) return rc;
   static const bool f32mfma = getenv("VLNI_ATTN_F32MFMA") != nullptr;
@@ -623,11 +657,12 @@ extern "C" int vlni_attn_fwd(int dtype, const void* q, long ldq, const void* k, 
 extern "C" int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                              const float* kmask, const float* bias, const void* out, long ldo, const void* dout, long lddo,
                              const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* dbias,
-                             int B, int nh, int Sq, int Sk, float scale, void* stream) {
+                             int B, int nh, int Sq, int Sk, float scale, float drop_p, unsigned drop_seed, void* stream) {
   AttnP p = {};
   p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kmask = kmask; p.bias = bias;
   p.out = (void*)out; p.ldo = ldo; p.lse = (float*)lse; p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
   p.dout = dout; p.lddo = lddo; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv; p.dbias = dbias;
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p);
   int rc = check_common("attn_bwd", dtype, p);
   if (rc) return rc;
   VLNI_CHECK(lddo % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, VLNI_EINVAL, "attn_bwd: grad strides");

@@ -105,4 +105,17 @@ template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) {
   }
 }
 
+// Counter-based dropout: keep(seed, idx) is a pure function, so the backward pass regenerates the forward mask from
+// (seed, element index) instead of storing it. idx = row * row_length + col of the tensor the mask applies to.
+__host__ __device__ __forceinline__ unsigned drop_hash(unsigned idx, unsigned seed) {
+  unsigned x = idx * 0x9E3779B1u + seed;
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+// returns 0 (dropped) or 1/(1-p) (kept); thr = p * 2^32
+__device__ __forceinline__ float drop_scale(unsigned idx, unsigned seed, unsigned thr, float inv_keep) {
+  return drop_hash(idx, seed) >= thr ? inv_keep : 0.f;
+}
+static inline unsigned drop_thr(float p) { return p <= 0.f ? 0u : (p >= 1.f ? 0xFFFFFFFFu : (unsigned)((double)p * 4294967296.0)); }
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

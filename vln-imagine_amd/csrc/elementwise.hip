@@ -246,6 +246,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int act, const T* __restri
   }
 }
 
+// y = x * keep(seed, idx)/(1-p)  (x == null: writes the mask itself, for tests); idx = linear element index
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, unsigned thr,
+                                                      unsigned seed, float inv) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float m = drop_scale((unsigned)i, seed, thr, inv);
+    DT<T>::st(y + i, x ? DT<T>::ld(x + i) * m : m);
+  }
+}
+
 // Fused AdamW over a flat parameter arena (torch.optim.AdamW semantics, decoupled weight decay), plus
 // global-norm clipping folded in: g <- g * clip_coef[0].   Optionally refreshes a bf16 shadow of p.
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -455,6 +467,19 @@ extern "C" int vlni_act_bwd(int dtype, int act, const void* da, const void* z, v
   dim3 grid((unsigned)std::min<long>(2048, (n / 4 + 255) / 256)), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((act_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, act, (const float*)da, (const float*)z, (float*)dz, n),
            hipLaunchKernelGGL((act_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, act, (const __bf16*)da, (const __bf16*)z, (__bf16*)dz, n));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// y[i] = x[i] * mask(i) / (1-p) with the library's counter-based mask (x NULL: y = the scaled mask). Used where a dropout
+// cannot ride a GEMM / LayerNorm / attention kernel, and by the tests to build exact torch references.
+extern "C" int vlni_dropout(int dtype, const void* x, void* y, long n, float p, unsigned seed, void* stream) {
+  VLNI_CHECK(n > 0 && p >= 0.f && p < 1.f, VLNI_EINVAL, "dropout: n=%ld p=%f", n, p);
+  dim3 grid((unsigned)std::min<long>(2048, (n + 255) / 256)), block(256);
+  const unsigned thr = drop_thr(p);
+  const float inv = 1.0f / (1.0f - p);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((dropout_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y, n, thr, seed, inv),
+           hipLaunchKernelGGL((dropout_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, n, thr, seed, inv));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

@@ -35,6 +35,7 @@ struct GemmP {
   char* preact; long ldp;       // value before act (after bias), same dtype as C
   const char* dact_src; long ldd; int dact;   // multiply by act'(src) (1 gelu', 2 relu')
   float alpha;
+  unsigned drop_thr, drop_seed; float drop_inv;   // dropout on the epilogue value (after act / act'), before the residual
   int atomic_f32;               // C is float, accumulate with atomics (split-K wgrad)
   int kt_per_split;
   int vec_ok;                   // every epilogue tensor allows 4-element vector accesses
@@ -144,6 +145,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16
 #pragma unroll
           for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
         }
+        if (p.drop_thr) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] *= drop_scale((unsigned)grow * (unsigned)p.N + gcol + u, p.drop_seed, p.drop_thr, p.drop_inv);
+        }
         if (p.residual) v += DT<T>::ld4((const T*)p.residual + (long)grow * p.ldr + gcol);
         DT<T>::st4((T*)p.C + (long)grow * p.ldc + gcol, v);
       } else {
@@ -157,6 +162,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16
           }
           if (p.act == 1) w = gelu_t<T>(w);
           else if (p.act == 2) w = fmaxf(w, 0.f);
+          if (p.drop_thr) w *= drop_scale((unsigned)grow * (unsigned)p.N + (unsigned)col, p.drop_seed, p.drop_thr, p.drop_inv);
           if (p.residual) w += DT<T>::ld((const T*)p.residual + (long)grow * p.ldr + col);
           DT<T>::st((T*)p.C + (long)grow * p.ldc + col, w);
         }
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
 extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
                               int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
                               const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,
-                              int variant, void* stream) {
+                              int variant, float drop_p, unsigned drop_seed, void* stream) {
   VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt: bad dtype %d", dtype);
   VLNI_CHECK(M > 0 && N > 0 && K > 0, VLNI_EINVAL, "gemm_nt: empty problem %d %d %d", M, N, K);
   const int es = dtype == VLNI_F32 ? 4 : 2, epc = 16 / es, bk = ROWB / es;
@@ -470,6 +476,8 @@ extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B,
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.residual = (const char*)residual; p.ldr = ldr;
   p.preact = (char*)preact; p.ldp = ldp; p.dact_src = (const char*)dact_src; p.ldd = ldd; p.dact = dact;
   p.alpha = alpha; p.atomic_f32 = atomic_f32;
+  VLNI_CHECK(drop_p >= 0.f && drop_p < 1.f && !(atomic_f32 && drop_p > 0.f), VLNI_EINVAL, "gemm_nt: dropout p=%f", drop_p);
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p);
   {
     const uintptr_t am = (uintptr_t)(4 * es - 1);     // 4 elements: 16 B (f32) / 8 B (bf16)
     auto okp = [&](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & am) == 0 && ld % 4 == 0); };
@@ -519,7 +527,7 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
                             const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,
                             void* stream) {
   return vlni_gemm_nt_v(dtype, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, preact, ldp, dact_src, ldd, dact,
-                        alpha, split_k, atomic_f32, 0, stream);
+                        alpha, split_k, atomic_f32, 0, 0.f, 0u, stream);
 }
 
 // C[N,K] += sum_s A_s[M_s,N]^T B_s[M_s,K] (bf16 operands as they lie in memory, float32 atomic accumulation, split over

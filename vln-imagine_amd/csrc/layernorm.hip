@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
                                                      const float* __restrict__ g, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx, long lddx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                     const T* __restrict__ dres, long lddres) {
+                                                     const T* __restrict__ dres, long lddres, T* __restrict__ dxd,
+                                                     long lddxd, unsigned dthr, unsigned dseed, float dinv) {
   constexpr int H = 256 * NC;
   __shared__ float red[WAVES][2][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -96,6 +97,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
       f32x4 o;
 #pragma unroll
       for (int j = 0; j < 4; ++j) o[j] = rs * (d[c][j] * gv[c][j] - s1 - xh[c][j] * s2);
+      if (dxd) {   // gradient w.r.t. the dropped dense output that was added to the residual before this LayerNorm
+        f32x4 od;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) od[j] = o[j] * drop_scale((unsigned)row * H + c * 256 + lane * 4 + j, dseed, dthr, dinv);
+        DT<T>::st4(dxd + (long)row * lddxd + c * 256 + lane * 4, od);
+      }
       if (dres) o += DT<T>::ld4(dres + (long)row * lddres + c * 256 + lane * 4);   // pre-norm blocks: + residual-path gradient
       DT<T>::st4(dx + (long)row * lddx + c * 256 + lane * 4, o);
     }
@@ -232,18 +239,19 @@ extern "C" int vlni_layernorm_fwd(int dtype, const void* x, long ldx, const floa
 
 extern "C" int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long ldx, const float* gamma,
                                   const float* mean, const float* rstd, void* dx, long lddx, float* dgamma, float* dbeta,
-                                  int rows, int H, const void* dres, long lddres, void* stream) {
+                                  int rows, int H, const void* dres, long lddres, void* dx_drop, long lddxd, float drop_p,
+                                  unsigned drop_seed, void* stream) {
   int rc = ln_check("layernorm_bwd", dtype, rows, H, ldx < lddx ? (ldx < lddy ? ldx : lddy) : (lddx < lddy ? lddx : lddy));
   if (rc) return rc;
   VLNI_CHECK((dgamma == nullptr) == (dbeta == nullptr), VLNI_EINVAL, "layernorm_bwd: dgamma/dbeta both or neither");
   if (dtype == VLNI_F32) {
     using TT = float;
-    const float* d = (const float*)dy; const float* xx = (const float*)x; float* o = (float*)dx; const float* dr = (const float*)dres;
-    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres);
+    const float* d = (const float*)dy; const float* xx = (const float*)x; float* o = (float*)dx; const float* dr = (const float*)dres; float* dd = (float*)dx_drop;
+    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
   } else {
     using TT = __bf16;
-    const __bf16* d = (const __bf16*)dy; const __bf16* xx = (const __bf16*)x; __bf16* o = (__bf16*)dx; const __bf16* dr = (const __bf16*)dres;
-    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres);
+    const __bf16* d = (const __bf16*)dy; const __bf16* xx = (const __bf16*)x; __bf16* o = (__bf16*)dx; const __bf16* dr = (const __bf16*)dres; __bf16* dd = (__bf16*)dx_drop;
+    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
   }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;

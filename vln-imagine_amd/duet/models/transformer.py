@@ -18,8 +18,9 @@ class _PackedSelfAttn(nn.Module):
 
 
 class TransformerEncoderLayer(nn.Module):
-    def __init__(self, d_model, dim_feedforward):
+    def __init__(self, d_model, dim_feedforward, dropout=0.1):
         super().__init__()
+        self.p = dropout
         self.self_attn = _PackedSelfAttn(d_model)
         self.linear1 = nn.Linear(d_model, dim_feedforward)
         self.linear2 = nn.Linear(dim_feedforward, d_model)
@@ -29,15 +30,18 @@ class TransformerEncoderLayer(nn.Module):
     def forward(self, x, key_add_mask):
         a = self.self_attn
         x = ops.prenorm_att_block(x, key_add_mask, (self.norm1.weight, self.norm1.bias, a.in_proj_weight, a.in_proj_bias,
-                                                    a.out_proj.weight, a.out_proj.bias), eps=self.norm1.eps)
+                                                    a.out_proj.weight, a.out_proj.bias), eps=self.norm1.eps,
+                                  drop=ops.drop_cfg(self.p, self.p, self.training))
         return ops.prenorm_ffn_block(x, (self.norm2.weight, self.norm2.bias, self.linear1.weight, self.linear1.bias,
-                                         self.linear2.weight, self.linear2.bias), eps=self.norm2.eps)
+                                         self.linear2.weight, self.linear2.bias), eps=self.norm2.eps,
+                                     drop=ops.drop_cfg(0.0, self.p, self.training))
 
 
 class TransformerEncoder(nn.Module):
     def __init__(self, config, num_layers):
         super().__init__()
-        self.layers = nn.ModuleList([TransformerEncoderLayer(config.hidden_size, config.intermediate_size)
+        self.layers = nn.ModuleList([TransformerEncoderLayer(config.hidden_size, config.intermediate_size,
+                                                             config.hidden_dropout_prob)
                                      for _ in range(num_layers)])
         self.norm = nn.LayerNorm(config.hidden_size, eps=1e-12)
 

@@ -12,12 +12,13 @@ holders; arithmetic runs in the fused HIP sublayer operators of vln_imagine_amd.
 import os
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from vln_imagine_amd import ops
 from vln_imagine_amd.hamt.models.vilmodel_cmt import (HID_EPS, AlignWithContrastiveLoss, BertAttention, BertEmbeddings,
                                                      BertIntermediate, BertLayer, BertOutput, BertXAttention,
-                                                     BypassImagineEmbeddings, _att, _ffn)
+                                                     BypassImagineEmbeddings, _att, _drop, _ffn)
 from .transformer import TransformerEncoder
 
 
@@ -32,9 +33,9 @@ class GraphLXRTXLayer(nn.Module):
         self.visual_attention = BertXAttention(c)
 
     def forward(self, lang, lang_mask, visn, visn_mask, graph_sprels=None):
-        visn = ops.xatt_block(visn, lang, lang_mask, _att(self.visual_attention))
-        visn = ops.self_att_block(visn, visn_mask, _att(self.visn_self_att), bias=graph_sprels)
-        return ops.ffn_block(visn, _ffn(self.visn_inter, self.visn_output))
+        visn = ops.xatt_block(visn, lang, lang_mask, _att(self.visual_attention), drop=_drop(self.visual_attention))
+        visn = self.visn_self_att(visn, visn_mask, bias=graph_sprels)
+        return ops.ffn_block(visn, _ffn(self.visn_inter, self.visn_output), drop=_drop(self.visn_output))
 
 
 class LanguageEncoder(nn.Module):
@@ -179,6 +180,7 @@ class GlocalTextPathNavCMT(nn.Module):
         srcs = [(e.word_embeddings.weight, "gather", txt_ids.reshape(-1).contiguous()),
                 (e.position_embeddings.weight, "gather", pos), (e.token_type_embeddings.weight[0], "bcast", None)]
         x = ops.sum_layer_norm(srcs, e.LayerNorm.weight, e.LayerNorm.bias, B * L, dt, HID_EPS).view(B, L, -1)
+        x = F.dropout(x, self.config.hidden_dropout_prob, self.training)
         km = ops.additive_mask(txt_masks)
         for layer in self.lang_encoder.layer:
             x = layer(x, km)
@@ -197,6 +199,7 @@ class GlocalTextPathNavCMT(nn.Module):
                 (ie.nav_type_embedding.weight, "gather", nav_types.reshape(-1).contiguous()),
                 (self.embeddings.token_type_embeddings.weight[1], "bcast", None)]
         x = ops.sum_layer_norm(srcs, ie.layer_norm.weight, ie.layer_norm.bias, B * S, dt, HID_EPS).view(B, S, -1)
+        x = F.dropout(x, self.config.hidden_dropout_prob, self.training)
         masks = torch.arange(S, device=x.device)[None, :] < view_lens[:, None]          # gen_seq_masks
         if ie.pano_encoder is not None:
             x = ie.pano_encoder(x, masks)

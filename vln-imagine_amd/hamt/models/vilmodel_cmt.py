@@ -8,12 +8,15 @@ used for their parameter registration and checkpoint compatibility, never for th
 
 Numerics: `compute_dtype` float32 (parity gate, exact-fp32 MFMA) or bfloat16 (throughput;
 float32 master weights, bf16 shadows, float32 accumulation and LayerNorm/softmax statistics).
-Dropout: the fused blocks implement p = 0 / eval only; see DESIGN.md (gap list).
+Dropout (train mode): attention-probability and hidden dropout run INSIDE the fused kernels with a counter-based
+mask (regenerated in backward from (seed, element index), never stored); the few dropouts on small tensors
+(embeddings, heads, features) use torch's. eval() / p = 0 is bit-identical to the no-dropout path.
 """
 import copy
 import os
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from vln_imagine_amd import ops
@@ -62,14 +65,20 @@ class BertSelfOutput(nn.Module):
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
 
 
+def _drop(m):
+    """(p_attn, p_hidden, seed) of a holder for one fused call; zeros in eval()."""
+    return ops.drop_cfg(m.pa, m.ph, m.training)
+
+
 class BertAttention(nn.Module):
     def __init__(self, c):
         super().__init__()
         self.self = BertSelfAttention(c)
         self.output = BertSelfOutput(c)
+        self.pa, self.ph = c.attention_probs_dropout_prob, c.hidden_dropout_prob
 
-    def forward(self, x, kmask):
-        return ops.self_att_block(x, kmask, _att(self))
+    def forward(self, x, kmask, bias=None):
+        return ops.self_att_block(x, kmask, _att(self), bias=bias, drop=_drop(self))
 
 
 class BertXAttention(nn.Module):
@@ -77,6 +86,7 @@ class BertXAttention(nn.Module):
         super().__init__()
         self.att = BertOutAttention(c)
         self.output = BertSelfOutput(c)
+        self.pa, self.ph = c.attention_probs_dropout_prob, c.hidden_dropout_prob
 
 
 class BertIntermediate(nn.Module):
@@ -90,6 +100,7 @@ class BertOutput(nn.Module):
         super().__init__()
         self.dense = nn.Linear(c.intermediate_size, c.hidden_size)
         self.LayerNorm = nn.LayerNorm(c.hidden_size, eps=c.layer_norm_eps)
+        self.pa, self.ph = 0.0, c.hidden_dropout_prob
 
 
 class BertLayer(nn.Module):
@@ -100,7 +111,7 @@ class BertLayer(nn.Module):
         self.output = BertOutput(c)
 
     def forward(self, x, kmask):
-        return ops.ffn_block(self.attention(x, kmask), _ffn(self.intermediate, self.output))
+        return ops.ffn_block(self.attention(x, kmask), _ffn(self.intermediate, self.output), drop=_drop(self.output))
 
 
 class BertEncoder(nn.Module):
@@ -131,12 +142,15 @@ class LXRTXLayer(nn.Module):
         self.visual_attention = BertXAttention(c)
 
     def forward(self, lang, lang_mask, visn, visn_mask):
+        xa = self.visual_attention
         if self.no_lang_ca:
-            visn = ops.xatt_block(visn, lang, lang_mask, _att(self.visual_attention))
+            visn = ops.xatt_block(visn, lang, lang_mask, _att(xa), drop=_drop(xa))
         else:
-            lang, visn = ops.xatt_pair_block(lang, visn, lang_mask, visn_mask, _att(self.visual_attention))
-            lang = ops.ffn_block(self.lang_self_att(lang, lang_mask), _ffn(self.lang_inter, self.lang_output))
-        visn = ops.ffn_block(self.visn_self_att(visn, visn_mask), _ffn(self.visn_inter, self.visn_output))
+            lang, visn = ops.xatt_pair_block(lang, visn, lang_mask, visn_mask, _att(xa), drop=_drop(xa))
+            lang = ops.ffn_block(self.lang_self_att(lang, lang_mask), _ffn(self.lang_inter, self.lang_output),
+                                 drop=_drop(self.lang_output))
+        visn = ops.ffn_block(self.visn_self_att(visn, visn_mask), _ffn(self.visn_inter, self.visn_output),
+                             drop=_drop(self.visn_output))
         return lang, visn
 
 
@@ -173,6 +187,7 @@ class ImageEmbeddings(_FeatEmbed):
         self.ang_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
         self.nav_type_embedding = nn.Embedding(3, h)
         self.layer_norm = nn.LayerNorm(h, eps=HID_EPS)
+        self.p_drop = c.hidden_dropout_prob
 
     def forward(self, img, ang, type_row, nav_types, dt):
         B, S, _ = img.shape
@@ -181,7 +196,7 @@ class ImageEmbeddings(_FeatEmbed):
         if nav_types is not None:
             srcs.append((self.nav_type_embedding.weight, "gather", nav_types.reshape(-1).contiguous()))
         y = ops.sum_layer_norm(srcs, self.layer_norm.weight, self.layer_norm.bias, B * S, dt, HID_EPS)
-        return y.view(B, S, -1)
+        return F.dropout(y.view(B, S, -1), self.p_drop, self.training)
 
 
 class HistoryEmbeddings(_FeatEmbed):
@@ -197,6 +212,7 @@ class HistoryEmbeddings(_FeatEmbed):
         self.type_embedding = nn.Embedding(1, h)
         self.layer_norm = nn.LayerNorm(h, eps=HID_EPS)
         self.hist_enc_pano = c.hist_enc_pano
+        self.p_drop = c.hidden_dropout_prob
         if c.hist_enc_pano:
             self.pano_img_linear = nn.Linear(c.image_feat_size, h)
             self.pano_img_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
@@ -210,7 +226,7 @@ class HistoryEmbeddings(_FeatEmbed):
         g, b = self.layer_norm.weight, self.layer_norm.bias
         if img is None:                                   # CLS path, reference :592-595
             srcs = [(self.cls_token, "bcast", None), (self.type_embedding.weight, "bcast", None)]
-            return ops.sum_layer_norm(srcs, g, b, 1, dt, HID_EPS)
+            return F.dropout(ops.sum_layer_norm(srcs, g, b, 1, dt, HID_EPS), self.p_drop, self.training)
         B = img.shape[0]
         ti, ta = self._feat(img, ang, "", dt)
         row = self.position_embeddings.weight[pos_ids].reshape(1, -1) + self.type_embedding.weight
@@ -218,9 +234,9 @@ class HistoryEmbeddings(_FeatEmbed):
         if self.pano_encoder is not None:                 # :603-614, pano mask is all ones -> no key mask
             Bp, P, _ = pano_img.shape
             pi, pa = self._feat(pano_img, pano_ang, "pano_", dt)
-            pe = (pi + pa).view(Bp, P, -1)
+            pe = F.dropout((pi + pa).view(Bp, P, -1), self.p_drop, self.training)
             srcs.append((ops.seq_mean(self.pano_encoder(pe, None)), "dense", None))
-        return ops.sum_layer_norm(srcs, g, b, B, dt, HID_EPS)
+        return F.dropout(ops.sum_layer_norm(srcs, g, b, B, dt, HID_EPS), self.p_drop, self.training)
 
 
 class BypassImagineEmbeddings(nn.Module):
@@ -243,6 +259,7 @@ class ImagineEmbeddings(nn.Module):
         self.pano_img_layer_norm = nn.LayerNorm(h, eps=HID_EPS)
         self.pano_encoder = BertEncoder(c, c.num_h_pano_layers)
         self.max_imagination_len = c.max_imagination_len
+        self.p_drop = c.hidden_dropout_prob
 
     def forward(self, feats, masks, dt):                 # reference :659-703
         B, n, _ = feats.shape
@@ -250,8 +267,8 @@ class ImagineEmbeddings(nn.Module):
         x = feats + self.position_embeddings.weight[:n] + self.type_embedding.weight[0]
         x = ops.layer_norm(ops.linear(x, self.pano_img_linear.weight, self.pano_img_linear.bias, out_dtype=dt),
                            self.pano_img_layer_norm.weight, self.pano_img_layer_norm.bias, HID_EPS)
-        x = self.pano_encoder(x, ops.additive_mask(masks))
-        return ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, HID_EPS)
+        x = self.pano_encoder(F.dropout(x, self.p_drop, self.training), ops.additive_mask(masks))
+        return F.dropout(ops.layer_norm(x, self.layer_norm.weight, self.layer_norm.bias, HID_EPS), self.p_drop, self.training)
 
 
 class MLPProjectionHead(nn.Module):
@@ -262,6 +279,7 @@ class MLPProjectionHead(nn.Module):
         self.fc3 = nn.Linear(h, o, bias=False)
 
     def forward(self, x):
+        x = F.dropout(x, 0.15, self.training)                 # reference :717,724
         x = ops.linear(x, self.fc1.weight, None, act=2)
         x = ops.linear(x, self.fc2.weight, None, act=2)
         return ops.linear(x, self.fc3.weight, None)
@@ -355,7 +373,7 @@ class NextActionPrediction(nn.Module):
     def forward(self, x, neg_inf_mask):
         n = self.net
         h = ops.layer_norm(ops.linear(x, n[0].weight, n[0].bias, act=2), n[2].weight, n[2].bias, HID_EPS)
-        return ops.row_dot(h, n[4].weight, n[4].bias, neg_inf_mask)
+        return ops.row_dot(n[3](h), n[4].weight, n[4].bias, neg_inf_mask)
 
 
 def _cfg(config):
@@ -438,6 +456,7 @@ class NavCMT(nn.Module):
                     (e.position_embeddings.weight, "gather", pos),
                     (e.token_type_embeddings.weight[0], "bcast", None)]
             x = ops.sum_layer_norm(srcs, e.LayerNorm.weight, e.LayerNorm.bias, B * L, dt, HID_EPS).view(B, L, -1)
+            x = F.dropout(x, c.hidden_dropout_prob, self.training)
             km = ops.additive_mask(txt_masks)
             for layer in self.encoder.layer:
                 x = layer(x, km)
@@ -446,7 +465,7 @@ class NavCMT(nn.Module):
             if c.no_lang_ca:
                 outs = [x]
                 for xl in self.encoder.x_layers:
-                    outs.append(ops.ffn_block(xl.lang_self_att(x, km), _ffn(xl.lang_inter, xl.lang_output)))
+                    outs.append(ops.ffn_block(xl.lang_self_att(x, km), _ffn(xl.lang_inter, xl.lang_output), drop=_drop(xl.lang_output)))
                 return outs
             return x
 

@@ -57,22 +57,25 @@ AUTOTUNE = True
 _GEMM_BEST = {}
 
 
-def _gemm_call(variant, a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K):
+def _gemm_call(variant, a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K, drop=None):
     _lib.call("vlni_gemm_nt_v", _dt(a), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
               out.stride(0), M, N, K, _p(bias), act, _p(residual), residual.stride(0) if residual is not None else 0,
               _p(preact), preact.stride(0) if preact is not None else 0, _p(dact_src),
-              dact_src.stride(0) if dact_src is not None else 0, dact, alpha, split_k, 1 if atomic else 0, variant, _st())
+              dact_src.stride(0) if dact_src is not None else 0, dact, alpha, split_k, 1 if atomic else 0, variant,
+              drop[0] if drop else 0.0, drop[1] if drop else 0, _st())
 
 
 def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_src=None, dact=0,
-            alpha=1.0, split_k=1, atomic=False, out_dtype=None):
-    """out[M,N] = epi(a[M,K] @ b[N,K]^T); a, b same dtype, K-contiguous."""
+            alpha=1.0, split_k=1, atomic=False, out_dtype=None, drop=None):
+    """out[M,N] = epi(a[M,K] @ b[N,K]^T); a, b same dtype, K-contiguous. drop = (p, seed): dropout after act, before residual."""
     M, K = a.shape
     N = b.shape[0]
     assert b.shape[1] == K and a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32 if atomic else a.dtype, device=a.device)
-    args = (a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K)
+    if drop is not None and drop[0] <= 0.0:
+        drop = None
+    args = (a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K, drop)
     variant = 0
     if AUTOTUNE and not atomic and M >= 512 and not torch.cuda.is_current_stream_capturing():
         key = (a.dtype, M, N, K, act, dact, residual is not None, preact is not None)
@@ -148,32 +151,64 @@ def ln_fwd(x, gamma, beta, eps):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, want_param_grads=True, dres=None):
+def ln_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, want_param_grads=True, dres=None, drop=None):
+    """drop = (p, seed): additionally returns dx * mask/(1-p) as 4th value (grad of the dropped dense output)."""
     rows, H = x.shape
     dx = torch.empty((rows, H), dtype=x.dtype, device=x.device)
+    dxd = torch.empty((rows, H), dtype=x.dtype, device=x.device) if (drop is not None and drop[0] > 0.0) else None
     if want_param_grads and dgamma is None:
         dgamma = torch.zeros((H,), dtype=torch.float32, device=x.device)
         dbeta = torch.zeros((H,), dtype=torch.float32, device=x.device)
     _lib.call("vlni_layernorm_bwd", _dt(x), dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), gamma.data_ptr(),
               mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dx.stride(0), _p(dgamma), _p(dbeta), rows, H,
-              _p(dres), dres.stride(0) if dres is not None else 0, _st())
+              _p(dres), dres.stride(0) if dres is not None else 0, _p(dxd), H if dxd is not None else 0,
+              drop[0] if dxd is not None else 0.0, drop[1] if dxd is not None else 0, _st())
+    if drop is not None:
+        return dx, dgamma, dbeta, (dxd if dxd is not None else dx)
     return dx, dgamma, dbeta
 
 
-def attn_fwd(q, k, v, B, Sq, Sk, kmask=None, bias=None, nh=12):
+def attn_fwd(q, k, v, B, Sq, Sk, kmask=None, bias=None, nh=12, drop=None):
     """q [B*Sq, >=nh*64] (strided view), k/v [B*Sk, ...]; returns ctx [B*Sq, nh*64], lse [B,nh,Sq]."""
     out = torch.empty((B * Sq, nh * 64), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, nh, Sq), dtype=torch.float32, device=q.device)
     _lib.call("vlni_attn_fwd", _dt(q), q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
-              _p(kmask), _p(bias), out.data_ptr(), out.stride(0), lse.data_ptr(), B, nh, Sq, Sk, 1.0 / 8.0, _st())
+              _p(kmask), _p(bias), out.data_ptr(), out.stride(0), lse.data_ptr(), B, nh, Sq, Sk, 1.0 / 8.0,
+              drop[0] if drop else 0.0, drop[1] if drop else 0, _st())
     return out, lse
 
 
-def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, Sq, Sk, kmask=None, bias=None, dbias=None, nh=12):
+def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, Sq, Sk, kmask=None, bias=None, dbias=None, nh=12, drop=None):
     _lib.call("vlni_attn_bwd", _dt(q), q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
               _p(kmask), _p(bias), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0), lse.data_ptr(),
               dq.data_ptr(), dq.stride(0), dk.data_ptr(), dk.stride(0), dv.data_ptr(), dv.stride(0), _p(dbias),
-              B, nh, Sq, Sk, 1.0 / 8.0, _st())
+              B, nh, Sq, Sk, 1.0 / 8.0, drop[0] if drop else 0.0, drop[1] if drop else 0, _st())
+
+
+def dropout_apply(x, p, seed):
+    """x * mask/(1-p) with the library's counter-based mask over the linear index (x contiguous)."""
+    if p <= 0.0:
+        return x
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.call("vlni_dropout", _dt(x), x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _st())
+    return y
+
+
+_SEED = [None]
+
+
+def next_seeds(n=4):
+    """n fresh 31-bit dropout seeds (deterministic after torch.manual_seed)."""
+    if _SEED[0] is None:
+        _SEED[0] = torch.initial_seed() & 0x3FFFFFFF
+    base = _SEED[0]
+    _SEED[0] = (base + n * 0x9E37 + 1) & 0x3FFFFFFF
+    return base
+
+
+def reseed(seed):
+    _SEED[0] = seed & 0x3FFFFFFF
 
 
 def cast(x, dtype):
@@ -346,12 +381,13 @@ def _wb_grad_to(ws, bs, dy, x):
     return tuple(_split_rows(gw, rows)), tuple(_split_rows(gb, rows))
 
 
-def _ln_bwd_to(dy, x, g, b, mean, rstd, want, dres=None):
-    """LayerNorm backward with dgamma/dbeta accumulated in place when possible."""
+def _ln_bwd_to(dy, x, g, b, mean, rstd, want, dres=None, drop=None):
+    """LayerNorm backward with dgamma/dbeta accumulated in place when possible. With drop=(p, seed) a 4th value,
+    dx * mask/(1-p), is returned (the gradient of the dropped dense output that fed this LayerNorm)."""
     if want and _direct(g, b):
-        dx, _, _ = ln_bwd(dy, x, g, mean, rstd, g.grad, b.grad, dres=dres)
-        return dx, None, None
-    return ln_bwd(dy, x, g, mean, rstd, want_param_grads=want, dres=dres)
+        r = ln_bwd(dy, x, g, mean, rstd, g.grad, b.grad, dres=dres, drop=drop)
+        return (r[0], None, None) + tuple(r[3:])
+    return ln_bwd(dy, x, g, mean, rstd, want_param_grads=want, dres=dres, drop=drop)
 
 
 # =====================================================================================
@@ -361,18 +397,19 @@ class _SelfAttBlock(torch.autograd.Function):
     """y = LN(dense(attn(x Wq, x Wk, x Wv)) + x): BertAttention, vilmodel_cmt.py:151-161."""
 
     @staticmethod
-    def forward(ctx, x, kmask, bias, eps, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
+    def forward(ctx, x, kmask, bias, eps, drop, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
         B, S, H = x.shape
+        pa, ph, sd = drop
         x2 = _rows(_chk(x, "x"))
         dt = x.dtype
         wqkv, bqkv = _w((wq, wk, wv), dt), _w((bq, bk, bv), torch.float32)
         qkv = gemm_nt(x2, wqkv, bias=bqkv)
-        c, lse = attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, S, kmask, bias)
-        pre = gemm_nt(c, _w((wo,), dt), bias=bo, residual=x2)
+        c, lse = attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, S, kmask, bias, drop=(pa, sd))
+        pre = gemm_nt(c, _w((wo,), dt), bias=bo, residual=x2, drop=(ph, sd + 1))
         y, mean, rstd = ln_fwd(pre, g, b, eps)
         ctx.save_for_backward(x2, qkv, c, lse, pre, mean, rstd, kmask, bias)
         ctx.P = (wq, bq, wk, bk, wv, bv, wo, bo, g, b)
-        ctx.dims = (B, S, H)
+        ctx.dims, ctx.drop = (B, S, H), drop
         return y.view(B, S, H)
 
     @staticmethod
@@ -380,39 +417,40 @@ class _SelfAttBlock(torch.autograd.Function):
         x2, qkv, c, lse, pre, mean, rstd, kmask, bias = ctx.saved_tensors
         wq, bq, wk, bk, wv, bv, wo, bo, g, b = ctx.P
         B, S, H = ctx.dims
+        pa, ph, sd = ctx.drop
         dt = x2.dtype
         ng = ctx.needs_input_grad
-        wparams = any(ng[4:])
-        dpre, dg, db = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams)
+        wparams = any(ng[5:])
+        dpre, dg, db, dpm = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams, drop=(ph, sd + 1))
         dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = None
         if wparams:
-            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dpre, c)
-        dc = gemm_nt(dpre, _w((wo,), dt, True))
+            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dpm, c)
+        dc = gemm_nt(dpm, _w((wo,), dt, True))
         dqkv = torch.empty_like(qkv)
         dbias = torch.zeros_like(bias) if (bias is not None and ng[2]) else None
         attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], c, dc, lse, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:],
-                 B, S, S, kmask, bias, dbias)
+                 B, S, S, kmask, bias, dbias, drop=(pa, sd))
         if wparams:
             (dwq, dwk, dwv), (dbq, dbk, dbv) = _wb_grad_to((wq, wk, wv), (bq, bk, bv), dqkv, x2)
         dx = gemm_nt(dqkv, _w((wq, wk, wv), dt, True), residual=dpre).view(B, S, H) if ng[0] else None
-        return dx, None, dbias, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
+        return dx, None, dbias, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
 
 
 class _FfnBlock(torch.autograd.Function):
     """y = LN(W2 gelu(W1 x + b1) + b2 + x): BertIntermediate + BertOutput, vilmodel_cmt.py:164-190."""
 
     @staticmethod
-    def forward(ctx, x, eps, w1, b1, w2, b2, g, b):
+    def forward(ctx, x, eps, drop, w1, b1, w2, b2, g, b):
         shp = x.shape
         x2 = _rows(_chk(x, "x"))
         dt = x.dtype
         z = torch.empty((x2.shape[0], w1.shape[0]), dtype=dt, device=x.device)
         a = gemm_nt(x2, _w((w1,), dt), bias=b1, act=1, preact=z)
-        pre = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2)
+        pre = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2, drop=(drop[1], drop[2]))
         y, mean, rstd = ln_fwd(pre, g, b, eps)
         ctx.save_for_backward(x2, z, a, pre, mean, rstd)
         ctx.P = (w1, b1, w2, b2, g, b)
-        ctx.shp = shp
+        ctx.shp, ctx.drop = shp, drop
         return y.view(shp)
 
     @staticmethod
@@ -421,16 +459,16 @@ class _FfnBlock(torch.autograd.Function):
         w1, b1, w2, b2, g, b = ctx.P
         dt = x2.dtype
         ng = ctx.needs_input_grad
-        wparams = any(ng[2:])
-        dpre, dg, db = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams)
+        wparams = any(ng[3:])
+        dpre, dg, db, dpm = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams, drop=(ctx.drop[1], ctx.drop[2]))
         dw1 = db1 = dw2 = db2 = None
         if wparams:
-            (dw2,), (db2,) = _wb_grad_to((w2,), (b2,), dpre, a)
-        dz = gemm_nt(dpre, _w((w2,), dt, True), dact_src=z, dact=1)      # GELU' fused in the dgrad epilogue
+            (dw2,), (db2,) = _wb_grad_to((w2,), (b2,), dpm, a)
+        dz = gemm_nt(dpm, _w((w2,), dt, True), dact_src=z, dact=1)       # GELU' fused in the dgrad epilogue
         if wparams:
             (dw1,), (db1,) = _wb_grad_to((w1,), (b1,), dz, x2)
         dx = gemm_nt(dz, _w((w1,), dt, True), residual=dpre).view(ctx.shp) if ng[0] else None
-        return dx, None, dw1, db1, dw2, db2, dg, db
+        return dx, None, None, dw1, db1, dw2, db2, dg, db
 
 
 class _XAttPairBlock(torch.autograd.Function):
@@ -440,24 +478,25 @@ class _XAttPairBlock(torch.autograd.Function):
     Q/K/V of both streams come from one packed [2304,768] projection each."""
 
     @staticmethod
-    def forward(ctx, lang, visn, mask_l, mask_v, eps, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
+    def forward(ctx, lang, visn, mask_l, mask_v, eps, drop, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
         B, Sl, H = lang.shape
+        pa, ph, sd = drop
         Sv = visn.shape[1]
         l2, v2 = _rows(_chk(lang, "lang")), _rows(_chk(visn, "visn"))
         dt = lang.dtype
         wqkv, bqkv, wo_c = _w((wq, wk, wv), dt), _w((bq, bk, bv), torch.float32), _w((wo,), dt)
         ql = gemm_nt(l2, wqkv, bias=bqkv)
         qv = gemm_nt(v2, wqkv, bias=bqkv)
-        cl, lse_l = attn_fwd(ql[:, :H], qv[:, H:2 * H], qv[:, 2 * H:], B, Sl, Sv, mask_v)
-        cv, lse_v = attn_fwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], B, Sv, Sl, mask_l)
-        pre_l = gemm_nt(cl, wo_c, bias=bo, residual=l2)
-        pre_v = gemm_nt(cv, wo_c, bias=bo, residual=v2)
+        cl, lse_l = attn_fwd(ql[:, :H], qv[:, H:2 * H], qv[:, 2 * H:], B, Sl, Sv, mask_v, drop=(pa, sd))
+        cv, lse_v = attn_fwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], B, Sv, Sl, mask_l, drop=(pa, sd + 1))
+        pre_l = gemm_nt(cl, wo_c, bias=bo, residual=l2, drop=(ph, sd + 2))
+        pre_v = gemm_nt(cv, wo_c, bias=bo, residual=v2, drop=(ph, sd + 3))
         yl, mean_l, rstd_l = ln_fwd(pre_l, g, b, eps)
         yv, mean_v, rstd_v = ln_fwd(pre_v, g, b, eps)
         ctx.save_for_backward(l2, v2, ql, qv, cl, cv, lse_l, lse_v, pre_l, pre_v, mean_l, rstd_l, mean_v, rstd_v,
                               mask_l, mask_v)
         ctx.P = (wq, bq, wk, bk, wv, bv, wo, bo, g, b)
-        ctx.dims = (B, Sl, Sv, H)
+        ctx.dims, ctx.drop = (B, Sl, Sv, H), drop
         return yl.view(B, Sl, H), yv.view(B, Sv, H)
 
     @staticmethod
@@ -468,27 +507,28 @@ class _XAttPairBlock(torch.autograd.Function):
         B, Sl, Sv, H = ctx.dims
         dt = l2.dtype
         ng = ctx.needs_input_grad
-        wparams = any(ng[5:])
+        pa, ph, sd = ctx.drop
+        wparams = any(ng[6:])
         direct = wparams and _direct(wq, bq, wk, bk, wv, bv, wo, bo, g, b)
         dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = dg = db = None
         if direct or not wparams:
-            dpl, _, _ = _ln_bwd_to(_rows(dyl), pre_l, g, b, mean_l, rstd_l, wparams)
-            dpv, _, _ = _ln_bwd_to(_rows(dyv), pre_v, g, b, mean_v, rstd_v, wparams)
+            dpl, _, _, dml = _ln_bwd_to(_rows(dyl), pre_l, g, b, mean_l, rstd_l, wparams, drop=(ph, sd + 2))
+            dpv, _, _, dmv = _ln_bwd_to(_rows(dyv), pre_v, g, b, mean_v, rstd_v, wparams, drop=(ph, sd + 3))
         else:
-            dpl, dg, db = ln_bwd(_rows(dyl), pre_l, g, mean_l, rstd_l)
-            dpv, dg, db = ln_bwd(_rows(dyv), pre_v, g, mean_v, rstd_v, dg, db)
+            dpl, dg, db, dml = ln_bwd(_rows(dyl), pre_l, g, mean_l, rstd_l, drop=(ph, sd + 2))
+            dpv, dg, db, dmv = ln_bwd(_rows(dyv), pre_v, g, mean_v, rstd_v, dg, db, drop=(ph, sd + 3))
         if direct:
-            _wb_grad_to((wo,), (bo,), dpl, cl); _wb_grad_to((wo,), (bo,), dpv, cv)
+            _wb_grad_to((wo,), (bo,), dml, cl); _wb_grad_to((wo,), (bo,), dmv, cv)
         elif wparams:
-            dwo = wgrad(dpv, cv, wgrad(dpl, cl))
-            dbo = colsum(dpv, colsum(dpl))
+            dwo = wgrad(dmv, cv, wgrad(dml, cl))
+            dbo = colsum(dmv, colsum(dml))
         wot = _w((wo,), dt, True)
-        dcl, dcv = gemm_nt(dpl, wot), gemm_nt(dpv, wot)
+        dcl, dcv = gemm_nt(dml, wot), gemm_nt(dmv, wot)
         dql, dqv = torch.empty_like(ql), torch.empty_like(qv)
         attn_bwd(ql[:, :H], qv[:, H:2 * H], qv[:, 2 * H:], cl, dcl, lse_l, dql[:, :H], dqv[:, H:2 * H], dqv[:, 2 * H:],
-                 B, Sl, Sv, mask_v)
+                 B, Sl, Sv, mask_v, drop=(pa, sd))
         attn_bwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], cv, dcv, lse_v, dqv[:, :H], dql[:, H:2 * H], dql[:, 2 * H:],
-                 B, Sv, Sl, mask_l)
+                 B, Sv, Sl, mask_l, drop=(pa, sd + 1))
         if direct:
             _wb_grad_to((wq, wk, wv), (bq, bk, bv), dql, l2); _wb_grad_to((wq, wk, wv), (bq, bk, bv), dqv, v2)
         elif wparams:
@@ -497,7 +537,7 @@ class _XAttPairBlock(torch.autograd.Function):
         wt = _w((wq, wk, wv), dt, True)
         dl = gemm_nt(dql, wt, residual=dpl).view(B, Sl, H) if ng[0] else None
         dv = gemm_nt(dqv, wt, residual=dpv).view(B, Sv, H) if ng[1] else None
-        return dl, dv, None, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
+        return dl, dv, None, None, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
 
 
 class _XAttBlock(torch.autograd.Function):
@@ -505,19 +545,20 @@ class _XAttBlock(torch.autograd.Function):
     (GraphLXRTXLayer cross step, VLN-DUET vilmodel.py:384-399; HAMT no_lang_ca)."""
 
     @staticmethod
-    def forward(ctx, x, c_in, mask_c, eps, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
+    def forward(ctx, x, c_in, mask_c, eps, drop, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
         B, Sq, H = x.shape
+        pa, ph, sd = drop
         Sk = c_in.shape[1]
         x2, c2 = _rows(_chk(x, "x")), _rows(_chk(c_in, "context"))
         dt = x.dtype
         q = gemm_nt(x2, _w((wq,), dt), bias=bq)
         kv = gemm_nt(c2, _w((wk, wv), dt), bias=_w((bk, bv), torch.float32))
-        a, lse = attn_fwd(q, kv[:, :H], kv[:, H:], B, Sq, Sk, mask_c)
-        pre = gemm_nt(a, _w((wo,), dt), bias=bo, residual=x2)
+        a, lse = attn_fwd(q, kv[:, :H], kv[:, H:], B, Sq, Sk, mask_c, drop=(pa, sd))
+        pre = gemm_nt(a, _w((wo,), dt), bias=bo, residual=x2, drop=(ph, sd + 1))
         y, mean, rstd = ln_fwd(pre, g, b, eps)
         ctx.save_for_backward(x2, c2, q, kv, a, lse, pre, mean, rstd, mask_c)
         ctx.P = (wq, bq, wk, bk, wv, bv, wo, bo, g, b)
-        ctx.dims = (B, Sq, Sk, H)
+        ctx.dims, ctx.drop = (B, Sq, Sk, H), drop
         return y.view(B, Sq, H)
 
     @staticmethod
@@ -527,20 +568,21 @@ class _XAttBlock(torch.autograd.Function):
         B, Sq, Sk, H = ctx.dims
         dt = x2.dtype
         ng = ctx.needs_input_grad
-        wparams = any(ng[4:])
-        dpre, dg, db = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams)
+        pa, ph, sd = ctx.drop
+        wparams = any(ng[5:])
+        dpre, dg, db, dpm = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams, drop=(ph, sd + 1))
         dwo = dbo = dwq = dbq = dwk = dwv = dbk = dbv = None
         if wparams:
-            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dpre, a)
-        da = gemm_nt(dpre, _w((wo,), dt, True))
+            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dpm, a)
+        da = gemm_nt(dpm, _w((wo,), dt, True))
         dq, dkv = torch.empty_like(q), torch.empty_like(kv)
-        attn_bwd(q, kv[:, :H], kv[:, H:], a, da, lse, dq, dkv[:, :H], dkv[:, H:], B, Sq, Sk, mask_c)
+        attn_bwd(q, kv[:, :H], kv[:, H:], a, da, lse, dq, dkv[:, :H], dkv[:, H:], B, Sq, Sk, mask_c, drop=(pa, sd))
         if wparams:
             (dwq,), (dbq,) = _wb_grad_to((wq,), (bq,), dq, x2)
             (dwk, dwv), (dbk, dbv) = _wb_grad_to((wk, wv), (bk, bv), dkv, c2)
         dx = gemm_nt(dq, _w((wq,), dt, True), residual=dpre).view(B, Sq, H) if ng[0] else None
         dc = gemm_nt(dkv, _w((wk, wv), dt, True)).view(B, Sk, H) if ng[1] else None
-        return dx, dc, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
+        return dx, dc, None, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
 
 
 class _PreNormAttBlock(torch.autograd.Function):
@@ -548,16 +590,17 @@ class _PreNormAttBlock(torch.autograd.Function):
     TransformerEncoderLayer.forward_pre, first half (VLN-DUET models/transformer.py:170-177)."""
 
     @staticmethod
-    def forward(ctx, x, kmask, eps, g, b, win, bin_, wo, bo):
+    def forward(ctx, x, kmask, eps, drop, g, b, win, bin_, wo, bo):
         B, S, H = x.shape
+        pa, ph, sd = drop
         x2 = _rows(_chk(x, "x"))
         dt = x.dtype
         xn, mean, rstd = ln_fwd(x2, g, b, eps)
         qkv = gemm_nt(xn, _w((win,), dt), bias=bin_)
-        c, lse = attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, S, kmask)
-        y = gemm_nt(c, _w((wo,), dt), bias=bo, residual=x2)
+        c, lse = attn_fwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], B, S, S, kmask, drop=(pa, sd))
+        y = gemm_nt(c, _w((wo,), dt), bias=bo, residual=x2, drop=(ph, sd + 1))
         ctx.save_for_backward(x2, xn, qkv, c, lse, mean, rstd, kmask)
-        ctx.P, ctx.dims = (g, b, win, bin_, wo, bo), (B, S, H)
+        ctx.P, ctx.dims, ctx.drop = (g, b, win, bin_, wo, bo), (B, S, H), drop
         return y.view(B, S, H)
 
     @staticmethod
@@ -567,36 +610,39 @@ class _PreNormAttBlock(torch.autograd.Function):
         B, S, H = ctx.dims
         dt = x2.dtype
         ng = ctx.needs_input_grad
-        wparams = any(ng[3:])
+        pa, ph, sd = ctx.drop
+        wparams = any(ng[4:])
         dy2 = _rows(dy)
+        dym = dropout_apply(dy2, ph, sd + 1)
         dwo = dbo = dwin = dbin = None
         if wparams:
-            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dy2, c)
-        dc = gemm_nt(dy2, _w((wo,), dt, True))
+            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dym, c)
+        dc = gemm_nt(dym, _w((wo,), dt, True))
         dqkv = torch.empty_like(qkv)
         attn_bwd(qkv[:, :H], qkv[:, H:2 * H], qkv[:, 2 * H:], c, dc, lse, dqkv[:, :H], dqkv[:, H:2 * H], dqkv[:, 2 * H:],
-                 B, S, S, kmask)
+                 B, S, S, kmask, drop=(pa, sd))
         if wparams:
             (dwin,), (dbin,) = _wb_grad_to((win,), (bin_,), dqkv, xn)
         dxn = gemm_nt(dqkv, _w((win,), dt, True))
         dx, dg, db = _ln_bwd_to(dxn, x2, g, b, mean, rstd, wparams, dres=dy2)
-        return dx.view(B, S, H), None, None, dg, db, dwin, dbin, dwo, dbo
+        return dx.view(B, S, H), None, None, None, dg, db, dwin, dbin, dwo, dbo
 
 
 class _PreNormFfnBlock(torch.autograd.Function):
     """y = x + W2 gelu(W1 LN(x) + b1) + b2: forward_pre, second half (transformer.py:178-181)."""
 
     @staticmethod
-    def forward(ctx, x, eps, g, b, w1, b1, w2, b2):
+    def forward(ctx, x, eps, drop, g, b, w1, b1, w2, b2):
         shp = x.shape
         x2 = _rows(_chk(x, "x"))
         dt = x.dtype
+        _, ph, sd = drop
         xn, mean, rstd = ln_fwd(x2, g, b, eps)
         z = torch.empty((x2.shape[0], w1.shape[0]), dtype=dt, device=x.device)
-        a = gemm_nt(xn, _w((w1,), dt), bias=b1, act=1, preact=z)
-        y = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2)
+        a = gemm_nt(xn, _w((w1,), dt), bias=b1, act=1, preact=z, drop=(ph, sd))
+        y = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2, drop=(ph, sd + 1))
         ctx.save_for_backward(x2, xn, z, a, mean, rstd)
-        ctx.P, ctx.shp = (g, b, w1, b1, w2, b2), shp
+        ctx.P, ctx.shp, ctx.drop = (g, b, w1, b1, w2, b2), shp, drop
         return y.view(shp)
 
     @staticmethod
@@ -605,17 +651,19 @@ class _PreNormFfnBlock(torch.autograd.Function):
         g, b, w1, b1, w2, b2 = ctx.P
         dt = x2.dtype
         ng = ctx.needs_input_grad
-        wparams = any(ng[2:])
+        _, ph, sd = ctx.drop
+        wparams = any(ng[3:])
         dy2 = _rows(dy)
+        dym = dropout_apply(dy2, ph, sd + 1)
         dw1 = db1 = dw2 = db2 = None
         if wparams:
-            (dw2,), (db2,) = _wb_grad_to((w2,), (b2,), dy2, a)
-        dz = gemm_nt(dy2, _w((w2,), dt, True), dact_src=z, dact=1)
+            (dw2,), (db2,) = _wb_grad_to((w2,), (b2,), dym, a)
+        dz = gemm_nt(dym, _w((w2,), dt, True), dact_src=z, dact=1, drop=(ph, sd))
         if wparams:
             (dw1,), (db1,) = _wb_grad_to((w1,), (b1,), dz, xn)
         dxn = gemm_nt(dz, _w((w1,), dt, True))
         dx, dg, db = _ln_bwd_to(dxn, x2, g, b, mean, rstd, wparams, dres=dy2)
-        return dx.view(ctx.shp), None, dg, db, dw1, db1, dw2, db2
+        return dx.view(ctx.shp), None, None, dg, db, dw1, db1, dw2, db2
 
 
 # =====================================================================================
@@ -889,28 +937,38 @@ class _Cosine(torch.autograd.Function):
 
 
 # ---- functional front-ends ------------------------------------------------------------
-def self_att_block(x, kmask, p, eps=1e-12, bias=None):
-    return _SelfAttBlock.apply(x, kmask, bias, eps, *p)
+NO_DROP = (0.0, 0.0, 0)
 
 
-def ffn_block(x, p, eps=1e-12):
-    return _FfnBlock.apply(x, eps, *p)
+def drop_cfg(p_attn, p_hidden, training):
+    """(p_attn, p_hidden, seed) for one fused block call; zeros outside training."""
+    if not training or (p_attn <= 0.0 and p_hidden <= 0.0):
+        return NO_DROP
+    return (float(p_attn), float(p_hidden), next_seeds(4))
 
 
-def xatt_pair_block(lang, visn, mask_l, mask_v, p, eps=1e-12):
-    return _XAttPairBlock.apply(lang, visn, mask_l, mask_v, eps, *p)
+def self_att_block(x, kmask, p, eps=1e-12, bias=None, drop=NO_DROP):
+    return _SelfAttBlock.apply(x, kmask, bias, eps, drop, *p)
 
 
-def xatt_block(x, c_in, mask_c, p, eps=1e-12):
-    return _XAttBlock.apply(x, c_in, mask_c, eps, *p)
+def ffn_block(x, p, eps=1e-12, drop=NO_DROP):
+    return _FfnBlock.apply(x, eps, drop, *p)
 
 
-def prenorm_att_block(x, kmask, p, eps=1e-5):
-    return _PreNormAttBlock.apply(x, kmask, eps, *p)
+def xatt_pair_block(lang, visn, mask_l, mask_v, p, eps=1e-12, drop=NO_DROP):
+    return _XAttPairBlock.apply(lang, visn, mask_l, mask_v, eps, drop, *p)
 
 
-def prenorm_ffn_block(x, p, eps=1e-5):
-    return _PreNormFfnBlock.apply(x, eps, *p)
+def xatt_block(x, c_in, mask_c, p, eps=1e-12, drop=NO_DROP):
+    return _XAttBlock.apply(x, c_in, mask_c, eps, drop, *p)
+
+
+def prenorm_att_block(x, kmask, p, eps=1e-5, drop=NO_DROP):
+    return _PreNormAttBlock.apply(x, kmask, eps, drop, *p)
+
+
+def prenorm_ffn_block(x, p, eps=1e-5, drop=NO_DROP):
+    return _PreNormFfnBlock.apply(x, eps, drop, *p)
 
 
 def linear(x, w, b=None, act=0, out_dtype=None):
