@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--V", type=int, default=37)
     ap.add_argument("--I", type=int, default=6)
     ap.add_argument("--freeze", default="none", choices=["none", "shipped"])
+    ap.add_argument("--time-batched", action="store_true",
+                    help="HAMT: run the T teacher-forced steps as one [T*B] batch (same results, SURVEY 8f rank 1)")
     ap.add_argument("--model", default="hamt", choices=["hamt", "duet"],
                     help="hamt = BASELINE.json configs[1] (the metric's config); duet = configs[3] (batch 32)")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -158,6 +160,9 @@ def main():
         model = make_model(cfg, dtype, dev)
         ep = synth.HamtEpisode(tag=f"bench{rank}", B=args.batch, L=args.L, V=args.V, I=args.I, T=args.T, ragged=False)
         et = EpisodeTensors(ep, dev)
+        if args.time_batched:
+            from vln_imagine_amd.hamt.episode import run_episode_time_batched
+            run_episode = lambda m, e, criterion=None, keep=False: run_episode_time_batched(m, e, criterion=criterion)
     trainer = FlatTrainer(model, lr=1e-5)
 
     def step():
@@ -240,7 +245,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{'HAMT-Imagine 9L+4X+2pano' if args.model == 'hamt' else 'DUET-Imagine 9L+2pano+4global+4local X, map 5+3t nodes'}, batch {args.batch}/GPU, {args.L} text, {args.V} obs tokens, "
-                                   f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, dropout p=0",
+                                   f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, dropout p=0"
+                                   + (", steps time-batched (teacher forcing)" if args.time_batched else ", step-by-step calls"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "steps_per_sec": round(args.T * args.batch * world / (dt / args.steps), 1),
                        "loss": round(float(loss), 5)},

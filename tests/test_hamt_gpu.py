@@ -167,3 +167,27 @@ def test_deferred_grouped_wgrad_bf16_matches_immediate():
     finally:
         ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
         ops._WQ.clear()
+
+
+def test_time_batched_episode_equals_stepwise():
+    """All T steps as one [T*B] batch (teacher forcing) == the step-by-step rollout: logits, loss, gradients (fp32)."""
+    from vln_imagine_amd.hamt.episode import run_episode_time_batched
+    cfg, ep = hamt_variant_setup("c1_T3_dense")
+    et = EpisodeTensors(ep, "cuda")
+    m1, m2 = build_product(cfg), build_product(cfg)
+    o1 = run_episode(m1, et)
+    o1["loss"].backward()
+    o2 = run_episode_time_batched(m2, et)
+    o2["loss"].backward()
+    assert abs(o1["loss"].item() - o2["loss"].item()) < 1e-5
+    for t in range(ep.T):
+        a, b = o1["logits"][t], o2["logits"][t]
+        fin = torch.isfinite(a)
+        assert (torch.isfinite(b) == fin).all() and (a[fin] - b[fin]).abs().max().item() < 2e-5
+        assert (o1["hist"][t] - o2["hist"][t]).abs().max().item() < 1e-5
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None or float(q.grad.abs().max()) == 0, n
+            continue
+        d = (p.grad - q.grad).abs().max().item()
+        assert d <= 3e-5 * max(1.0, p.grad.abs().max().item()), (n, d)

@@ -79,3 +79,45 @@ def run_episode(model, et, bypass=True, use_aux=True, train_ml=0.2, cosine_weigh
     out.update(loss=loss, ml_loss=ml_loss, aux=aux, txt_embeds=txt_embeds,
                imagine_embeds=imagine_embeds, hist_cls=hist[0])
     return out
+
+
+def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum):
+    """The same teacher-forced episode with all T steps executed as ONE batch of T*B samples.
+
+    Under teacher forcing every step's observation and history INPUTS are known up front (agent_cmt.py:561-562), so the
+    T `history` calls collapse into one call on [T*B] rows and the T `visual` calls into one call whose sample (t, b)
+    sees the history prefix [CLS, h_0 .. h_{t-1}] (padded to T entries, masked exactly like ended episodes are in the
+    reference, model_HAMT.py:62-63). Logits, loss and gradients equal the step-by-step rollout; only the GEMM row
+    count (x T) and the launch count (/ T) change. Sampling / RL rollouts cannot use this (actions feed back)."""
+    ep, B, T = et.ep, et.B, et.T
+    dev = et.txt_ids.device
+    txt = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
+    img = model("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None if bypass else et.imagine_masks)
+    aux = None
+    if use_aux:
+        aux, img = model("align_with_contrastive_loss", align_txt_embeds=txt, txt_masks=et.txt_masks, align_imagine_embeds=img,
+                         imagine_masks=et.imagine_masks, sub_instr_segs=ep.sub_instr_segs,
+                         sub_instr_imag_flag=ep.sub_instr_imag_flag, noun_phrase_segs=ep.noun_phrase_segs)
+    cat = lambda k: torch.cat([s[k] for s in et.steps], 0)
+    cls = model("history").expand(B, -1)                                                   # [B, H]
+    h_all = model("history", hist_img_feats=cat("hist_img_feats"), hist_ang_feats=cat("hist_ang_feats"),
+                  ob_step_ids=torch.arange(T, device=dev).repeat_interleave(B),
+                  hist_pano_img_feats=cat("hist_pano_img_feats"), hist_pano_ang_feats=cat("hist_pano_ang_feats"))
+    H = h_all.shape[-1]
+    hist_steps = h_all.view(T, B, H)
+    # sample (t, b): [CLS, h_0 .. h_{T-2}] with the first t+1 entries valid
+    prefix = torch.cat([cls.to(h_all.dtype).unsqueeze(0), hist_steps[:T - 1]], 0)          # [T, B, H] entries 0..T-1
+    hist = prefix.permute(1, 0, 2).unsqueeze(0).expand(T, B, T, H).reshape(T * B, T, H)
+    hist_masks = (torch.arange(T, device=dev)[None, :] <= torch.arange(T, device=dev)[:, None])    # [t, entry]
+    hist_masks = hist_masks.unsqueeze(1).expand(T, B, T).reshape(T * B, T)
+    rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+    logits, txt_o, hist_o, ob_o = model(
+        "visual", txt_embeds=rep(txt), txt_masks=rep(et.txt_masks), hist_embeds=hist, hist_masks=hist_masks,
+        ob_img_feats=cat("ob_img_feats"), ob_ang_feats=cat("ob_ang_feats"), ob_nav_types=cat("ob_nav_types"),
+        ob_masks=cat("ob_masks"), imagine_embeds=rep(img), imagine_masks=rep(et.imagine_masks))
+    ml_loss = criterion(logits, cat("target"))
+    loss = ml_loss * train_ml / B
+    if use_aux and torch.is_tensor(aux):
+        loss = loss + cosine_weight * aux
+    return {"loss": loss, "ml_loss": ml_loss, "aux": aux, "logits": list(logits.view(T, B, -1)), "txt_embeds": txt,
+            "imagine_embeds": img, "hist": list(hist_steps)}

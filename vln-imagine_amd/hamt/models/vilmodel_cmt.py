@@ -229,13 +229,21 @@ class HistoryEmbeddings(_FeatEmbed):
             return F.dropout(ops.sum_layer_norm(srcs, g, b, 1, dt, HID_EPS), self.p_drop, self.training)
         B = img.shape[0]
         ti, ta = self._feat(img, ang, "", dt)
-        row = self.position_embeddings.weight[pos_ids].reshape(1, -1) + self.type_embedding.weight
-        srcs = [(ti, "dense", None), (ta, "dense", None), (row, "bcast", None)]
+        if pos_ids.numel() == 1:                          # one step for the whole batch (the agent's per-step call)
+            row = self.position_embeddings.weight[pos_ids].reshape(1, -1) + self.type_embedding.weight
+            srcs = [(ti, "dense", None), (ta, "dense", None), (row, "bcast", None)]
+        else:                                             # per-row step ids (time-batched teacher forcing)
+            srcs = [(ti, "dense", None), (ta, "dense", None), (self.type_embedding.weight, "bcast", None),
+                    (self.position_embeddings.weight, "gather", pos_ids.reshape(-1).contiguous())]
         if self.pano_encoder is not None:                 # :603-614, pano mask is all ones -> no key mask
             Bp, P, _ = pano_img.shape
             pi, pa = self._feat(pano_img, pano_ang, "pano_", dt)
             pe = F.dropout((pi + pa).view(Bp, P, -1), self.p_drop, self.training)
-            srcs.append((ops.seq_mean(self.pano_encoder(pe, None)), "dense", None))
+            pm = ops.seq_mean(self.pano_encoder(pe, None))
+            if len(srcs) == 4:                            # the sum kernel takes 4 sources: fold the type row into the pano mean
+                pm = pm + self.type_embedding.weight.to(pm.dtype)
+                srcs = [srcs[0], srcs[1], srcs[3]]
+            srcs.append((pm, "dense", None))
         return F.dropout(ops.sum_layer_norm(srcs, g, b, B, dt, HID_EPS), self.p_drop, self.training)
 
 
