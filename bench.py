@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--freeze", default="none", choices=["none", "shipped"])
     ap.add_argument("--time-batched", action="store_true",
                     help="HAMT: run the T teacher-forced steps as one [T*B] batch (same results, SURVEY 8f rank 1)")
+    ap.add_argument("--no-time-batched-extra", action="store_true")
     ap.add_argument("--model", default="hamt", choices=["hamt", "duet"],
                     help="hamt = BASELINE.json configs[1] (the metric's config); duet = configs[3] (batch 32)")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -234,6 +235,38 @@ def main():
                 "step_algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
                 "step_frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / peak, 4)}
 
+    tb = None
+    if args.model == "hamt" and not args.time_batched and not args.no_time_batched_extra:
+        # extra, reported beside `value` (never instead of it): the same episodes with the T teacher-forced steps run as one
+        # [T*B] batch (identical logits/loss/gradients, tests/test_hamt_gpu.py)
+        from vln_imagine_amd.hamt.episode import run_episode_time_batched
+
+        def step_tb():
+            trainer.zero_grad()
+            out = run_episode_time_batched(model, et, criterion=ops.cross_entropy_sum)
+            out["loss"].backward()
+            trainer.allreduce_grads()
+            trainer.step()
+            return out["loss"]
+
+        for _ in range(max(2, args.warmup)):
+            step_tb()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_tb()
+        fence()
+        dtb = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dtb], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dtb = float(tt.item())
+        tb = {"value": round(args.batch * world / (dtb / args.steps), 2), "unit": "episodes/s",
+              "ms_per_step": round(dtb / args.steps * 1e3, 3),
+              "step_algorithmic_tflops": round(flops / (dtb / args.steps) / 1e12, 2),
+              "note": "T steps as one [T*B] batch under teacher forcing; same results as the step-by-step calls"}
+        log(f"time-batched extra: {tb['ms_per_step']} ms/step")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "hamt":
         cpu = cpu_baseline(cfg, args)
@@ -250,7 +283,7 @@ def main():
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "steps_per_sec": round(args.T * args.batch * world / (dt / args.steps), 1),
                        "loss": round(float(loss), 5)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "time_batched": tb,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
