@@ -139,6 +139,8 @@ def test_flat_trainer_direct_grads_match_autograd():
             assert d <= 2e-5 * max(1.0, ref_g[n].abs().max().item()), (n, d)
         tr.step()
         for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+            if ref_g[n].abs().max().item() < 1e-5:
+                continue            # ~zero gradient (e.g. the logit bias): Adam turns rounding noise into +-lr
             assert (p - q).abs().max().item() < 1e-4, n      # lr 1e-3: elements with ~0 gradient have a noisy Adam direction
     finally:
         ops.DIRECT_GRAD = ops.DEFER_WGRAD = False

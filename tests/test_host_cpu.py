@@ -159,3 +159,47 @@ def test_data_parallel_gradient_mean_gloo_world2(tmp_path):
     mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
     want = torch.arange(1000, dtype=torch.float32) * 1.5
     assert torch.equal(out[0], want) and torch.equal(out[1], want)
+
+
+def test_graph_map_shortest_paths_and_features():
+    """GraphMap: distances restricted to paths through visited nodes (brute-force check), path reconstruction, features."""
+    import itertools
+    from vln_imagine_amd.duet.models.graph_utils import GraphMap
+    rng = np.random.RandomState(0)
+    pos = {f"n{i}": tuple(rng.uniform(-5, 5, 3)) for i in range(9)}
+    adj = {"n0": ["n1", "n2"], "n1": ["n0", "n3", "n4"], "n3": ["n1", "n5", "n6"], "n5": ["n3", "n7", "n2"], "n2": ["n0", "n5", "n8"]}
+    g = GraphMap("n0")
+    order = ["n0", "n1", "n3", "n5", "n2"]
+    for vp in order:
+        g.update_graph({"viewpoint": vp, "position": pos[vp], "candidate": [{"viewpointId": c, "position": pos[c]} for c in adj[vp]]})
+    d = lambda a, b: float(np.linalg.norm(np.array(pos[a]) - np.array(pos[b])))
+    nodes = sorted(g.node_positions)
+    visited = set(order)
+    # brute force: shortest path whose INTERIOR nodes are all visited, edges = observed adjacency
+    edges = {}
+    for a, cs in adj.items():
+        for c in cs:
+            edges[(a, c)] = edges[(c, a)] = d(a, c)
+    def brute(x, y):
+        best = edges.get((x, y), float("inf"))
+        inner = [v for v in visited if v not in (x, y)]
+        for r in range(1, len(inner) + 1):
+            for perm in itertools.permutations(inner, r):
+                p = (x,) + perm + (y,)
+                if all((p[i], p[i + 1]) in edges for i in range(len(p) - 1)):
+                    best = min(best, sum(edges[(p[i], p[i + 1])] for i in range(len(p) - 1)))
+        return best
+    for x in visited:
+        for y in nodes:
+            if x != y:
+                want = brute(x, y)
+                assert abs(g.graph.distance(x, y) - want) < 1e-9, (x, y)
+                path = g.graph.path(x, y)
+                assert path[-1] == y and abs(sum(edges[(a, b)] for a, b in zip([x] + path[:-1], path)) - want) < 1e-9
+    assert g.graph.visited("n3") and not g.graph.visited("n7")
+    f = g.get_pos_fts("n5", [None, "n0", "n7"], 0.3, -0.1)
+    assert f.shape == (3, 7) and float(np.abs(f[0]).sum()) == 2.0          # STOP row: sin 0, cos 0 -> (0,1,0,1,0,0,0)
+    assert abs(f[2, 4] - d("n5", "n7") / 30) < 1e-6 and abs(f[1, 6] - len(g.graph.path("n5", "n0")) / 10) < 1e-6
+    e = torch.ones(4, requires_grad=True)
+    g.update_node_embed("n7", e * 2); g.update_node_embed("n7", e * 4)
+    assert torch.allclose(g.get_node_embed("n7"), torch.full((4,), 3.0)) and g.get_node_embed("n7").requires_grad

@@ -152,6 +152,28 @@ def test_attention_fwd_bwd(ops, dtype, B, Sq, Sk, use_bias):
         assert _err(dbias, br.grad) < t * 5, ("dbias", _err(dbias, br.grad))
 
 
+@pytest.mark.parametrize("B,Sq,Sk", [(2, 45, 150), (2, 70, 200), (1, 130, 256), (2, 37, 129)])
+def test_attention_long_context_bf16(ops, B, Sq, Sk):
+    """129..256 keys (long DUET instructions + imaginations): bf16 kernels, 8-wave backward."""
+    H, dtype = 768, torch.bfloat16
+    qt, kt = _rand((B * Sq, H), dtype, 21, 0.7), _rand((B * Sk, 2 * H), dtype, 22, 0.7)
+    lens = torch.tensor([Sk] + [Sk - 37] * (B - 1))
+    kmask = ((torch.arange(Sk)[None, :] >= lens[:, None]).float() * -10000.0).cuda()
+    k, v = kt[:, :H], kt[:, H:]
+    out, lse = ops.attn_fwd(qt, k, v, B, Sq, Sk, kmask)
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (qt, k, v))
+    ref = _attn_ref(qr, kr, vr, kmask, None, B, Sq, Sk)
+    assert _err(out, ref) < 3e-2, _err(out, ref)
+    dout = _rand((B * Sq, H), dtype, 23)
+    ref.backward(dout.double())
+    dq, dkv = torch.zeros_like(qt), torch.zeros_like(kt)
+    ops.attn_bwd(qt, k, v, out, dout, lse, dq, dkv[:, :H], dkv[:, H:], B, Sq, Sk, kmask)
+    for a, r, n in ((dq, qr.grad, "dq"), (dkv[:, :H], kr.grad, "dk"), (dkv[:, H:], vr.grad, "dv")):
+        assert _err(a, r) < 6e-2, (n, _err(a, r))
+    with pytest.raises(Exception, match="not covered"):
+        ops.attn_fwd(qt.float(), k.float(), v.float(), B, Sq, Sk, kmask)      # fp32 parity path: <= 128 keys
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_blocks_against_torch(ops, dtype):
     """The fused sublayer nodes (self-att, FFN, x-att pair, x-att) fwd+bwd vs the same math in torch fp64."""

@@ -1,4 +1,4 @@
-// Fused masked multi-head attention, forward and backward, head dim 64, Sk <= 128 keys per call.
+// Fused masked multi-head attention, forward and backward, head dim 64; Sk <= 256 keys (bf16) / 128 (fp32 parity path).
 //   forward : O = softmax(Q K^T * scale + kmask[b,key] + bias[b,q,key]) V,  LSE saved
 //   backward: dQ, dK, dV (and dbias) by recomputing P from LSE (no S x S tensor ever reaches HBM)
 // restating BertSelfAttention / BertOutAttention
@@ -425,9 +425,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
   if (p.lse && hh == 0 && qg < p.Sq) p.lse[((long)b * p.nh + hd) * p.Sq + qg] = m + __logf(l);
 }
 
-// backward: block = 4 waves; wave w owns key tile w; grid = B*nh; query rows in chunks of 64
-template <int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(AttnP p) {
+// backward: block = NW waves (4, or 8 for 129..256 keys); wave w owns key tile w; grid = B*nh; query rows in chunks of 64
+template <int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(AttnP p) {
+  constexpr int NTH = NW * 64;
   constexpr int SKP = NKT * 32, DSS = SKP * 2 + 16;       // dS row stride in bytes (odd number of 16-B slots)
   __shared__ __attribute__((aligned(16))) char smem[2 * SKP * 128 + 2 * 64 * 128 + 64 * DSS + 2 * 64 * 4];
   char* Ks = smem;
@@ -440,8 +441,8 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(AttnP p) {
   const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1, half8 = 8 * (pp & 1);
-  stage_bf16(Ks, (const __bf16*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, 256);
-  stage_bf16(Vs, (const __bf16*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, 256);
+  stage_bf16(Ks, (const __bf16*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, NTH);
+  stage_bf16(Vs, (const __bf16*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, NTH);
   __syncthreads();
   const bool owner = wave < NKT;
   const int key = wave * 32 + r;
@@ -462,24 +463,25 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(AttnP p) {
 
   for (int q0 = 0; q0 < p.Sq; q0 += 64) {
     const int nq = min(64, p.Sq - q0);
-    stage_bf16(Qs, (const __bf16*)p.q + (long)b * p.Sq * p.ldq + hd * 64, p.ldq, q0, nq, 64, tid, 256);
-    stage_bf16(dOs, (const __bf16*)p.dout + (long)b * p.Sq * p.lddo + hd * 64, p.lddo, q0, nq, 64, tid, 256);
+    stage_bf16(Qs, (const __bf16*)p.q + (long)b * p.Sq * p.ldq + hd * 64, p.ldq, q0, nq, 64, tid, NTH);
+    stage_bf16(dOs, (const __bf16*)p.dout + (long)b * p.Sq * p.lddo + hd * 64, p.lddo, q0, nq, 64, tid, NTH);
     {
-      // delta[q] = <dO[q], O[q]>: 16 rows per wave, all loads issued before the first reduction
-      float dl[16];
+      // delta[q] = <dO[q], O[q]>: 64/NW rows per wave, all loads issued before the first reduction
+      constexpr int RPW = 64 / NW;
+      float dl[RPW];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = wave + 4 * i;
+      for (int i = 0; i < RPW; ++i) {
+        const int row = wave + NW * i;
         const long qrow = (long)b * p.Sq + q0 + min(row, nq - 1);
         dl[i] = (float)((const __bf16*)p.dout)[qrow * p.lddo + hd * 64 + lane] * (float)((const __bf16*)p.out)[qrow * p.ldo + hd * 64 + lane];
       }
-      const float lv = (lane < 16 && wave + 4 * lane < nq) ? p.lse[((long)b * p.nh + hd) * p.Sq + q0 + wave + 4 * lane] : 0.f;
+      const float lv = (lane < RPW && wave + NW * lane < nq) ? p.lse[((long)b * p.nh + hd) * p.Sq + q0 + wave + NW * lane] : 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < RPW; ++i) {
         const float t = wave_sum(dl[i]);
-        if (lane == 0) del_s[wave + 4 * i] = (wave + 4 * i < nq) ? t : 0.f;
+        if (lane == 0) del_s[wave + NW * i] = (wave + NW * i < nq) ? t : 0.f;
       }
-      if (lane < 16) lse_s[wave + 4 * lane] = lv;
+      if (lane < RPW) lse_s[wave + NW * lane] = lv;
     }
     __syncthreads();
 
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(AttnP p) {
       }
     }
     __syncthreads();
-    {
+    if (wave < 4) {
       const int qt = wave >> 1, dt = wave & 1;
       const int ch = dt * 4 + 2 * cb + (pp >> 1);
       f32x16 dq;
@@ -573,7 +575,8 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(AttnP p) {
 
 template <int NKT>
 int launch_bf16(const AttnP& p, bool bwd, hipStream_t st) {
-  if (bwd) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT>), dim3(p.B * p.nh), dim3(256), 0, st, p);
+  constexpr int NW = NKT <= 4 ? 4 : 8;
+  if (bwd) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, NW>), dim3(p.B * p.nh), dim3(NW * 64), 0, st, p);
   else hipLaunchKernelGGL((attn_fwd_bf16_kernel<NKT>), dim3(cdiv(p.Sq, 128), p.B * p.nh), dim3(256), 0, st, p);
   return 0;
 }
@@ -583,6 +586,8 @@ int dispatch_bf16(const AttnP& p, bool bwd, hipStream_t st) {
     case 2: return launch_bf16<2>(p, bwd, st);
     case 3: return launch_bf16<3>(p, bwd, st);
     case 4: return launch_bf16<4>(p, bwd, st);
+    case 5: case 6: return launch_bf16<6>(p, bwd, st);      // 129..192 keys (8 waves in the backward pass)
+    case 7: case 8: return launch_bf16<8>(p, bwd, st);      // 193..256 keys
   }
   return -1;
 }
@@ -625,7 +630,7 @@ int dispatch(const AttnP& p, bool bwd, hipStream_t st) {
 int check_common(const char* who, int dtype, const AttnP& p) {
   VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "%s: bad dtype %d", who, dtype);
   VLNI_CHECK(p.B > 0 && p.nh > 0 && p.Sq > 0 && p.Sk > 0, VLNI_EINVAL, "%s: empty problem", who);
-  VLNI_CHECK(p.Sk <= 128, VLNI_EUNSUP, "%s: Sk=%d > 128 keys not covered by this build", who, p.Sk);
+  VLNI_CHECK(p.Sk <= (dtype == VLNI_BF16 ? 256 : 128), VLNI_EUNSUP, "%s: Sk=%d keys not covered (bf16 <= 256, fp32 <= 128)", who, p.Sk);
   VLNI_CHECK(p.ldq % 4 == 0 && p.ldk % 4 == 0 && p.ldv % 4 == 0 && p.ldo % 4 == 0, VLNI_EINVAL,
              "%s: row strides must be multiples of 4 elements", who);
   VLNI_CHECK(p.ldq >= p.nh * 64 && p.ldk >= p.nh * 64 && p.ldv >= p.nh * 64 && p.ldo >= p.nh * 64, VLNI_EINVAL,
