@@ -1,0 +1,28 @@
+"""Micro-benchmark of the grouped transposing-read wgrad kernel: TF/s vs split for the episode-level shapes."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vln_imagine_amd import ops, _lib
+
+def t(fn, reps=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+st = torch.cuda.current_stream().cuda_stream
+for (N, K, M, nseg) in [(768, 768, 5504, 6), (2304, 768, 5504, 6), (3072, 768, 5504, 6), (768, 3072, 5504, 6), (768, 768, 2560, 6), (2304, 768, 7936, 6)]:
+    dys = [(torch.randn(M, N, device="cuda") * 0.1).bfloat16() for _ in range(nseg)]
+    xs = [(torch.randn(M, K, device="cuda") * 0.5).bfloat16() for _ in range(nseg)]
+    out = torch.zeros(N, K, device="cuda"); cs = torch.zeros(N, device="cuda")
+    pa = (ctypes.c_void_p * nseg)(*[d.data_ptr() for d in dys]); pb = (ctypes.c_void_p * nseg)(*[x.data_ptr() for x in xs])
+    pm = (ctypes.c_int * nseg)(*[M] * nseg)
+    fl = 2.0 * N * K * M * nseg
+    res = []
+    for split in (1, 2, 4, 8, 16, 32):
+        us = t(lambda: _lib.call("vlni_gemm_tn_bf16_grouped", nseg, pa, pb, pm, N, K, out.data_ptr(), K, N, K, (cs.data_ptr() if os.environ.get("CS", "1") == "1" else 0), split, st))
+        res.append(f"s{split}:{us:6.0f}us/{fl/us/1e6:4.0f}TF")
+    print(f"N={N:5d} K={K:5d} M={M}x{nseg}: " + "  ".join(res), flush=True)

@@ -411,13 +411,25 @@ __global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
-  const bool do_cs = p.colsum != nullptr && k0 == 0 && tid < BM;
-  float cs = 0.f;
+  // bias gradient (column sums of A) for the k-tile-0 blocks: accumulated from the staging REGISTERS (the 8 columns of
+  // this thread's chunk over its 4 rows per stage), so the MFMA loop sees no extra LDS traffic
+  const bool do_cs = p.colsum != nullptr && k0 == 0;
+  float csr[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) csr[e] = 0.f;
 
   if (mt0 < mt1) {
     gload(mt0);
     for (int mt = mt0; mt < mt1; ++mt) {
       lstore();
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16x8 v = __builtin_bit_cast(bf16x8, sa[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csr[e] += (float)v[e];
+        }
+      }
       __syncthreads();
       if (mt + 1 < mt1) gload(mt + 1);
 #pragma unroll
@@ -431,10 +443,6 @@ __global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-      }
-      if (do_cs) {
-#pragma unroll 8
-        for (int row = 0; row < BR; ++row) cs += (float)*(const __bf16*)(As + tr_off(row, tid >> 3) + (tid & 7) * 2);
       }
       __syncthreads();
     }
@@ -451,7 +459,17 @@ __global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
         if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
       }
   }
-  if (do_cs && n0 + tid < p.N) atomicAdd(p.colsum + n0 + tid, cs);
+  if (do_cs) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {                        // lanes l, l+16, l+32, l+48 hold the same chunk: fold them first
+      csr[e] += __shfl_xor(csr[e], 16, 64);
+      csr[e] += __shfl_xor(csr[e], 32, 64);
+    }
+    if (lane < 16 && a_ok) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(p.colsum + n0 + ch * 8 + e, csr[e]);
+    }
+  }
 }
 
 }  // namespace

@@ -117,7 +117,7 @@ def wgrad(dy, x, out=None, colsum_out=None, want_colsum=False):
         colsum_out = torch.zeros((N,), dtype=torch.float32, device=dev)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     if dy.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
-        split = max(1, min((M + 63) // 64, 8, round(512 / tiles)))
+        split = max(1, min(8, ((M + 63) // 64) // 8, round(768 / tiles)))
         _lib.call("vlni_gemm_tn_bf16", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
                   M, N, K, _p(colsum_out), split, _st())
     else:
@@ -349,7 +349,7 @@ def flush_wgrads():
             pm = (ctypes.c_int * n)(*[d.shape[0] for d, _ in chunk])
             tiles = ((N + 127) // 128) * ((K + 127) // 128)
             nmt = sum((d.shape[0] + 63) // 64 for d, _ in chunk)
-            split = max(1, min(nmt, 16, round(768 / tiles)))
+            split = max(1, min(8, nmt // 8))
             _lib.call("vlni_gemm_tn_bf16_grouped", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
                       split, _st())
     _WQ.clear()
