@@ -215,7 +215,7 @@ def main():
             e0.record()
             r = orig(a, b, *p, **k)
             e1.record()
-            rec.append((2.0 * a.shape[0] * b.shape[0] * a.shape[1], e0, e1))
+            rec.append((2.0 * a.shape[0] * b.shape[0] * a.shape[1], e0, e1, (a.shape[0], b.shape[0], a.shape[1])))
             return r
 
         ops.gemm_nt = timed
@@ -224,8 +224,15 @@ def main():
             torch.cuda.synchronize()
         finally:
             ops.gemm_nt = orig
-        tot_f = sum(f for f, _, _ in rec)
-        tot_ms = sum(e0.elapsed_time(e1) for _, e0, e1 in rec)
+        tot_f = sum(r[0] for r in rec)
+        tot_ms = sum(r[1].elapsed_time(r[2]) for r in rec)
+        if os.environ.get("VLNI_GEMM_BREAKDOWN"):
+            agg = {}
+            for f, e0, e1, shp in rec:
+                a_ = agg.setdefault(shp, [0, 0.0, 0.0])
+                a_[0] += 1; a_[1] += e0.elapsed_time(e1); a_[2] += f
+            for shp, (n, ms_, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+                log(f"gemm M={shp[0]:6d} N={shp[1]:5d} K={shp[2]:5d}: {n:4d} calls {ms_:7.2f} ms {f / ms_ / 1e9:7.1f} TF/s")
         ach = tot_f / (tot_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % ("__bf16" if args.dtype == "bf16" else "float"),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
