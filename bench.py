@@ -234,8 +234,16 @@ def main():
             for shp, (n, ms_, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
                 log(f"gemm M={shp[0]:6d} N={shp[1]:5d} K={shp[2]:5d}: {n:4d} calls {ms_:7.2f} ms {f / ms_ / 1e9:7.1f} TF/s")
         ach = tot_f / (tot_ms * 1e-3) / 1e12
+        traffic = None
+        try:      # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/); never live
+            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+            if pmc and args.dtype == "bf16":
+                traffic = round(json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["bytes_per_launch"])
+        except Exception:
+            traffic = None
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % ("__bf16" if args.dtype == "bf16" else "float"),
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": round(sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec) / len(rec)),
                 "launches_per_step": len(rec), "avg_launch_us": round(tot_ms * 1e3 / len(rec), 2),
                 "avg_gflop_per_launch": round(tot_f / len(rec) / 1e9, 3),
                 "gemm_share_of_step": round(tot_ms / ms, 3),
