@@ -128,10 +128,13 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # "nccl" IS RCCL on ROCm; VLNI_DIST_BACKEND=gloo + VLNI_ONE_GPU=1 rehearse the multi-rank path on a 1-GPU box
+        dist.init_process_group(os.environ.get("VLNI_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if os.environ.get("VLNI_ONE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -204,7 +207,7 @@ def main():
     peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:           # EVERY rank runs the instrumented step (it contains the gradient all-reduce)
         # instrumented pass: HIP events (torch.cuda.Event on the launch stream = torch's current stream) around
         # every vlni_gemm_nt launch of ONE more step; not part of the timed region above.
         rec = []
@@ -224,6 +227,7 @@ def main():
             torch.cuda.synchronize()
         finally:
             ops.gemm_nt = orig
+        log("instrumented roofline step done")
         tot_f = sum(r[0] for r in rec)
         tot_ms = sum(r[1].elapsed_time(r[2]) for r in rec)
         if os.environ.get("VLNI_GEMM_BREAKDOWN"):
