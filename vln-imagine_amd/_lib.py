@@ -77,8 +77,13 @@ def load():
     return lib
 
 
+_fn = {}
+
+
 def call(name, *args):
-    lib = load()
-    rc = getattr(lib, name)(*args)
+    f = _fn.get(name)
+    if f is None:
+        f = _fn[name] = getattr(load(), name)
+    rc = f(*args)
     if rc != 0:
-        raise VlniError(f"{name} failed ({rc}): {lib.vlni_last_error().decode()}")
+        raise VlniError(f"{name} failed ({rc}): {load().vlni_last_error().decode()}")

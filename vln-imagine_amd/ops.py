@@ -27,7 +27,13 @@ def _dt(t):
         raise TypeError(f"vlni ops take float32 or bfloat16 activations, got {t.dtype}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _st():
+    """hipStream_t of torch's current stream (the raw getter is ~20x cheaper than torch.cuda.current_stream())."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -243,11 +249,14 @@ class ShadowCache:
         self.epoch += 1
 
     def get(self, params, dtype, transposed=False):
-        key = (tuple(id(p) for p in params), dtype, transposed)
-        ver = (self.epoch,) + tuple(p._version for p in params) + tuple(p.data_ptr() for p in params)
+        key = (id(params[0]), len(params), dtype, transposed)
         hit = self._c.get(key)
-        if hit is not None and hit[0] == ver:
-            return hit[1]
+        if hit is not None:
+            ver = hit[0]
+            if ver[0] == self.epoch and ver[1] == params[0]._version and ver[2] == params[0].data_ptr() and \
+                    (len(params) == 1 or ver[3] == sum(p._version for p in params[1:])):
+                return hit[1]
+        ver = (self.epoch, params[0]._version, params[0].data_ptr(), sum(p._version for p in params[1:]))
         with torch.no_grad():
             for p in params:
                 _chk(p, "parameter")
