@@ -42,6 +42,13 @@ int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, 
                    float drop_p, unsigned drop_seed /* dropout after act, before residual; mask = f(seed, row*N+col) */,
                    void* stream);
 
+/* Two problems (same N, K, epilogue kind; arrays of 2) in ONE launch: the language / vision streams of a cross-modal layer. */
+int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* lda, const void* const* B, const long* ldb, void* const* C,
+                      const long* ldc, const int* M, int N, int K, const float* const* bias, int act,
+                      const void* const* residual, const long* ldr, void* const* preact, const long* ldp,
+                      const void* const* dact_src, const long* ldd, int dact, int variant, float drop_p,
+                      const unsigned* drop_seed, void* stream);
+
 /* Weight gradient without transposes: C[N,K] += A[M,N]^T B[M,K] (bf16 in, float32 atomics out, split over M rows);
  * colsum[N] (optional) += column sums of A = bias gradient. Autograd of nn.Linear (R:101-103,...). */
 int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,

@@ -117,3 +117,46 @@ def test_models_train_mode_runs_and_is_reproducible():
         assert losses[0] == losses[1], losses                 # same seeds -> same masks -> same loss
         m.eval()
         assert abs(run(m, et)["loss"].item() - losses[0]) > 1e-4      # dropout really was active in train mode
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_dual_stream_blocks_equal_two_single_blocks(train):
+    """The dual-problem launches (language + vision stream in one GEMM launch) reproduce the single-stream blocks
+    bit for bit in forward, and to rounding in backward (with the same dropout seeds in train mode)."""
+    from vln_imagine_amd import ops
+    torch.manual_seed(1)
+    B, S0, S1, H, FF = 3, 45, 20, 768, 3072
+    mk = lambda *s, sc=0.04: (torch.randn(*s) * sc).cuda().requires_grad_(True)
+    def att():
+        return [mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1),
+                (1 + 0.1 * torch.randn(H)).cuda().requires_grad_(True), (0.1 * torch.randn(H)).cuda().requires_grad_(True)]
+    def ffn():
+        return [mk(FF, H), mk(FF, sc=0.1), mk(H, FF, sc=0.02), mk(H, sc=0.1),
+                (1 + 0.1 * torch.randn(H)).cuda().requires_grad_(True), (0.1 * torch.randn(H)).cuda().requires_grad_(True)]
+    A0, A1, F0, F1 = att(), att(), ffn(), ffn()
+    params = A0 + A1 + F0 + F1
+    x0, x1 = torch.randn(B, S0, H).cuda(), torch.randn(B, S1, H).cuda()
+    m0, m1 = torch.zeros(B, S0).cuda(), torch.zeros(B, S1).cuda()
+    m0[:, -5:] = -10000.0
+    d0 = (0.1, 0.1, 4000) if train else ops.NO_DROP
+    d1 = (0.1, 0.1, 5000) if train else ops.NO_DROP
+    def single(a, b):
+        y0 = ops.ffn_block(ops.self_att_block(a, m0, tuple(A0), drop=d0), tuple(F0), drop=(0.0, d0[1], d0[2] + 7))
+        y1 = ops.ffn_block(ops.self_att_block(b, m1, tuple(A1), drop=d1), tuple(F1), drop=(0.0, d1[1], d1[2] + 7))
+        return y0, y1
+    def dual(a, b):
+        y0, y1 = ops.dual_self_att_block(a, b, m0, m1, tuple(A0), tuple(A1), drop0=d0, drop1=d1)
+        return ops.dual_ffn_block(y0, y1, tuple(F0), tuple(F1), drop0=(0.0, d0[1], d0[2] + 7), drop1=(0.0, d1[1], d1[2] + 7))
+    res = []
+    for fn in (single, dual):
+        a, b = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True)
+        for prm in params:
+            prm.grad = None
+        y0, y1 = fn(a, b)
+        (y0.sum() * 0.7 + (y1 * y1).sum()).backward()
+        res.append((y0.detach(), y1.detach(), a.grad.clone(), b.grad.clone(), [prm.grad.clone() for prm in params]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for i in (2, 3):
+        assert _err(res[0][i], res[1][i]) < 1e-5
+    for g0, g1 in zip(res[0][4], res[1][4]):
+        assert _err(g0, g1) < 1e-4 * max(1.0, g0.abs().max().item())

@@ -39,7 +39,29 @@ struct GemmP {
   int atomic_f32;               // C is float, accumulate with atomics (split-K wgrad)
   int kt_per_split;
   int vec_ok;                   // every epilogue tensor allows 4-element vector accesses
+  // optional SECOND problem with the same N, K and epilogue kind (the language / vision streams of a cross-modal
+  // layer): tiles [0, tiles0) belong to problem 0, the rest to problem 1 -> one launch fills the chip instead of two tails
+  int tiles0;
+  const char* A1; long lda1;
+  const char* B1; long ldb1;
+  char* C1; long ldc1;
+  int M1;
+  const float* bias1;
+  const char* residual1; long ldr1;
+  char* preact1; long ldp1;
+  const char* dact_src1; long ldd1;
+  unsigned drop_seed1;
 };
+
+// tile -> (problem, tile inside the problem); rewrites the by-value parameter block for problem 1 (block-uniform)
+__device__ __forceinline__ void select_problem(GemmP& p, int& wgid) {
+  if (wgid >= p.tiles0) {
+    wgid -= p.tiles0;
+    p.A = p.A1; p.lda = p.lda1; p.B = p.B1; p.ldb = p.ldb1; p.C = p.C1; p.ldc = p.ldc1; p.M = p.M1;
+    p.bias = p.bias1; p.residual = p.residual1; p.ldr = p.ldr1; p.preact = p.preact1; p.ldp = p.ldp1;
+    p.dact_src = p.dact_src1; p.ldd = p.ldd1; p.drop_seed = p.drop_seed1;
+  }
+}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -186,7 +208,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
   // ---- tile assignment: contiguous chunk of the tile list per XCD (bijective for any grid) ----
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-  const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  select_problem(p, wgid);
   const int ntn = (p.N + BN - 1) / BN;
   const int m0 = (wgid / ntn) * BM, n0 = (wgid % ntn) * BN;
 
@@ -262,7 +285,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_glds_kernel(GemmP p) {
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   const int nwg = gridDim.x, bid = blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-  const int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  select_problem(p, wgid);
   const int ntn = (p.N + BN - 1) / BN;
   const int m0 = (wgid / ntn) * BM, n0 = (wgid % ntn) * BN;
   constexpr int BK = ROWB / ES;
@@ -474,45 +498,31 @@ __global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
 
 }  // namespace
 
-// variant: 0 = choose by shape, 1 = register-staged 32-KiB kernel (4 blocks/CU), 2 = LDS-DMA 2-stage (64 KiB),
-// 3 = LDS-DMA 3-stage (96 KiB). All variants compute the same result; the host side may time them once per shape.
-extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
-                              int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
-                              const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,
-                              int variant, float drop_p, unsigned drop_seed, void* stream) {
-  VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt: bad dtype %d", dtype);
+static int gemm_check_one(int es, const void* A, long lda, const void* B, long ldb, long ldc, int M, int N, int K) {
+  const int epc = 16 / es;
   VLNI_CHECK(M > 0 && N > 0 && K > 0, VLNI_EINVAL, "gemm_nt: empty problem %d %d %d", M, N, K);
-  const int es = dtype == VLNI_F32 ? 4 : 2, epc = 16 / es, bk = ROWB / es;
   VLNI_CHECK(K % epc == 0 && lda % epc == 0 && ldb % epc == 0, VLNI_EINVAL,
              "gemm_nt: K/lda/ldb (%d/%ld/%ld) must be multiples of %d", K, lda, ldb, epc);
   VLNI_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, VLNI_EINVAL, "gemm_nt: A/B must be 16-B aligned");
   VLNI_CHECK(lda >= K && ldb >= K && ldc >= N, VLNI_EINVAL, "gemm_nt: leading dims too small");
-  VLNI_CHECK(!(atomic_f32 && (bias || act || residual || preact || dact)), VLNI_EINVAL, "gemm_nt: atomic output takes no epilogue");
-  VLNI_CHECK(split_k >= 1 && (split_k == 1 || atomic_f32), VLNI_EINVAL, "gemm_nt: split_k needs atomic_f32");
-  GemmP p;
-  p.A = (const char*)A; p.lda = lda; p.B = (const char*)B; p.ldb = ldb; p.C = (char*)C; p.ldc = ldc;
-  p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.residual = (const char*)residual; p.ldr = ldr;
-  p.preact = (char*)preact; p.ldp = ldp; p.dact_src = (const char*)dact_src; p.ldd = ldd; p.dact = dact;
-  p.alpha = alpha; p.atomic_f32 = atomic_f32;
-  VLNI_CHECK(drop_p >= 0.f && drop_p < 1.f && !(atomic_f32 && drop_p > 0.f), VLNI_EINVAL, "gemm_nt: dropout p=%f", drop_p);
-  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p);
-  {
-    const uintptr_t am = (uintptr_t)(4 * es - 1);     // 4 elements: 16 B (f32) / 8 B (bf16)
-    auto okp = [&](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & am) == 0 && ld % 4 == 0); };
-    p.vec_ok = (N % 4 == 0) && okp(C, ldc) && okp(residual, ldr) && okp(preact, ldp) && okp(dact_src, ldd) &&
-               (bias == nullptr || (((uintptr_t)bias) & 15) == 0);
-  }
-  const int nkt = cdiv(K, bk);
+  return VLNI_OK;
+}
+
+static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stream) {
+  const int es = dtype == VLNI_F32 ? 4 : 2, bk = ROWB / es;
+  const int nkt = cdiv(p.K, bk);
   p.kt_per_split = cdiv(nkt, split_k);
   const int splits = cdiv(nkt, p.kt_per_split);
-  dim3 grid(cdiv(M, BM) * cdiv(N, BN), 1, splits);
+  const int ntn = cdiv(p.N, BN);
+  p.tiles0 = cdiv(p.M, BM) * ntn;
+  const int tiles = p.tiles0 + (p.A1 ? cdiv(p.M1, BM) * ntn : 0);
+  dim3 grid(tiles, 1, splits);
   static const bool no_glds = getenv("VLNI_NO_GLDS") != nullptr;
-  // the 96-KiB deep-pipeline kernel runs ONE block per CU: it wins when the launch cannot fill the chip anyway
-  // (<= 256 tiles: latency-bound k-loop), the 32-KiB kernel (4 blocks/CU) wins when blocks can cover each other
-  const bool glds_ok = !no_glds && (K % bk == 0) && p.kt_per_split >= 3;
+  const bool glds_ok = !no_glds && (p.K % bk == 0) && p.kt_per_split >= 3;
   if (variant == 0) variant = (glds_ok && (long)grid.x * grid.z <= 256) ? 3 : 1;
   if (!glds_ok) variant = 1;
   const bool deep = variant == 3;
+  hipStream_t st = (hipStream_t)stream;
   if (variant >= 2) {
     constexpr int ST = (BM + BN) * ROWB;
     static bool attr = false;
@@ -523,7 +533,6 @@ extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B,
       hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<__bf16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
       attr = true;
     }
-    hipStream_t st = (hipStream_t)stream;
     if (deep) {
       if (dtype == VLNI_F32) hipLaunchKernelGGL((gemm_nt_glds_kernel<float, 3>), grid, dim3(NT), 3 * ST, st, p);
       else hipLaunchKernelGGL((gemm_nt_glds_kernel<__bf16, 3>), grid, dim3(NT), 3 * ST, st, p);
@@ -532,12 +541,76 @@ extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B,
       else hipLaunchKernelGGL((gemm_nt_glds_kernel<__bf16, 2>), grid, dim3(NT), 2 * ST, st, p);
     }
   } else if (dtype == VLNI_F32) {
-    hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(NT), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(NT), 0, st, p);
   } else {
-    hipLaunchKernelGGL(gemm_nt_kernel<__bf16>, grid, dim3(NT), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(gemm_nt_kernel<__bf16>, grid, dim3(NT), 0, st, p);
   }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
+}
+
+static bool gemm_vec_ok(int es, int N, const void* C, long ldc, const void* residual, long ldr, const void* preact, long ldp,
+                        const void* dact_src, long ldd, const float* bias) {
+  const uintptr_t am = (uintptr_t)(4 * es - 1);     // 4 elements: 16 B (f32) / 8 B (bf16)
+  auto okp = [&](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & am) == 0 && ld % 4 == 0); };
+  return (N % 4 == 0) && okp(C, ldc) && okp(residual, ldr) && okp(preact, ldp) && okp(dact_src, ldd) &&
+         (bias == nullptr || (((uintptr_t)bias) & 15) == 0);
+}
+
+// variant: 0 = choose by shape, 1 = register-staged 32-KiB kernel (4 blocks/CU), 2 = LDS-DMA 2-stage (64 KiB),
+// 3 = LDS-DMA 3-stage (96 KiB). All variants compute the same result; the host side may time them once per shape.
+extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
+                              int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
+                              const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,
+                              int variant, float drop_p, unsigned drop_seed, void* stream) {
+  VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt: bad dtype %d", dtype);
+  const int es = dtype == VLNI_F32 ? 4 : 2;
+  int rc = gemm_check_one(es, A, lda, B, ldb, ldc, M, N, K);
+  if (rc) return rc;
+  VLNI_CHECK(!(atomic_f32 && (bias || act || residual || preact || dact)), VLNI_EINVAL, "gemm_nt: atomic output takes no epilogue");
+  VLNI_CHECK(split_k >= 1 && (split_k == 1 || atomic_f32), VLNI_EINVAL, "gemm_nt: split_k needs atomic_f32");
+  VLNI_CHECK(drop_p >= 0.f && drop_p < 1.f && !(atomic_f32 && drop_p > 0.f), VLNI_EINVAL, "gemm_nt: dropout p=%f", drop_p);
+  GemmP p = {};
+  p.A = (const char*)A; p.lda = lda; p.B = (const char*)B; p.ldb = ldb; p.C = (char*)C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.residual = (const char*)residual; p.ldr = ldr;
+  p.preact = (char*)preact; p.ldp = ldp; p.dact_src = (const char*)dact_src; p.ldd = ldd; p.dact = dact;
+  p.alpha = alpha; p.atomic_f32 = atomic_f32;
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p);
+  p.vec_ok = gemm_vec_ok(es, N, C, ldc, residual, ldr, preact, ldp, dact_src, ldd, bias);
+  return gemm_launch(dtype, p, split_k, variant, stream);
+}
+
+// Two problems of the same N, K and epilogue kind in ONE launch (arrays of 2: operands, rows, bias, residual, preact,
+// dact_src, dropout seed). The language and vision streams of a cross-modal layer never fill 256 CUs on their own.
+extern "C" int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* lda, const void* const* B, const long* ldb,
+                                 void* const* C, const long* ldc, const int* M, int N, int K, const float* const* bias, int act,
+                                 const void* const* residual, const long* ldr, void* const* preact, const long* ldp,
+                                 const void* const* dact_src, const long* ldd, int dact, int variant, float drop_p,
+                                 const unsigned* drop_seed, void* stream) {
+  VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt_dual: bad dtype %d", dtype);
+  const int es = dtype == VLNI_F32 ? 4 : 2;
+  for (int i = 0; i < 2; ++i) {
+    int rc = gemm_check_one(es, A[i], lda[i], B[i], ldb[i], ldc[i], M[i], N, K);
+    if (rc) return rc;
+  }
+  VLNI_CHECK(drop_p >= 0.f && drop_p < 1.f, VLNI_EINVAL, "gemm_nt_dual: dropout p=%f", drop_p);
+  auto at = [](const void* const* arr, int i) -> const void* { return arr ? arr[i] : nullptr; };
+  auto al = [](const long* arr, int i) -> long { return arr ? arr[i] : 0; };
+  GemmP p = {};
+  p.A = (const char*)A[0]; p.lda = lda[0]; p.B = (const char*)B[0]; p.ldb = ldb[0]; p.C = (char*)C[0]; p.ldc = ldc[0];
+  p.M = M[0]; p.N = N; p.K = K; p.bias = bias ? bias[0] : nullptr; p.act = act;
+  p.residual = (const char*)at(residual, 0); p.ldr = al(ldr, 0);
+  p.preact = (char*)at((const void* const*)preact, 0); p.ldp = al(ldp, 0);
+  p.dact_src = (const char*)at(dact_src, 0); p.ldd = al(ldd, 0); p.dact = dact; p.alpha = 1.f; p.atomic_f32 = 0;
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed ? drop_seed[0] : 0; p.drop_inv = 1.0f / (1.0f - drop_p);
+  p.A1 = (const char*)A[1]; p.lda1 = lda[1]; p.B1 = (const char*)B[1]; p.ldb1 = ldb[1]; p.C1 = (char*)C[1]; p.ldc1 = ldc[1];
+  p.M1 = M[1]; p.bias1 = bias ? bias[1] : nullptr;
+  p.residual1 = (const char*)at(residual, 1); p.ldr1 = al(ldr, 1);
+  p.preact1 = (char*)at((const void* const*)preact, 1); p.ldp1 = al(ldp, 1);
+  p.dact_src1 = (const char*)at(dact_src, 1); p.ldd1 = al(ldd, 1); p.drop_seed1 = drop_seed ? drop_seed[1] : 0;
+  p.vec_ok = gemm_vec_ok(es, N, p.C, p.ldc, p.residual, p.ldr, p.preact, p.ldp, p.dact_src, p.ldd, p.bias) &&
+             gemm_vec_ok(es, N, p.C1, p.ldc1, p.residual1, p.ldr1, p.preact1, p.ldp1, p.dact_src1, p.ldd1, p.bias1);
+  return gemm_launch(dtype, p, 1, variant, stream);
 }
 
 extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,

@@ -125,17 +125,6 @@ class BertEncoder(nn.Module):
         return x
 
 
-TWO_STREAMS = os.environ.get("VLNI_TWO_STREAMS", "0") == "1"
-_SIDE = {}
-
-
-def _side_stream(device):
-    st = _SIDE.get(device)
-    if st is None:
-        st = _SIDE[device] = torch.cuda.Stream(device=device)
-    return st
-
-
 class LXRTXLayer(nn.Module):
     """Cross-modal layer (reference vilmodel_cmt.py:366-445): bidirectional cross-attention with shared
     weights on pre-update inputs, then per-stream self-attention and FFN: 5 fused nodes instead of ~45 kernels.
@@ -158,23 +147,13 @@ class LXRTXLayer(nn.Module):
             visn = ops.xatt_block(visn, lang, lang_mask, _att(xa), drop=_drop(xa))
         else:
             lang, visn = ops.xatt_pair_block(lang, visn, lang_mask, visn_mask, _att(xa), drop=_drop(xa))
-            if TWO_STREAMS and lang.is_cuda:
-                # the language and vision streams are independent until the next layer's cross-attention: run the
-                # (smaller) vision self-attention + FFN on a side HIP stream so its under-filled launches share the
-                # chip with the language ones; autograd replays each node on its forward stream, so backward overlaps too
-                main, side = torch.cuda.current_stream(), _side_stream(lang.device)
-                side.wait_stream(main)
-                visn.record_stream(side)
-                with torch.cuda.stream(side):
-                    visn = ops.ffn_block(self.visn_self_att(visn, visn_mask), _ffn(self.visn_inter, self.visn_output),
-                                         drop=_drop(self.visn_output))
-                lang = ops.ffn_block(self.lang_self_att(lang, lang_mask), _ffn(self.lang_inter, self.lang_output),
-                                     drop=_drop(self.lang_output))
-                main.wait_stream(side)
-                visn.record_stream(main)
-                return lang, visn
-            lang = ops.ffn_block(self.lang_self_att(lang, lang_mask), _ffn(self.lang_inter, self.lang_output),
-                                 drop=_drop(self.lang_output))
+            # language and vision streams are independent until the next layer: their self-attention and FFN blocks
+            # run as dual-problem launches (one GEMM launch covers both streams)
+            lang, visn = ops.dual_self_att_block(lang, visn, lang_mask, visn_mask, _att(self.lang_self_att),
+                                                 _att(self.visn_self_att), drop0=_drop(self.lang_self_att),
+                                                 drop1=_drop(self.visn_self_att))
+            return ops.dual_ffn_block(lang, visn, _ffn(self.lang_inter, self.lang_output), _ffn(self.visn_inter, self.visn_output),
+                                      drop0=_drop(self.lang_output), drop1=_drop(self.visn_output))
         visn = ops.ffn_block(self.visn_self_att(visn, visn_mask), _ffn(self.visn_inter, self.visn_output),
                              drop=_drop(self.visn_output))
         return lang, visn

@@ -101,6 +101,48 @@ def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_s
     return out
 
 
+def _arr(ctype, vals):
+    return (ctype * 2)(*vals)
+
+
+def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None, None), dact_src=(None, None), dact=0,
+             drop=None):
+    """Two GEMMs with the same (N, K) and epilogue kind in ONE launch: out_i = epi(a_i @ b_i^T), i = 0, 1.
+    drop = (p, (seed0, seed1)). Returns (out0, out1)."""
+    (a0, a1), (b0, b1) = a, b
+    M0, K = a0.shape
+    M1 = a1.shape[0]
+    N = b0.shape[0]
+    assert b1.shape == b0.shape and a1.shape[1] == K and a0.dtype == a1.dtype == b0.dtype == b1.dtype
+    outs = (torch.empty((M0, N), dtype=a0.dtype, device=a0.device), torch.empty((M1, N), dtype=a0.dtype, device=a0.device))
+    vp, lg = ctypes.c_void_p, ctypes.c_long
+    ptr2 = lambda ts: _arr(vp, [_p(t) for t in ts])
+    ld2 = lambda ts: _arr(lg, [t.stride(0) if t is not None else 0 for t in ts])
+    if drop is not None and drop[0] <= 0.0:
+        drop = None
+    seeds = _arr(ctypes.c_uint, drop[1] if drop else (0, 0))
+    cargs = (_dt(a0), ptr2(a), ld2(a), ptr2(b), ld2(b), ptr2(outs), ld2(outs), _arr(ctypes.c_int, (M0, M1)), N, K,
+             ptr2(bias), act, ptr2(residual), ld2(residual), ptr2(preact), ld2(preact), ptr2(dact_src), ld2(dact_src), dact)
+    variant = 0
+    if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+        key = (a0.dtype, M0, M1, N, K, act, dact, residual[0] is not None, preact[0] is not None)
+        variant = _GEMM_BEST.get(key)
+        if variant is None:
+            best = (float("inf"), 0)
+            for v in (1, 2, 3):
+                _lib.call("vlni_gemm_nt_dual", *cargs, v, drop[0] if drop else 0.0, seeds, _st())
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.call("vlni_gemm_nt_dual", *cargs, v, drop[0] if drop else 0.0, seeds, _st())
+                _lib.call("vlni_gemm_nt_dual", *cargs, v, drop[0] if drop else 0.0, seeds, _st())
+                e1.record()
+                e1.synchronize()
+                best = min(best, (e0.elapsed_time(e1), v))
+            variant = _GEMM_BEST[key] = best[1]
+    _lib.call("vlni_gemm_nt_dual", *cargs, variant, drop[0] if drop else 0.0, seeds, _st())
+    return outs
+
+
 def transpose_pad(x, rpad, dtype=None):
     """[R,C] -> [C,rpad] (zero-padded columns R..rpad), optional dtype change."""
     R, C = x.shape
@@ -494,12 +536,10 @@ class _XAttPairBlock(torch.autograd.Function):
         l2, v2 = _rows(_chk(lang, "lang")), _rows(_chk(visn, "visn"))
         dt = lang.dtype
         wqkv, bqkv, wo_c = _w((wq, wk, wv), dt), _w((bq, bk, bv), torch.float32), _w((wo,), dt)
-        ql = gemm_nt(l2, wqkv, bias=bqkv)
-        qv = gemm_nt(v2, wqkv, bias=bqkv)
+        ql, qv = gemm_nt2((l2, v2), (wqkv, wqkv), bias=(bqkv, bqkv))
         cl, lse_l = attn_fwd(ql[:, :H], qv[:, H:2 * H], qv[:, 2 * H:], B, Sl, Sv, mask_v, drop=(pa, sd))
         cv, lse_v = attn_fwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], B, Sv, Sl, mask_l, drop=(pa, sd + 1))
-        pre_l = gemm_nt(cl, wo_c, bias=bo, residual=l2, drop=(ph, sd + 2))
-        pre_v = gemm_nt(cv, wo_c, bias=bo, residual=v2, drop=(ph, sd + 3))
+        pre_l, pre_v = gemm_nt2((cl, cv), (wo_c, wo_c), bias=(bo, bo), residual=(l2, v2), drop=(ph, (sd + 2, sd + 3)))
         yl, mean_l, rstd_l = ln_fwd(pre_l, g, b, eps)
         yv, mean_v, rstd_v = ln_fwd(pre_v, g, b, eps)
         ctx.save_for_backward(l2, v2, ql, qv, cl, cv, lse_l, lse_v, pre_l, pre_v, mean_l, rstd_l, mean_v, rstd_v,
@@ -532,7 +572,7 @@ class _XAttPairBlock(torch.autograd.Function):
             dwo = wgrad(dmv, cv, wgrad(dml, cl))
             dbo = colsum(dmv, colsum(dml))
         wot = _w((wo,), dt, True)
-        dcl, dcv = gemm_nt(dml, wot), gemm_nt(dmv, wot)
+        dcl, dcv = gemm_nt2((dml, dmv), (wot, wot))
         dql, dqv = torch.empty_like(ql), torch.empty_like(qv)
         attn_bwd(ql[:, :H], qv[:, H:2 * H], qv[:, 2 * H:], cl, dcl, lse_l, dql[:, :H], dqv[:, H:2 * H], dqv[:, 2 * H:],
                  B, Sl, Sv, mask_v, drop=(pa, sd))
@@ -544,9 +584,110 @@ class _XAttPairBlock(torch.autograd.Function):
             dwq, dwk, dwv = _split_rows(wgrad(dqv, v2, wgrad(dql, l2)), (H, H, H))
             dbq, dbk, dbv = _split_rows(colsum(dqv, colsum(dql)), (H, H, H))
         wt = _w((wq, wk, wv), dt, True)
-        dl = gemm_nt(dql, wt, residual=dpl).view(B, Sl, H) if ng[0] else None
-        dv = gemm_nt(dqv, wt, residual=dpv).view(B, Sv, H) if ng[1] else None
+        dl, dv = gemm_nt2((dql, dqv), (wt, wt), residual=(dpl, dpv))
+        dl, dv = dl.view(B, Sl, H), dv.view(B, Sv, H)
         return dl, dv, None, None, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
+
+
+class _DualSelfAttBlock(torch.autograd.Function):
+    """Two independent BertAttention blocks (language and vision streams of an LXRT layer, vilmodel_cmt.py:399-407) whose
+    projections run as dual-problem GEMM launches: y_i = LN_i(dense_i(attn(x_i Wq_i, x_i Wk_i, x_i Wv_i)) + x_i)."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, km0, km1, eps, drop0, drop1, *P):
+        P0, P1 = P[:10], P[10:]
+        (B, S0, H), S1 = x0.shape, x1.shape[1]
+        a0, a1 = _rows(_chk(x0, "x0")), _rows(_chk(x1, "x1"))
+        dt = x0.dtype
+        wqkv = [_w((Pi[0], Pi[2], Pi[4]), dt) for Pi in (P0, P1)]
+        bqkv = [_w((Pi[1], Pi[3], Pi[5]), torch.float32) for Pi in (P0, P1)]
+        q0, q1 = gemm_nt2((a0, a1), wqkv, bias=bqkv)
+        c0, lse0 = attn_fwd(q0[:, :H], q0[:, H:2 * H], q0[:, 2 * H:], B, S0, S0, km0, drop=(drop0[0], drop0[2]))
+        c1, lse1 = attn_fwd(q1[:, :H], q1[:, H:2 * H], q1[:, 2 * H:], B, S1, S1, km1, drop=(drop1[0], drop1[2]))
+        ph = max(drop0[1], drop1[1])
+        pre0, pre1 = gemm_nt2((c0, c1), (_w((P0[6],), dt), _w((P1[6],), dt)), bias=(P0[7], P1[7]), residual=(a0, a1),
+                              drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
+        y0, m0, r0 = ln_fwd(pre0, P0[8], P0[9], eps)
+        y1, m1, r1 = ln_fwd(pre1, P1[8], P1[9], eps)
+        ctx.save_for_backward(a0, a1, q0, q1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, km0, km1)
+        ctx.P, ctx.dims, ctx.drop = (P0, P1), (B, S0, S1, H), (drop0, drop1, ph)
+        return y0.view(B, S0, H), y1.view(B, S1, H)
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        a0, a1, q0, q1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, km0, km1 = ctx.saved_tensors
+        P0, P1 = ctx.P
+        B, S0, S1, H = ctx.dims
+        drop0, drop1, ph = ctx.drop
+        dt = a0.dtype
+        ng = ctx.needs_input_grad
+        w0, w1 = any(ng[7:17]), any(ng[17:27])
+        dp0, dg0, db0, dm0 = _ln_bwd_to(_rows(dy0), pre0, P0[8], P0[9], m0, r0, w0, drop=(ph, drop0[2] + 1))
+        dp1, dg1, db1, dm1 = _ln_bwd_to(_rows(dy1), pre1, P1[8], P1[9], m1, r1, w1, drop=(ph, drop1[2] + 1))
+        g0, g1 = [None] * 8, [None] * 8
+        if w0:
+            (g0[6],), (g0[7],) = _wb_grad_to((P0[6],), (P0[7],), dm0, c0)
+        if w1:
+            (g1[6],), (g1[7],) = _wb_grad_to((P1[6],), (P1[7],), dm1, c1)
+        dc0, dc1 = gemm_nt2((dm0, dm1), (_w((P0[6],), dt, True), _w((P1[6],), dt, True)))
+        dq0, dq1 = torch.empty_like(q0), torch.empty_like(q1)
+        attn_bwd(q0[:, :H], q0[:, H:2 * H], q0[:, 2 * H:], c0, dc0, lse0, dq0[:, :H], dq0[:, H:2 * H], dq0[:, 2 * H:],
+                 B, S0, S0, km0, drop=(drop0[0], drop0[2]))
+        attn_bwd(q1[:, :H], q1[:, H:2 * H], q1[:, 2 * H:], c1, dc1, lse1, dq1[:, :H], dq1[:, H:2 * H], dq1[:, 2 * H:],
+                 B, S1, S1, km1, drop=(drop1[0], drop1[2]))
+        if w0:
+            (g0[0], g0[2], g0[4]), (g0[1], g0[3], g0[5]) = _wb_grad_to((P0[0], P0[2], P0[4]), (P0[1], P0[3], P0[5]), dq0, a0)
+        if w1:
+            (g1[0], g1[2], g1[4]), (g1[1], g1[3], g1[5]) = _wb_grad_to((P1[0], P1[2], P1[4]), (P1[1], P1[3], P1[5]), dq1, a1)
+        dx0, dx1 = gemm_nt2((dq0, dq1), (_w((P0[0], P0[2], P0[4]), dt, True), _w((P1[0], P1[2], P1[4]), dt, True)),
+                            residual=(dp0, dp1))
+        return (dx0.view(B, S0, H), dx1.view(B, S1, H), None, None, None, None, None) + tuple(g0) + (dg0, db0) + tuple(g1) + (dg1, db1)
+
+
+class _DualFfnBlock(torch.autograd.Function):
+    """Two independent FFN blocks (vilmodel_cmt.py:409-421) with dual-problem GEMM launches."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, eps, drop0, drop1, *P):
+        P0, P1 = P[:6], P[6:]
+        s0, s1 = x0.shape, x1.shape
+        a0, a1 = _rows(_chk(x0, "x0")), _rows(_chk(x1, "x1"))
+        dt = x0.dtype
+        FF = P0[0].shape[0]
+        z0 = torch.empty((a0.shape[0], FF), dtype=dt, device=x0.device)
+        z1 = torch.empty((a1.shape[0], FF), dtype=dt, device=x0.device)
+        h0, h1 = gemm_nt2((a0, a1), (_w((P0[0],), dt), _w((P1[0],), dt)), bias=(P0[1], P1[1]), act=1, preact=(z0, z1))
+        ph = max(drop0[1], drop1[1])
+        pre0, pre1 = gemm_nt2((h0, h1), (_w((P0[2],), dt), _w((P1[2],), dt)), bias=(P0[3], P1[3]), residual=(a0, a1),
+                              drop=(ph, (drop0[2], drop1[2])))
+        y0, m0, r0 = ln_fwd(pre0, P0[4], P0[5], eps)
+        y1, m1, r1 = ln_fwd(pre1, P1[4], P1[5], eps)
+        ctx.save_for_backward(a0, a1, z0, z1, h0, h1, pre0, pre1, m0, r0, m1, r1)
+        ctx.P, ctx.shp, ctx.drop = (P0, P1), (s0, s1), (drop0, drop1, ph)
+        return y0.view(s0), y1.view(s1)
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        a0, a1, z0, z1, h0, h1, pre0, pre1, m0, r0, m1, r1 = ctx.saved_tensors
+        P0, P1 = ctx.P
+        drop0, drop1, ph = ctx.drop
+        dt = a0.dtype
+        ng = ctx.needs_input_grad
+        w0, w1 = any(ng[5:11]), any(ng[11:17])
+        dp0, dg0, db0, dm0 = _ln_bwd_to(_rows(dy0), pre0, P0[4], P0[5], m0, r0, w0, drop=(ph, drop0[2]))
+        dp1, dg1, db1, dm1 = _ln_bwd_to(_rows(dy1), pre1, P1[4], P1[5], m1, r1, w1, drop=(ph, drop1[2]))
+        g0, g1 = [None] * 4, [None] * 4
+        if w0:
+            (g0[2],), (g0[3],) = _wb_grad_to((P0[2],), (P0[3],), dm0, h0)
+        if w1:
+            (g1[2],), (g1[3],) = _wb_grad_to((P1[2],), (P1[3],), dm1, h1)
+        dz0, dz1 = gemm_nt2((dm0, dm1), (_w((P0[2],), dt, True), _w((P1[2],), dt, True)), dact_src=(z0, z1), dact=1)
+        if w0:
+            (g0[0],), (g0[1],) = _wb_grad_to((P0[0],), (P0[1],), dz0, a0)
+        if w1:
+            (g1[0],), (g1[1],) = _wb_grad_to((P1[0],), (P1[1],), dz1, a1)
+        dx0, dx1 = gemm_nt2((dz0, dz1), (_w((P0[0],), dt, True), _w((P1[0],), dt, True)), residual=(dp0, dp1))
+        return (dx0.view(ctx.shp[0]), dx1.view(ctx.shp[1]), None, None, None) + tuple(g0) + (dg0, db0) + tuple(g1) + (dg1, db1)
 
 
 class _XAttBlock(torch.autograd.Function):
@@ -962,6 +1103,14 @@ def self_att_block(x, kmask, p, eps=1e-12, bias=None, drop=NO_DROP):
 
 def ffn_block(x, p, eps=1e-12, drop=NO_DROP):
     return _FfnBlock.apply(x, eps, drop, *p)
+
+
+def dual_self_att_block(x0, x1, km0, km1, p0, p1, eps=1e-12, drop0=NO_DROP, drop1=NO_DROP):
+    return _DualSelfAttBlock.apply(x0, x1, km0, km1, eps, drop0, drop1, *p0, *p1)
+
+
+def dual_ffn_block(x0, x1, p0, p1, eps=1e-12, drop0=NO_DROP, drop1=NO_DROP):
+    return _DualFfnBlock.apply(x0, x1, eps, drop0, drop1, *p0, *p1)
 
 
 def xatt_pair_block(lang, visn, mask_l, mask_v, p, eps=1e-12, drop=NO_DROP):
