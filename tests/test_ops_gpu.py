@@ -372,3 +372,19 @@ def test_wgrad_tn_bf16_exact_and_random(ops, M, N, K):
     out2, cs2 = ops.wgrad(dy, x, out=out, want_colsum=True)
     assert _err(out2, 2 * ref) < 4e-3 * max(1.0, ref.abs().max().item())
     assert _err(cs2, dy.double().sum(0)) < 2e-3 * max(1.0, dy.double().sum(0).abs().max().item())
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+def test_gemm_variants_identical(ops, variant):
+    """The five GEMM pipelines (register-staged, LDS-DMA 2/3-stage, 4 or 8 waves) give identical results, incl. epilogues and edges."""
+    from vln_imagine_amd import _lib
+    for dtype in (torch.bfloat16, torch.float32):
+        M, N, K = 333, 768, 768
+        a, b = _rand((M, K), dtype, 31, 0.5), _rand((N, K), dtype, 32, 0.05)
+        bias, res = _rand((N,), torch.float32, 33, 0.1), _rand((M, N), dtype, 34, 0.5)
+        outs = []
+        for v in (1, variant):
+            out, z = torch.empty((M, N), dtype=dtype, device="cuda"), torch.empty((M, N), dtype=dtype, device="cuda")
+            ops._gemm_call(v, a, b, out, bias, 1, res, z, None, 0, 1.0, 1, False, M, N, K)
+            outs.append((out, z))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (variant, dtype)

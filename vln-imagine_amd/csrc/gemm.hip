@@ -68,47 +68,50 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB +
 template <typename T> struct Mma;
 template <> struct Mma<__bf16> {
   static constexpr int KSTEPS = 4;   // 4 x k16 per 128-byte tile row
+  template <int NJ>
   __device__ static __forceinline__ void step(const char* As, const char* Bs, int kk, int rowA0, int rowB0, int r, int h,
-                                              f32x16 (&acc)[2][2]) {
+                                              f32x16 (&acc)[2][NJ]) {
     const int chunk = kk * 2 + h;
-    bf16x8 a[2], b[2];
+    bf16x8 a[2], b[NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)(As + lds_off(rowA0 + i * 32 + r, chunk));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = *(const bf16x8*)(Bs + lds_off(rowB0 + j * 32 + r, chunk));
+    for (int j = 0; j < NJ; ++j) b[j] = *(const bf16x8*)(Bs + lds_off(rowB0 + j * 32 + r, chunk));
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 };
 template <> struct Mma<float> {
   static constexpr int KSTEPS = 16;  // 16 x k2 per 128-byte tile row (BK = 32 floats)
+  template <int NJ>
   __device__ static __forceinline__ void step(const char* As, const char* Bs, int kk, int rowA0, int rowB0, int r, int h,
-                                              f32x16 (&acc)[2][2]) {
+                                              f32x16 (&acc)[2][NJ]) {
     const int k = kk * 2 + h;
     const int chunk = k >> 2, within = (k & 3) * 4;
-    float a[2], b[2];
+    float a[2], b[NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i) a[i] = *(const float*)(As + lds_off(rowA0 + i * 32 + r, chunk) + within);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b[j] = *(const float*)(Bs + lds_off(rowB0 + j * 32 + r, chunk) + within);
+    for (int j = 0; j < NJ; ++j) b[j] = *(const float*)(Bs + lds_off(rowB0 + j * 32 + r, chunk) + within);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
   }
 };
 
-template <typename T>
-__device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16 (&acc)[2][2], int m0, int n0, int tid, int wr,
-                                              int wc, int r, int h) {
+template <typename T, int NW>      // NW waves: 2 (M) x NW/2 (N); a wave owns 64 rows x (256/NW) columns
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16 (&acc)[2][NW == 4 ? 2 : 1], int m0, int n0,
+                                              int tid, int wr, int wc, int r, int h) {
+  constexpr int NJ = NW == 4 ? 2 : 1, WCOLS = 32 * NJ, RPP = NW * 2, NPASS = 64 / RPP;   // rows per read pass, passes per half
   // ---- split-K / wgrad: float32 atomics straight from the accumulators (128 contiguous bytes per half-wave) ----
   if (p.atomic_f32) {
     float* Cf = (float*)p.C;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = n0 + wc * 64 + j * 32 + r;
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wc * WCOLS + j * 32 + r;
       if (col >= p.N) continue;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -139,15 +142,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
           for (int x = 0; x < 16; ++x)
-            e[(i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h) * BN + wc * 64 + j * 32 + r] = acc[i][j][x];
+            e[(i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h) * BN + wc * WCOLS + j * 32 + r] = acc[i][j][x];
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int rl = (tid >> 5) + 8 * k;
+    for (int k = 0; k < NPASS; ++k) {
+      const int rl = (tid >> 5) + RPP * k;
       const int grow = m0 + half * 64 + rl;
       if (grow >= p.M || gcol >= p.N) continue;
       f32x4 v = *(const f32x4*)(e + rl * BN + c4);
@@ -263,12 +266,12 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
       __syncthreads();
       if (kt + 1 < kt1) gload(kt + 1);               // issue early: in flight under the MFMAs below
 #pragma unroll
-      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::step(As, Bs, kk, wr * 64, wc * 64, r, h, acc);
+      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::template step<2>(As, Bs, kk, wr * 64, wc * 64, r, h, acc);
       __syncthreads();                               // every wave done reading before the stage is rewritten
     }
   }
 
-  gemm_epilogue<T>(p, smem, acc, m0, n0, tid, wr, wc, r, h);
+  gemm_epilogue<T, 4>(p, smem, acc, m0, n0, tid, wr, wc, r, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -278,9 +281,10 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
 // __syncthreads(), which would drain the queue). The LDS image is lane-linear per wave-instruction (1 KiB = 8 rows
 // of 128 B), so the XOR swizzle is applied to the per-lane SOURCE chunk; reads use the same lds_off().
 // Used when K is a multiple of the k-tile and rows need no zero fill (M/N edges are clamped, never stored).
-template <typename T, int NST>     // NST stages = NST-1 k-tiles in flight (3: 96 KiB, 1 block/CU; 2: 64 KiB, 2 blocks/CU)
-__global__ __launch_bounds__(NT) void gemm_nt_glds_kernel(GemmP p) {
+template <typename T, int NST, int NW>     // NST stages = NST-1 k-tiles in flight (3: 96 KiB, 2: 64 KiB); NW = 4 or 8 waves
+__global__ __launch_bounds__(NW * 64) void gemm_nt_glds_kernel(GemmP p) {
   constexpr int ES = sizeof(T);
+  constexpr int WC = NW / 2, NJ = NW == 4 ? 2 : 1, WCOLS = 32 * NJ, IPW = 16 / NW;   // LDS-DMA instructions per operand per wave
   constexpr int STAGE = (BM + BN) * ROWB;
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -296,13 +300,13 @@ __global__ __launch_bounds__(NT) void gemm_nt_glds_kernel(GemmP p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  const int wr = wave / WC, wc = wave % WC, r = lane & 31, h = lane >> 5;
 
-  const char* ga[4];
-  const char* gb[4];
+  const char* ga[IPW];
+  const char* gb[IPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 4 + wave) * 8 + (lane >> 3);
+  for (int i = 0; i < IPW; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);                       // logical chunk this LDS slot must hold
     ga[i] = p.A + ((long)min(m0 + row, p.M - 1) * p.lda) * ES + c * 16 + (long)kt0 * ROWB;
     gb[i] = p.B + ((long)min(n0 + row, p.N - 1) * p.ldb) * ES + c * 16 + (long)kt0 * ROWB;
@@ -312,17 +316,17 @@ __global__ __launch_bounds__(NT) void gemm_nt_glds_kernel(GemmP p) {
   auto issue = [&](int t, int stage) {
     char* sa = dsmem + stage * STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr)(ga[i] + (long)t * ROWB), (lptr)(sa + i * 4096), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr)(gb[i] + (long)t * ROWB), (lptr)(sa + BM * ROWB + i * 4096), 16, 0, 0);
+    for (int i = 0; i < IPW; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr)(ga[i] + (long)t * ROWB), (lptr)(sa + i * NW * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)(gb[i] + (long)t * ROWB), (lptr)(sa + BM * ROWB + i * NW * 1024), 16, 0, 0);
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
 
@@ -331,18 +335,22 @@ __global__ __launch_bounds__(NT) void gemm_nt_glds_kernel(GemmP p) {
     if (NST == 3 && nk > 1) issue(1, 1);
     int stage = 0;
     for (int t = 0; t < nk; ++t) {
-      if (NST == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile t landed (this wave); t+1 may still fly
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (NST == 3 && t + 1 < nk) {                  // tile t landed (this wave's part); tile t+1 may still fly
+        if (NW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();                                       // every wave's part of tile t landed; stage (t-1)%NST is free
       if (t + NST - 1 < nk) issue(t + NST - 1, stage == 0 ? NST - 1 : stage - 1);   // (t+NST-1)%NST == (t-1)%NST
       const char* As = dsmem + stage * STAGE;
 #pragma unroll
-      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::step(As, As + BM * ROWB, kk, wr * 64, wc * 64, r, h, acc);
+      for (int kk = 0; kk < Mma<T>::KSTEPS; ++kk) Mma<T>::template step<NJ>(As, As + BM * ROWB, kk, wr * 64, wc * WCOLS, r, h, acc);
       stage = stage == NST - 1 ? 0 : stage + 1;
     }
   }
   __syncthreads();                                                        // all reads done before the epilogue reuses stage 0
-  gemm_epilogue<T>(p, dsmem, acc, m0, n0, tid, wr, wc, r, h);
+  gemm_epilogue<T, NW>(p, dsmem, acc, m0, n0, tid, wr, wc, r, h);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -521,25 +529,28 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
   const bool glds_ok = !no_glds && (p.K % bk == 0) && p.kt_per_split >= 3;
   if (variant == 0) variant = (glds_ok && (long)grid.x * grid.z <= 256) ? 3 : 1;
   if (!glds_ok) variant = 1;
-  const bool deep = variant == 3;
   hipStream_t st = (hipStream_t)stream;
   if (variant >= 2) {
     constexpr int ST = (BM + BN) * ROWB;
+    const bool deep = variant == 3 || variant == 4, wide = variant >= 4;
     static bool attr = false;
     if (!attr) {
-      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
-      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<__bf16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
-      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
-      hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<__bf16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
+#define VLNI_ATTR(TT, NS, W) hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<TT, NS, W>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * ST)
+      VLNI_ATTR(float, 3, 4); VLNI_ATTR(__bf16, 3, 4); VLNI_ATTR(float, 2, 4); VLNI_ATTR(__bf16, 2, 4);
+      VLNI_ATTR(float, 3, 8); VLNI_ATTR(__bf16, 3, 8); VLNI_ATTR(float, 2, 8); VLNI_ATTR(__bf16, 2, 8);
+#undef VLNI_ATTR
       attr = true;
     }
-    if (deep) {
-      if (dtype == VLNI_F32) hipLaunchKernelGGL((gemm_nt_glds_kernel<float, 3>), grid, dim3(NT), 3 * ST, st, p);
-      else hipLaunchKernelGGL((gemm_nt_glds_kernel<__bf16, 3>), grid, dim3(NT), 3 * ST, st, p);
-    } else {
-      if (dtype == VLNI_F32) hipLaunchKernelGGL((gemm_nt_glds_kernel<float, 2>), grid, dim3(NT), 2 * ST, st, p);
-      else hipLaunchKernelGGL((gemm_nt_glds_kernel<__bf16, 2>), grid, dim3(NT), 2 * ST, st, p);
-    }
+#define VLNI_GO(NS, W)                                                                                       \
+    do {                                                                                                     \
+      if (dtype == VLNI_F32) hipLaunchKernelGGL((gemm_nt_glds_kernel<float, NS, W>), grid, dim3(W * 64), NS * ST, st, p);  \
+      else hipLaunchKernelGGL((gemm_nt_glds_kernel<__bf16, NS, W>), grid, dim3(W * 64), NS * ST, st, p);       \
+    } while (0)
+    if (deep && !wide) VLNI_GO(3, 4);
+    else if (!deep && !wide) VLNI_GO(2, 4);
+    else if (deep) VLNI_GO(3, 8);
+    else VLNI_GO(2, 8);
+#undef VLNI_GO
   } else if (dtype == VLNI_F32) {
     hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, dim3(NT), 0, st, p);
   } else {
@@ -558,7 +569,7 @@ static bool gemm_vec_ok(int es, int N, const void* C, long ldc, const void* resi
 }
 
 // variant: 0 = choose by shape, 1 = register-staged 32-KiB kernel (4 blocks/CU), 2 = LDS-DMA 2-stage (64 KiB),
-// 3 = LDS-DMA 3-stage (96 KiB). All variants compute the same result; the host side may time them once per shape.
+// 3 = LDS-DMA 3-stage (96 KiB), 4 / 5 = the 3- / 2-stage kernels with 8 waves per tile (2 waves per SIMD). All variants compute the same result; the host side may time them once per shape.
 extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
                               int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
                               const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,

@@ -60,6 +60,7 @@ def _rows(t):
 # compute identical results; which is fastest depends on how the tile count fills 256 CUs. The first call of a shape
 # times each once with HIP events (a few hundred microseconds) and the winner is cached for the life of the process.
 AUTOTUNE = True
+GEMM_VARIANTS = (1, 2, 3, 4, 5)
 _GEMM_BEST = {}
 
 
@@ -88,7 +89,7 @@ def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_s
         variant = _GEMM_BEST.get(key)
         if variant is None:
             best = (float("inf"), 0)
-            for v in (1, 2, 3):
+            for v in GEMM_VARIANTS:
                 _gemm_call(v, *args)                                    # warm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -129,7 +130,7 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
         variant = _GEMM_BEST.get(key)
         if variant is None:
             best = (float("inf"), 0)
-            for v in (1, 2, 3):
+            for v in GEMM_VARIANTS:
                 _lib.call("vlni_gemm_nt_dual", *cargs, v, drop[0] if drop else 0.0, seeds, _st())
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
