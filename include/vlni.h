@@ -59,6 +59,10 @@ int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C
 int vlni_gemm_tn_bf16_grouped(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb, float* C,
                               long ldc, int N, int K, float* colsum, int split, void* stream);
 
+int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb, float* C,
+                                long ldc, int N, int K, float* colsum, int split, int variant /* 0/1 register-staged, 2..5 LDS-DMA */,
+                                void* stream);
+
 /* Fused masked attention, head dim 64, heads packed along the row (head h at column h*64), Sk <= 128.
  * kmask [B,Sk] additive float32 ((1-m)*-10000, R:1010-1012) or NULL; bias [B,Sq,Sk] additive float32
  * shared by all heads (graph_sprels, D:1145-1147) or NULL; lse [B,nh,Sq] float32.

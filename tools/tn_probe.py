@@ -22,7 +22,8 @@ for (N, K, M, nseg) in [(768, 768, 5504, 6), (2304, 768, 5504, 6), (3072, 768, 5
     pm = (ctypes.c_int * nseg)(*[M] * nseg)
     fl = 2.0 * N * K * M * nseg
     res = []
-    for split in (1, 2, 4, 8, 16, 32):
-        us = t(lambda: _lib.call("vlni_gemm_tn_bf16_grouped", nseg, pa, pb, pm, N, K, out.data_ptr(), K, N, K, (cs.data_ptr() if os.environ.get("CS", "1") == "1" else 0), split, st))
-        res.append(f"s{split}:{us:6.0f}us/{fl/us/1e6:4.0f}TF")
+    for variant in (0, 2, 3, 4, 5):
+        for split in (4, 8):
+            us = t(lambda: _lib.call("vlni_gemm_tn_bf16_grouped_v", nseg, pa, pb, pm, N, K, out.data_ptr(), K, N, K, cs.data_ptr(), split, variant, st))
+            res.append(f"v{variant}s{split}:{us:4.0f}us/{fl/us/1e6:3.0f}TF")
     print(f"N={N:5d} K={K:5d} M={M}x{nseg}: " + "  ".join(res), flush=True)

@@ -504,6 +504,139 @@ __global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same weight-gradient contraction with the LDS-DMA pipeline of gemm_nt_glds_kernel: row tiles go global -> LDS with
+// global_load_lds_dwordx4 (1 KiB = 4 rows of 256 B per wave-instruction, the image-(b) swizzle applied to the per-lane SOURCE
+// chunk), NST stages, NW = 4 or 8 waves. Rows past a segment's end and columns past N / K read a 256-byte page of zeros
+// (LDS-DMA cannot zero-fill). The bias gradient rides the matrix pipe: colsum(A) = A^T * 1, one extra MFMA per k-step with an
+// all-ones B fragment in the k-tile-0 blocks (no VALU / LDS work in the loop).
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+template <int NST, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_tn_glds_kernel(TnP p) {
+  constexpr int BR = 64, STAGE = 2 * BR * 256, WC = NW / 2, NJ = NW == 4 ? 2 : 1, WCOLS = 32 * NJ, IPW = 16 / NW;
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int ntk = (p.K + BN - 1) / BN;
+  const int n0 = (wgid / ntk) * BM, k0 = (wgid % ntk) * BN;
+  const int nmt = p.mt_start[p.nseg];
+  const int mt0 = blockIdx.z * p.mt_per_split;
+  const int nk = min(nmt, mt0 + p.mt_per_split) - mt0;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC, r = lane & 31, h = lane >> 5;
+
+  // per-lane source geometry of this wave's IPW LDS-DMA instructions per operand
+  int srow[IPW], acol[IPW], bcol[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int row = (i * NW + wave) * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));     // logical chunk this LDS slot must hold
+    srow[i] = row;
+    acol[i] = (n0 + c * 8 < p.N) ? n0 + c * 8 : -1;
+    bcol[i] = (k0 + c * 8 < p.K) ? k0 + c * 8 : -1;
+  }
+  using gptr = const __attribute__((address_space(1))) void*;
+  using lptr = __attribute__((address_space(3))) void*;
+  int seg = 0;
+  auto issue = [&](int t, int stage) {
+    const int mt = mt0 + t;
+    while (mt >= p.mt_start[seg + 1]) ++seg;                 // tiles are issued in increasing order
+    const int segM = p.segM[seg], r0 = (mt - p.mt_start[seg]) * BR;
+    const __bf16* A = p.A[seg];
+    const __bf16* B = p.B[seg];
+    char* sa = dsmem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int row = r0 + srow[i];
+      const bool rok = row < segM;
+      const void* pa = (rok && acol[i] >= 0) ? (const void*)(A + (long)row * p.lda + acol[i]) : (const void*)g_zero_page;
+      const void* pb = (rok && bcol[i] >= 0) ? (const void*)(B + (long)row * p.ldb + bcol[i]) : (const void*)g_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr)pa, (lptr)(sa + i * NW * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(sa + BR * 256 + i * NW * 1024), 16, 0, 0);
+    }
+  };
+  const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
+  const int frow = 8 * h + qq, half8 = 8 * (pp & 1);
+  const int cha = (wr * 64 + 16 * cb) / 8 + (pp >> 1);
+  const int chb = (wc * WCOLS + 16 * cb) / 8 + (pp >> 1);
+
+  f32x16 acc[2][NJ], acs[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acs[i][x] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+  }
+  const bool do_cs = p.colsum != nullptr && k0 == 0 && wc == 0;      // wave-uniform
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+  if (nk > 0) {
+    issue(0, 0);
+    if (NST == 3 && nk > 1) issue(1, 1);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+      if (NST == 3 && t + 1 < nk) {
+        if (NW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (t + NST - 1 < nk) issue(t + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+      const char* As = dsmem + stage * STAGE;
+      const char* Bs = As + BR * 256;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 a[2], b[NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = tr_frag(As, 16 * kk + frow, cha + 4 * i, half8);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = tr_frag(Bs, 16 * kk + frow, chb + 4 * j, half8);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, acs[i], 0, 0, 0);
+        }
+      }
+      stage = stage == NST - 1 ? 0 : stage + 1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int col = k0 + wc * WCOLS + j * 32 + r;
+    if (col >= p.K) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int row = n0 + wr * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+        if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
+      }
+  }
+  if (do_cs && r == 0) {                                   // column 0 of the ones-product holds the column sums of A
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int row = n0 + wr * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+        if (row < p.N) atomicAdd(p.colsum + row, acs[i][x]);
+      }
+  }
+}
+
 }  // namespace
 
 static int gemm_check_one(int es, const void* A, long lda, const void* B, long ldb, long ldc, int M, int N, int K) {
@@ -635,8 +768,10 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
 // C[N,K] += sum_s A_s[M_s,N]^T B_s[M_s,K] (bf16 operands as they lie in memory, float32 atomic accumulation, split over
 // rows); colsum (optional, [N]) += column sums of all A_s (the bias gradient). nseg <= 16 row segments share lda/ldb.
 // Replaces autograd's weight-gradient matmuls (one launch per parameter per episode when the segments are the T steps).
-extern "C" int vlni_gemm_tn_bf16_grouped(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
-                                         float* C, long ldc, int N, int K, float* colsum, int split, void* stream) {
+// variant: 0/1 = register-staged kernel, 2 = LDS-DMA 2-stage, 3 = 3-stage, 4 / 5 = 3- / 2-stage with 8 waves (identical sums up
+// to float atomics order).
+extern "C" int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
+                                           float* C, long ldc, int N, int K, float* colsum, int split, int variant, void* stream) {
   VLNI_CHECK(nseg >= 1 && nseg <= TN_MAXSEG, VLNI_EINVAL, "gemm_tn: nseg=%d not in 1..%d", nseg, TN_MAXSEG);
   VLNI_CHECK(N > 0 && K > 0 && split >= 1, VLNI_EINVAL, "gemm_tn: bad problem N=%d K=%d split=%d", N, K, split);
   VLNI_CHECK(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, VLNI_EINVAL, "gemm_tn: N/K/lda/ldb multiples of 8");
@@ -653,9 +788,31 @@ extern "C" int vlni_gemm_tn_bf16_grouped(int nseg, const void* const* A, const v
   const int nmt = p.mt_start[nseg];
   p.mt_per_split = cdiv(nmt, split);
   dim3 grid(cdiv(N, BM) * cdiv(K, BN), 1, cdiv(nmt, p.mt_per_split));
-  hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(NT), 0, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  if (variant >= 2 && p.mt_per_split >= 3) {
+    constexpr int ST = 2 * 64 * 256;
+    static bool attr = false;
+    if (!attr) {
+      hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
+      hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
+      hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
+      hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
+      attr = true;
+    }
+    if (variant == 2) hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 4>), grid, dim3(256), 2 * ST, st, p);
+    else if (variant == 3) hipLaunchKernelGGL((gemm_tn_glds_kernel<3, 4>), grid, dim3(256), 3 * ST, st, p);
+    else if (variant == 4) hipLaunchKernelGGL((gemm_tn_glds_kernel<3, 8>), grid, dim3(512), 3 * ST, st, p);
+    else hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 8>), grid, dim3(512), 2 * ST, st, p);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(NT), 0, st, p);
+  }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
+}
+
+extern "C" int vlni_gemm_tn_bf16_grouped(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
+                                         float* C, long ldc, int N, int K, float* colsum, int split, void* stream) {
+  return vlni_gemm_tn_bf16_grouped_v(nseg, A, B, M, lda, ldb, C, ldc, N, K, colsum, split, 0, stream);
 }
 
 extern "C" int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,

@@ -386,6 +386,7 @@ def _bgrad_to(params, dy):
 # queued during backward and reduced by ONE grouped transposing-read GEMM per parameter at flush time, i.e. one launch
 # with a T-times longer reduction instead of T short split-K launches. 288 GB of HBM make keeping dY alive free.
 DEFER_WGRAD = False
+TN_VARIANT = 5          # LDS-DMA 2-stage, 8 waves: fastest of the five on every episode-level shape (tools/tn_probe.py)
 _WQ = {}
 
 
@@ -402,8 +403,8 @@ def flush_wgrads():
             tiles = ((N + 127) // 128) * ((K + 127) // 128)
             nmt = sum((d.shape[0] + 63) // 64 for d, _ in chunk)
             split = max(1, min(8, nmt // 8))
-            _lib.call("vlni_gemm_tn_bf16_grouped", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
-                      split, _st())
+            _lib.call("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
+                      split, TN_VARIANT, _st())
     _WQ.clear()
 
 
