@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--time-batched", action="store_true",
                     help="HAMT: run the T teacher-forced steps as one [T*B] batch (same results, SURVEY 8f rank 1)")
     ap.add_argument("--no-time-batched-extra", action="store_true")
+    ap.add_argument("--grad-comm", default="bf16", choices=["bf16", "fp32"],
+                    help="dtype of the gradient all-reduce payload for N > 1 (arena stays fp32)")
     ap.add_argument("--model", default="hamt", choices=["hamt", "duet"],
                     help="hamt = BASELINE.json configs[1] (the metric's config); duet = configs[3] (batch 32)")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -167,7 +169,7 @@ def main():
         if args.time_batched:
             from vln_imagine_amd.hamt.episode import run_episode_time_batched
             run_episode = lambda m, e, criterion=None, keep=False: run_episode_time_batched(m, e, criterion=criterion)
-    trainer = FlatTrainer(model, lr=1e-5)
+    trainer = FlatTrainer(model, lr=1e-5, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
 
     def step():
         trainer.zero_grad()
@@ -311,6 +313,7 @@ def main():
                                    f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, dropout p=0"
                                    + (", steps time-batched (teacher forcing)" if args.time_batched else ", step-by-step calls"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "grad_allreduce": (args.grad_comm + " payload, flat arena, 128-MiB chunks, RCCL") if world > 1 else "none (1 GPU)",
                        "steps_per_sec": round(args.T * args.batch * world / (dt / args.steps), 1),
                        "loss": round(float(loss), 5)},
             "roofline": roof, "cpu_baseline": cpu, "time_batched": tb,

@@ -147,6 +147,9 @@ def _dp_worker(rank, world, port, out):
     g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     allreduce_mean_(g, 256)                       # 4 chunks
     out[rank] = g.clone()
+    h = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    allreduce_mean_(h, 300, torch.bfloat16)       # compressed exchange
+    out[10 + rank] = h.clone()
     dist.destroy_process_group()
 
 
@@ -159,6 +162,8 @@ def test_data_parallel_gradient_mean_gloo_world2(tmp_path):
     mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
     want = torch.arange(1000, dtype=torch.float32) * 1.5
     assert torch.equal(out[0], want) and torch.equal(out[1], want)
+    for r in (10, 11):                            # bf16 exchange: every rank identical, within bf16 rounding of the mean
+        assert torch.equal(out[r], out[10]) and ((out[r] - want).abs() <= want.abs() * 2 ** -7 + 1e-6).all()
 
 
 def test_graph_map_shortest_paths_and_features():

@@ -10,23 +10,34 @@ import torch.distributed as dist
 from . import _lib, ops
 
 
-def allreduce_mean_(flat, chunk_elems):
+def allreduce_mean_(flat, chunk_elems, comm_dtype=None):
     """In-place mean over the data-parallel group (DDP's gradient averaging, r2r/agent_cmt.py:61-63) on ONE flat
     buffer: a handful of large all-reduces (RCCL over xGMI on the GPU box, gloo in the CPU tests) instead of
-    per-tensor buckets. No-op without an initialised process group."""
+    per-tensor buckets. comm_dtype=torch.bfloat16 halves the bytes on the xGMI links (the reduction then runs in bf16,
+    like DDP's bf16 compression hook; the arena stays float32). No-op without an initialised process group."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return flat
     ws = dist.get_world_size()
-    works = [dist.all_reduce(flat[o:o + chunk_elems], op=dist.ReduceOp.SUM, async_op=True)
-             for o in range(0, flat.numel(), chunk_elems)]
-    for w in works:
+    if comm_dtype is None or comm_dtype == flat.dtype:
+        works = [dist.all_reduce(flat[o:o + chunk_elems], op=dist.ReduceOp.SUM, async_op=True)
+                 for o in range(0, flat.numel(), chunk_elems)]
+        for w in works:
+            w.wait()
+        return flat.mul_(1.0 / ws)
+    # pre-divide so the bf16 sum of ws terms stays in range, reduce compressed chunks, expand back
+    parts = []
+    for o in range(0, flat.numel(), chunk_elems):
+        c = (flat[o:o + chunk_elems] * (1.0 / ws)).to(comm_dtype)
+        parts.append((o, c, dist.all_reduce(c, op=dist.ReduceOp.SUM, async_op=True)))
+    for o, c, w in parts:
         w.wait()
-    return flat.mul_(1.0 / ws)
+        flat[o:o + c.numel()].copy_(c)
+    return flat
 
 
 class FlatTrainer:
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=40.0,
-                 chunk_mb=128):
+                 chunk_mb=128, grad_comm_dtype=None):
         self.model = model
         # arena order: the q/k/v projections of every attention module sit back to back (weights, then biases), so
         # the packed [2304,768] QKV gradient is ONE wgrad GEMM into a contiguous view (ops._packed_grad)
@@ -64,6 +75,7 @@ class FlatTrainer:
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.coef = torch.ones(1, dtype=torch.float32, device=dev)
         self.chunk = chunk_mb * (1 << 20) // 4
+        self.grad_comm_dtype = grad_comm_dtype
         ops.SHADOWS.invalidate()
         ops.DIRECT_GRAD = True
         ops.DEFER_WGRAD = True
@@ -78,7 +90,7 @@ class FlatTrainer:
 
     def allreduce_grads(self):
         self.flush()
-        allreduce_mean_(self.flat_g, self.chunk)
+        allreduce_mean_(self.flat_g, self.chunk, self.grad_comm_dtype)
 
     def step(self):
         self.flush()
