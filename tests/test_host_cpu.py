@@ -38,8 +38,8 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     rc = lib.vlni_gemm_nt(0, 16, 7, 16, 8, 16, 8, 4, 4, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0)   # K=7 not a multiple of 4
     assert rc == -1 and b"multiples" in lib.vlni_last_error()
-    rc = lib.vlni_attn_fwd(1, 16, 768, 16, 768, 16, 768, 0, 0, 16, 768, 16, 2, 12, 10, 200, 0.125, 0.0, 0, 0)   # Sk > 128
-    assert rc == -3 and b"128" in lib.vlni_last_error()
+    rc = lib.vlni_attn_fwd(1, 16, 768, 16, 768, 16, 768, 0, 0, 16, 768, 16, 2, 12, 10, 300, 0.125, 0.0, 0, 0)   # Sk > 256
+    assert rc == -3 and b"not covered" in lib.vlni_last_error()
 
 
 def test_product_path_has_no_cpu_fallback():
