@@ -64,3 +64,51 @@ def test_product_bf16_tracks_fp32():
         fin = torch.isfinite(b)
         assert (torch.isfinite(a) == fin).all()
         assert (a[fin] - b[fin]).abs().max().item() < 0.15
+
+
+def test_text_kv_cache_is_transparent():
+    """SURVEY.md 8f rank 1 (DUET half): projecting the step-invariant text K/V once per episode must not change anything."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.duet.models import vilmodel
+    cfg, ep = duet_variant_setup("c1_shipped")
+    et = DuetEpisodeTensors(ep, "cuda")
+    res = {}
+    for on in (False, True):
+        vilmodel.CACHE_TEXT_KV = on
+        try:
+            model = build_product(cfg)
+            outs = []
+            for rep in range(2):                      # second pass: the entry of pass 1 was dropped by its backward
+                model.zero_grad(set_to_none=True)
+                out = run_episode(model, et, criterion=ops.cross_entropy_sum)
+                out["loss"].backward()
+                outs.append(out)
+            assert model._kv_cache is None
+            assert abs(outs[0]["loss"].item() - outs[1]["loss"].item()) < 1e-6
+            res[on] = (outs[1], {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+        finally:
+            vilmodel.CACHE_TEXT_KV = True
+    (o0, g0), (o1, g1) = res[False], res[True]
+    assert abs(o0["loss"].item() - o1["loss"].item()) < 1e-6
+    for t in range(ep.T):
+        a, b = o0["fused"][t], o1["fused"][t]
+        fin = torch.isfinite(a)
+        assert (a[fin] - b[fin]).abs().max().item() < 1e-5
+    assert g0.keys() == g1.keys()
+    for n in g0:
+        d = (g0[n] - g1[n]).abs().max().item()
+        assert d <= 1e-5 + 1e-4 * g0[n].abs().max().item(), (n, d)
+
+
+def test_text_kv_cache_sees_parameter_updates():
+    from vln_imagine_amd.duet.models import vilmodel
+    cfg, ep = duet_variant_setup("c1_shipped")
+    et = DuetEpisodeTensors(ep, "cuda")
+    model = build_product(cfg)
+    with torch.no_grad():
+        a = run_episode(model, et)["fused"][-1].clone()
+        w = model.global_encoder.encoder.x_layers[0].visual_attention.att.key.weight
+        w.mul_(1.5)
+        b = run_episode(model, et)["fused"][-1]
+    fin = torch.isfinite(a)
+    assert (a[fin] - b[fin]).abs().max().item() > 1e-4

@@ -14,6 +14,18 @@ class DuetEpisodeTensors:
         self.txt_ids, self.txt_masks = t(ep.txt_ids), t(ep.txt_masks)
         self.imagine_feats, self.imagine_masks = t(ep.imagine_feats), t(ep.imagine_masks)
         self.steps = [{k: (t(v) if hasattr(v, "dtype") else v) for k, v in s.items()} for s in ep.steps]
+        # map-node sources as gather indices into the bank [zero row | avg_0, pano_0 | avg_1, pano_1 | ...]
+        import numpy as np
+        widths = [int(s["view_lens"].max()) for s in ep.steps]
+        base = np.concatenate([[1], 1 + np.cumsum([w + 1 for w in widths])])
+        self.pano_widths, self.node_idx = widths, []
+        for s in ep.steps:
+            G = s["gmap_masks"].shape[1]
+            idx = np.zeros((ep.B, G), np.int64)
+            for b, srcs in enumerate(s["node_src"]):
+                for j, src in enumerate(srcs):
+                    idx[b, j + 1] = base[src[1]] + (0 if src[0] == "avg" else 1 + src[2])
+            self.node_idx.append(t(idx))
 
 
 def ce_sum(logits, target):
@@ -33,24 +45,21 @@ def run_episode(model, et, use_aux=True, train_ml=0.2, cosine_weight=0.5, criter
             "sub_instr_imag_flag": ep.sub_instr_imag_flag, "noun_phrase_segs": ep.noun_phrase_segs,
             "obs_instr_ids": [f"i{b}" for b in range(et.B)]})
     ml_loss = 0.0
-    panos, avgs = [], []
+    bank = None
     for t, s in enumerate(et.steps):
         pano, pano_masks = model("panorama", {
             "view_img_fts": s["view_img_fts"], "obj_img_fts": None, "loc_fts": s["loc_fts"],
             "nav_types": s["nav_types"], "view_lens": s["view_lens"], "obj_lens": None})
         lens = s["view_lens"].to(pano.dtype)
         avg = (pano * pano_masks.unsqueeze(2)).sum(1) / lens[:, None]         # agent.py:468-469
-        panos.append(pano); avgs.append(avg)
-        G = s["gmap_masks"].shape[1]
-        rows = []
-        for b in range(et.B):
-            nodes = [torch.zeros_like(avg[0])]
-            for src in s["node_src"][b]:
-                nodes.append(avgs[src[1]][b] if src[0] == "avg" else panos[src[1]][b, src[2]])
-            while len(nodes) < G:
-                nodes.append(torch.zeros_like(avg[0]))
-            rows.append(torch.stack(nodes, 0))
-        gmap_img = torch.stack(rows, 0)                                         # pad_tensors_wgrad equivalent
+        assert pano.shape[1] == et.pano_widths[t]
+        if bank is None:
+            bank = [torch.zeros_like(avg).unsqueeze(1)]
+        bank += [avg.unsqueeze(1), pano]
+        # node j of sample b = one row of an earlier step's panorama output (the agent's per-node python lists + pad_tensors_wgrad,
+        # agent.py:100-134), here one gather
+        idx = et.node_idx[t]
+        gmap_img = torch.gather(torch.cat(bank, 1), 1, idx.unsqueeze(2).expand(-1, -1, pano.shape[2]))
         vp_img = torch.cat([torch.zeros_like(pano[:, :1]), pano], 1)           # agent.py:164-166
         ones = torch.ones(et.B, 1, dtype=torch.bool, device=pano.device)
         vlen1 = s["view_lens"] + 1

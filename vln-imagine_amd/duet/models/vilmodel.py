@@ -22,6 +22,9 @@ from vln_imagine_amd.hamt.models.vilmodel_cmt import (HID_EPS, AlignWithContrast
 from .transformer import TransformerEncoder
 
 
+CACHE_TEXT_KV = os.environ.get("VLNI_CACHE_TEXT_KV", "1") == "1"
+
+
 class GraphLXRTXLayer(nn.Module):
     def __init__(self, c):
         super().__init__()
@@ -32,8 +35,11 @@ class GraphLXRTXLayer(nn.Module):
         self.visn_output = BertOutput(c)
         self.visual_attention = BertXAttention(c)
 
-    def forward(self, lang, lang_mask, visn, visn_mask, graph_sprels=None):
-        visn = ops.xatt_block(visn, lang, lang_mask, _att(self.visual_attention), drop=_drop(self.visual_attention))
+    def forward(self, lang, lang_mask, visn, visn_mask, graph_sprels=None, kv=None):
+        if kv is not None:      # text-side K/V projected once per episode (CrossmodalEncoder caches it)
+            visn = ops.xatt_q_block(visn, kv, lang_mask, _att(self.visual_attention), drop=_drop(self.visual_attention))
+        else:
+            visn = ops.xatt_block(visn, lang, lang_mask, _att(self.visual_attention), drop=_drop(self.visual_attention))
         visn = self.visn_self_att(visn, visn_mask, bias=graph_sprels)
         return ops.ffn_block(visn, _ffn(self.visn_inter, self.visn_output), drop=_drop(self.visn_output))
 
@@ -53,10 +59,14 @@ class CrossmodalEncoder(nn.Module):
         super().__init__()
         self.x_layers = nn.ModuleList([GraphLXRTXLayer(c) for _ in range(c.num_x_layers)])
 
-    def forward(self, txt, txt_add_mask, visn, visn_add_mask, graph_sprels=None):
-        for l in self.x_layers:
-            visn = l(txt, txt_add_mask, visn, visn_add_mask, graph_sprels)
+    def forward(self, txt, txt_add_mask, visn, visn_add_mask, graph_sprels=None, kvs=None):
+        for i, l in enumerate(self.x_layers):
+            visn = l(txt, txt_add_mask, visn, visn_add_mask, graph_sprels, kv=None if kvs is None else kvs[i])
         return visn
+
+    def project_context(self, txt):
+        """K/V projections of the (step-invariant) text + imagination context for every layer."""
+        return [ops.kv_proj(txt, _att(l.visual_attention)) for l in self.x_layers]
 
 
 class ImageEmbeddings(nn.Module):
@@ -155,6 +165,10 @@ class GlocalTextPathNavCMT(nn.Module):
                     p.requires_grad = False
         self.compute_dtype = torch.bfloat16 if os.environ.get("VLNI_DTYPE", "fp32").lower() in ("bf16", "bfloat16") \
             else torch.float32
+        self._kv_cache = None
+
+    def _drop_kv_cache(self, _grad=None):
+        self._kv_cache = None
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path=None, config=None, state_dict=None):
@@ -224,8 +238,25 @@ class GlocalTextPathNavCMT(nn.Module):
         else:
             assert not c.imagine_enc_pano
         lm = ops.additive_mask(tm).contiguous()
-        gmap = ge.encoder(txt.contiguous(), lm, gmap.contiguous(), ops.additive_mask(gmap_masks), sprels)
-        vp = le.encoder(txt, lm, vp.contiguous(), ops.additive_mask(vp_masks))
+        txt = txt.contiguous()
+        kv_g = kv_l = None
+        if CACHE_TEXT_KV:
+            # the language stream is never updated (use_lang2visn_attn False), so its per-layer K/V projections are the same
+            # for every step of an episode: project once, reduce their gradient once. Key = identity of the caller-held
+            # embeddings (strong refs keep the ids unique) + the parameter epoch; a backward through the entry drops it.
+            wk = ge.encoder.x_layers[0].visual_attention.att.key.weight
+            key = (id(txt_embeds), id(imagine_embeds), txt_embeds._version, torch.is_grad_enabled(), dt, ops.SHADOWS.epoch,
+                   wk._version, tuple(tm.shape))
+            ent = self._kv_cache
+            if ent is None or ent[0] != key:
+                kvs = (ge.encoder.project_context(txt), le.encoder.project_context(txt))
+                ent = self._kv_cache = (key, (txt_embeds, imagine_embeds), kvs[0], kvs[1])
+                for kv in kvs[0] + kvs[1]:
+                    if kv.requires_grad:
+                        kv.register_hook(self._drop_kv_cache)
+            kv_g, kv_l = ent[2], ent[3]
+        gmap = ge.encoder(txt, lm, gmap.contiguous(), ops.additive_mask(gmap_masks), sprels, kvs=kv_g)
+        vp = le.encoder(txt, lm, vp.contiguous(), ops.additive_mask(vp_masks), kvs=kv_l)
         if self.sap_fuse_linear is None:
             fuse = 0.5
         else:

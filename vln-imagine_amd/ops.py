@@ -737,6 +737,72 @@ class _XAttBlock(torch.autograd.Function):
         return dx, dc, None, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
 
 
+class _KvProj(torch.autograd.Function):
+    """kv = ctx_in [Wk;Wv]^T + [bk;bv]: the context side of a cross-attention, as its own node so that a context that
+    does not change over the steps of an episode (DUET never updates the text stream, vilmodel.py:384-399) is projected ONCE
+    and its gradient is reduced once."""
+
+    @staticmethod
+    def forward(ctx, c_in, wk, bk, wv, bv):
+        c2 = _rows(_chk(c_in, "context"))
+        kv = gemm_nt(c2, _w((wk, wv), c2.dtype), bias=_w((bk, bv), torch.float32))
+        ctx.save_for_backward(c2)
+        ctx.P, ctx.shp = (wk, bk, wv, bv), c_in.shape
+        return kv
+
+    @staticmethod
+    def backward(ctx, dkv):
+        (c2,) = ctx.saved_tensors
+        wk, bk, wv, bv = ctx.P
+        ng = ctx.needs_input_grad
+        dkv = dkv.contiguous()
+        dwk = dwv = dbk = dbv = None
+        if any(ng[1:]):
+            (dwk, dwv), (dbk, dbv) = _wb_grad_to((wk, wv), (bk, bv), dkv, c2)
+        dc = gemm_nt(dkv, _w((wk, wv), c2.dtype, True)).view(ctx.shp) if ng[0] else None
+        return dc, dwk, dbk, dwv, dbv
+
+
+class _XAttQBlock(torch.autograd.Function):
+    """y = LN(dense(attn(q = x Wq, k/v = given projected context)) + x): the query side of _XAttBlock."""
+
+    @staticmethod
+    def forward(ctx, x, kv, mask_c, eps, drop, wq, bq, wo, bo, g, b):
+        B, Sq, H = x.shape
+        Sk = kv.shape[0] // B
+        pa, ph, sd = drop
+        x2 = _rows(_chk(x, "x"))
+        dt = x.dtype
+        q = gemm_nt(x2, _w((wq,), dt), bias=bq)
+        a, lse = attn_fwd(q, kv[:, :H], kv[:, H:], B, Sq, Sk, mask_c, drop=(pa, sd))
+        pre = gemm_nt(a, _w((wo,), dt), bias=bo, residual=x2, drop=(ph, sd + 1))
+        y, mean, rstd = ln_fwd(pre, g, b, eps)
+        ctx.save_for_backward(x2, q, kv, a, lse, pre, mean, rstd, mask_c)
+        ctx.P, ctx.dims, ctx.drop = (wq, bq, wo, bo, g, b), (B, Sq, Sk, H), drop
+        return y.view(B, Sq, H)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, q, kv, a, lse, pre, mean, rstd, mask_c = ctx.saved_tensors
+        wq, bq, wo, bo, g, b = ctx.P
+        B, Sq, Sk, H = ctx.dims
+        pa, ph, sd = ctx.drop
+        dt = x2.dtype
+        ng = ctx.needs_input_grad
+        wparams = any(ng[5:])
+        dpre, dg, db, dpm = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams, drop=(ph, sd + 1))
+        dwo = dbo = dwq = dbq = None
+        if wparams:
+            (dwo,), (dbo,) = _wb_grad_to((wo,), (bo,), dpm, a)
+        da = gemm_nt(dpm, _w((wo,), dt, True))
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        attn_bwd(q, kv[:, :H], kv[:, H:], a, da, lse, dq, dkv[:, :H], dkv[:, H:], B, Sq, Sk, mask_c, drop=(pa, sd))
+        if wparams:
+            (dwq,), (dbq,) = _wb_grad_to((wq,), (bq,), dq, x2)
+        dx = gemm_nt(dq, _w((wq,), dt, True), residual=dpre).view(B, Sq, H) if ng[0] else None
+        return dx, (dkv if ng[1] else None), None, None, None, dwq, dbq, dwo, dbo, dg, db
+
+
 class _PreNormAttBlock(torch.autograd.Function):
     """y = x + out_proj(attn(in_proj(LN(x)))) with a packed [2304,768] in_proj and a key-padding mask (-inf):
     TransformerEncoderLayer.forward_pre, first half (VLN-DUET models/transformer.py:170-177)."""
@@ -1121,6 +1187,15 @@ def xatt_pair_block(lang, visn, mask_l, mask_v, p, eps=1e-12, drop=NO_DROP):
 
 def xatt_block(x, c_in, mask_c, p, eps=1e-12, drop=NO_DROP):
     return _XAttBlock.apply(x, c_in, mask_c, eps, drop, *p)
+
+
+def kv_proj(c_in, p):
+    """Packed K/V projection of a cross-attention context; p = (wq,bq,wk,bk,wv,bv,wo,bo,g,b) of the attention holder."""
+    return _KvProj.apply(c_in, p[2], p[3], p[4], p[5])
+
+
+def xatt_q_block(x, kv, mask_c, p, eps=1e-12, drop=NO_DROP):
+    return _XAttQBlock.apply(x, kv, mask_c, eps, drop, p[0], p[1], p[6], p[7], p[8], p[9])
 
 
 def prenorm_att_block(x, kmask, p, eps=1e-5, drop=NO_DROP):
