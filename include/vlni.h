@@ -130,11 +130,23 @@ int vlni_cosine_bwd(int dtype, const void* x, const void* y, const float* gcos, 
 int vlni_dropout(int dtype, const void* x, void* y, long n, float p, unsigned seed, void* stream);
 /* dz = da * act'(z), act 1 gelu-erf / 2 relu (n multiple of 4) */
 int vlni_act_bwd(int dtype, int act, const void* da, const void* z, void* dz, long n, void* stream);
+/* DUET global/local logit fusion, replaces the per-sample python loop of VLN-DUET/map_nav_src/models/vilmodel.py:1198-1217:
+   src[B,G]: local candidate index that IS map node g (>= 0), -2 = unvisited node without a candidate (takes the summed local
+   logits of the visited candidates), -1 = nothing to add; bw[B,V]: candidate j is an already-visited viewpoint.
+   fwd: out = gl + gathered ll (float32 logits, may hold -inf); bwd: dll from dout (dgl = dout) */
+int vlni_duet_fuse_fwd(const float* gl, const float* ll, const int* src, const unsigned char* bw, float* out, int B, int G, int V,
+                       void* stream);
+int vlni_duet_fuse_bwd(const float* dout, const int* src, const unsigned char* bw, float* dll, int B, int G, int V, void* stream);
 /* optimizer side of the measured step (r2r/agent_cmt.py:827-832): clip_grad_norm_ + AdamW over a flat arena */
 int vlni_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, const float* clip_coef, void* stream);
 int vlni_sumsq(const float* g, long n, float* sumsq, void* stream);
 int vlni_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream);
+/* the same step with every per-step quantity on the device (replayable inside a captured hipGraph): state = 4 floats
+   [clip factor, 1-beta1^t, 1-beta2^t, t], zeroed once by the caller; vlni_optim_prepare advances t and fills the rest */
+int vlni_optim_prepare(const float* sumsq, float max_norm, float beta1, float beta2, float* state, void* stream);
+int vlni_adamw_step_dev(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, const float* lr_dev,
+                        float beta1, float beta2, float eps, float weight_decay, const float* state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -112,3 +112,53 @@ def test_text_kv_cache_sees_parameter_updates():
         b = run_episode(model, et)["fused"][-1]
     fin = torch.isfinite(a)
     assert (a[fin] - b[fin]).abs().max().item() > 1e-4
+
+
+def test_logit_fusion_kernel_matches_reference_loop():
+    """vlni_duet_fuse_fwd/bwd against a literal restatement of VLN-DUET/map_nav_src/models/vilmodel.py:1198-1217 (autograd)."""
+    from vln_imagine_amd.duet.models.vilmodel import GlocalTextPathNavCMT
+    from vln_imagine_amd.duet.config import DuetConfig
+    torch.manual_seed(0)
+    B, G, V = 3, 7, 6
+    gl0, ll0 = torch.randn(B, G), torch.randn(B, V)
+    vpids = [[None, "a", "b", "c", "d", "e", "f"], [None, "a", "b", "c", "d"], [None, "x", "y", "z", "w", "u", "t"]]
+    vis = torch.tensor([[0, 1, 1, 0, 0, 0, 0], [0, 1, 0, 0, 0, 0, 0], [0, 0, 0, 0, 0, 0, 0]], dtype=torch.bool)
+    cands = [[None, "b", "d", "e"], [None, "c"], [None, "x", "t", "q"]]
+    w = torch.randn(B, G)
+
+    def masked(gl, ll):
+        gl = gl.masked_fill(vis.to(gl.device), -float("inf"))
+        keep = torch.ones(B, V, dtype=torch.bool, device=ll.device)
+        keep[:, 4:] = False
+        return gl, ll.masked_fill(~keep, -float("inf"))
+
+    gl_r, ll_r = gl0.clone().requires_grad_(), ll0.clone().requires_grad_()
+    gl, ll = masked(gl_r, ll_r)
+    rows = []
+    for i in range(B):
+        visited = {vp for vp, m in zip(vpids[i], vis[i].tolist()) if m}
+        tmp, bw = {}, 0
+        for j, c in enumerate(cands[i]):
+            if j > 0:
+                if c in visited:
+                    bw = bw + ll[i, j]
+                else:
+                    tmp[c] = ll[i, j]
+        row = [gl[i, 0] + ll[i, 0]]
+        for j in range(1, G):
+            vp = vpids[i][j] if j < len(vpids[i]) else None
+            add = 0
+            if j < len(vpids[i]) and vp not in visited:
+                add = tmp[vp] if vp in tmp else bw
+            row.append(gl[i, j] + add)
+        rows.append(torch.stack(row))
+    ref = torch.stack(rows)
+    fin = torch.isfinite(ref)
+    (ref[fin] * w[fin]).sum().backward()
+
+    model = GlocalTextPathNavCMT(DuetConfig(num_l_layers=1, num_pano_layers=1, num_x_layers=1))
+    gl_g, ll_g = gl0.clone().cuda().requires_grad_(), ll0.clone().cuda().requires_grad_()
+    out = model._fuse(*masked(gl_g, ll_g), vpids, vis.cuda(), cands)
+    assert (torch.isfinite(out).cpu() == fin).all() and torch.allclose(out.cpu()[fin], ref[fin], atol=1e-6)
+    (out[fin.cuda()] * w.cuda()[fin.cuda()]).sum().backward()
+    assert torch.allclose(gl_g.grad.cpu(), gl_r.grad, atol=1e-6) and torch.allclose(ll_g.grad.cpu(), ll_r.grad, atol=1e-6)

@@ -193,3 +193,50 @@ def test_time_batched_episode_equals_stepwise():
             continue
         d = (p.grad - q.grad).abs().max().item()
         assert d <= 3e-5 * max(1.0, p.grad.abs().max().item()), (n, d)
+
+
+@pytest.mark.parametrize("family", ["hamt", "duet"])
+def test_graphed_step_replays_the_eager_step(family):
+    """FlatTrainer.capture: zero_grad + fwd + bwd + wgrad flush in one hipGraph, clip + AdamW in a second (step count, bias
+    corrections, clip factor and lr on the device). 1 warm-up step + 2 replays == 3 eager steps."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    if family == "hamt":
+        cfg, ep = hamt_variant_setup("c1_T3_dense")
+        et, build, run = EpisodeTensors(ep, "cuda"), build_product, run_episode
+    else:
+        from tests.golden.variants import duet_variant_setup
+        from tests.test_duet_gpu import build_product as build
+        from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode as run
+        cfg, ep = duet_variant_setup("c1_T3_dense")
+        et = DuetEpisodeTensors(ep, "cuda")
+    try:
+        finals, losses = [], []
+        for graphed in (False, True):
+            m = build(cfg)
+            tr = FlatTrainer(m, lr=1e-3)
+
+            def fwd_bwd():
+                loss = run(m, et, criterion=ops.cross_entropy_sum, keep=False)["loss"]
+                loss.backward()
+                return loss
+
+            if graphed:
+                step = tr.capture(fwd_bwd, warmup=1)
+                for _ in range(2):
+                    loss = step()
+                assert tr.step_no == 3 and abs(float(tr.state[3]) - 3.0) < 1e-6
+            else:
+                for _ in range(3):
+                    tr.zero_grad()
+                    loss = fwd_bwd()
+                    tr.step()
+            losses.append(float(loss.detach()))
+            finals.append(tr.flat_p.clone())
+        assert abs(losses[0] - losses[1]) < 2e-4 * max(1.0, abs(losses[0])), losses
+        # three Adam steps at lr 1e-3 move every parameter by <= 3e-3; sign flips of ~zero gradients bound the difference
+        d = (finals[0] - finals[1]).abs()
+        assert d.max().item() < 6.5e-3 and d.mean().item() < 1e-5, (d.max().item(), d.mean().item())
+    finally:
+        ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
+        ops._WQ.clear()

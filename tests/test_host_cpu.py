@@ -120,7 +120,18 @@ def test_duet_logit_fusion_matches_reference_loop():
         for j, vp in enumerate(vpids[i]):
             if j > 0 and vp not in visited:
                 ref[i, j] += tmp[vp] if vp in tmp else bw
-    out = M._fuse(gl, ll, vpids, vis, cands)
+    # host half (the index plan) evaluated with the kernel's semantics (csrc/elementwise.hip duet_fuse_fwd_kernel);
+    # the kernel itself is checked against the same loop in tests/test_duet_gpu.py
+    src, bwm = M.fuse_plan(vpids, vis.tolist(), cands, G, V)
+    out = gl.clone()
+    for i in range(B):
+        s_bw = sum(ll[i, j] for j in range(V) if bwm[i][j])
+        out[i, 0] += ll[i, 0]
+        for g in range(1, G):
+            if src[i][g] >= 0:
+                out[i, g] += ll[i, src[i][g]]
+            elif src[i][g] == -2:
+                out[i, g] += s_bw
     fin = torch.isfinite(ref)
     assert (torch.isfinite(out) == fin).all() and torch.allclose(out[fin], ref[fin], atol=1e-6)
 

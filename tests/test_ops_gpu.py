@@ -395,17 +395,40 @@ def test_wgrad_tn_lds_dma_variants_exact(ops, variant):
     assert torch.equal(cs.cpu(), sum(d.sum(0) for d in dys))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8])
 def test_gemm_variants_identical(ops, variant):
-    """The five GEMM pipelines (register-staged, LDS-DMA 2/3-stage, 4 or 8 waves) give identical results, incl. epilogues and edges."""
-    from vln_imagine_amd import _lib
+    """All GEMM pipelines (register-staged, LDS-DMA 2/3-stage with 4 or 8 waves, large tiles 256x128 / 256x256 / 128x256) give
+    bit-identical results, incl. epilogues and ragged tile edges."""
     for dtype in (torch.bfloat16, torch.float32):
-        M, N, K = 333, 768, 768
-        a, b = _rand((M, K), dtype, 31, 0.5), _rand((N, K), dtype, 32, 0.05)
-        bias, res = _rand((N,), torch.float32, 33, 0.1), _rand((M, N), dtype, 34, 0.5)
-        outs = []
-        for v in (1, variant):
-            out, z = torch.empty((M, N), dtype=dtype, device="cuda"), torch.empty((M, N), dtype=dtype, device="cuda")
-            ops._gemm_call(v, a, b, out, bias, 1, res, z, None, 0, 1.0, 1, False, M, N, K)
-            outs.append((out, z))
-        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (variant, dtype)
+        for (M, N, K) in ((333, 768, 768), (700, 640, 384)):
+            a, b = _rand((M, K), dtype, 31, 0.5), _rand((N, K), dtype, 32, 0.05)
+            bias, res = _rand((N,), torch.float32, 33, 0.1), _rand((M, N), dtype, 34, 0.5)
+            outs = []
+            for v in (1, variant):
+                out, z = torch.empty((M, N), dtype=dtype, device="cuda"), torch.empty((M, N), dtype=dtype, device="cuda")
+                ops._gemm_call(v, a, b, out, bias, 1, res, z, None, 0, 1.0, 1, False, M, N, K)
+                outs.append((out, z))
+            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (variant, dtype, M, N, K)
+
+
+@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8])
+def test_gemm_dual_launch_variants(ops, variant):
+    """Two problems in one launch (language + vision stream) == two single launches, for every tile geometry."""
+    saved = (ops.AUTOTUNE, ops.GEMM_VARIANTS)
+    try:
+        ops.AUTOTUNE, ops.GEMM_VARIANTS = True, (variant,)
+        ops._GEMM_BEST.clear()
+        for dtype in (torch.bfloat16, torch.float32):
+            N, K = 768, 768
+            a0, a1 = _rand((5 * 86, K), dtype, 41, 0.5), _rand((5 * 44 + 3, K), dtype, 42, 0.5)
+            b0, b1 = _rand((N, K), dtype, 43, 0.05), _rand((N, K), dtype, 44, 0.05)
+            bias = (_rand((N,), torch.float32, 45, 0.1), _rand((N,), torch.float32, 46, 0.1))
+            res = (_rand((a0.shape[0], N), dtype, 47, 0.5), _rand((a1.shape[0], N), dtype, 48, 0.5))
+            o0, o1 = ops.gemm_nt2((a0, a1), (b0, b1), bias=bias, residual=res)
+            r0 = torch.empty_like(o0); r1 = torch.empty_like(o1)
+            ops._gemm_call(1, a0, b0, r0, bias[0], 0, res[0], None, None, 0, 1.0, 1, False, a0.shape[0], N, K)
+            ops._gemm_call(1, a1, b1, r1, bias[1], 0, res[1], None, None, 0, 1.0, 1, False, a1.shape[0], N, K)
+            assert torch.equal(o0, r0) and torch.equal(o1, r1), (variant, dtype)
+    finally:
+        ops.AUTOTUNE, ops.GEMM_VARIANTS = saved
+        ops._GEMM_BEST.clear()

@@ -306,6 +306,78 @@ __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef
   coef[0] = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
 }
 
+// Device-resident optimizer state so that a captured hipGraph replays a CORRECT step: state = [clip coef, 1-b1^t, 1-b2^t, t].
+__global__ void optim_prepare_kernel(const float* sumsq, float max_norm, float b1, float b2, float* state) {
+  const float t = state[3] + 1.f;
+  state[3] = t;
+  state[0] = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
+  state[1] = 1.f - powf(b1, t);
+  state[2] = 1.f - powf(b2, t);
+}
+
+__global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, __bf16* __restrict__ shadow, long n,
+                                                        const float* __restrict__ lr_dev, float b1, float b2, float eps, float wd,
+                                                        const float* __restrict__ state) {
+  const float cc = state[0], bc1 = state[1], rbc2 = 1.f / sqrtf(state[2]), lr = lr_dev[0];
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    f32x4 pv = *(f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gv[j] * cc;
+      pv[j] *= (1.f - lr * wd);
+      mv[j] = b1 * mv[j] + (1.f - b1) * gg;
+      vv[j] = b2 * vv[j] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vv[j]) * rbc2 + eps;
+      pv[j] -= (lr / bc1) * mv[j] / denom;
+    }
+    *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
+    if (shadow) {
+      bf16x4 s = {(__bf16)pv[0], (__bf16)pv[1], (__bf16)pv[2], (__bf16)pv[3]};
+      *(bf16x4*)(shadow + i) = s;
+    }
+  }
+}
+
+// DUET global/local logit fusion (VLN-DUET/map_nav_src/models/vilmodel.py:1198-1217) as one gather / one scatter:
+//   fused[b,0] = gl[b,0] + ll[b,0];  fused[b,g] = gl[b,g] + (src[b,g] >= 0 ? ll[b,src] : src == -2 ? sum_{j: bw[b,j]} ll[b,j] : 0)
+// src / bw come from the host-side plan (which map node is which local candidate; which candidates are visited).
+__global__ __launch_bounds__(64) void duet_fuse_fwd_kernel(const float* __restrict__ gl, const float* __restrict__ ll,
+                                                           const int* __restrict__ src, const unsigned char* __restrict__ bw,
+                                                           float* __restrict__ out, int G, int V) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int j = lane; j < V; j += 64)
+    if (bw[b * V + j]) s += ll[b * V + j];
+  s = wave_sum(s);
+  for (int g = lane; g < G; g += 64) {
+    const int c = src[b * G + g];
+    float v = gl[b * G + g];
+    if (g == 0) v += ll[b * V];
+    else if (c >= 0) v += ll[b * V + c];
+    else if (c == -2) v += s;
+    out[b * G + g] = v;
+  }
+}
+__global__ __launch_bounds__(64) void duet_fuse_bwd_kernel(const float* __restrict__ dout, const int* __restrict__ src,
+                                                           const unsigned char* __restrict__ bw, float* __restrict__ dll, int G,
+                                                           int V) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float sb = 0.f;
+  for (int g = lane; g < G; g += 64)
+    if (g > 0 && src[b * G + g] == -2) sb += dout[b * G + g];
+  sb = wave_sum(sb);
+  for (int j = lane; j < V; j += 64) {
+    float d = (j == 0) ? dout[b * G] : 0.f;
+    for (int g = 1; g < G; ++g)
+      if (src[b * G + g] == j) d += dout[b * G + g];
+    if (bw[b * V + j]) d += sb;
+    dll[b * V + j] = d;
+  }
+}
+
 }  // namespace
 
 #define BY_DTYPE(dtype, CALL_F32, CALL_BF16)        \
@@ -500,6 +572,38 @@ extern "C" int vlni_sumsq(const float* g, long n, float* sumsq, void* stream) {
   VLNI_CHECK(n > 0 && n % 4 == 0, VLNI_EINVAL, "sumsq: n=%ld", n);
   dim3 grid((unsigned)std::min<long>(2048, (n / 4 + 255) / 256)), block(256);
   hipLaunchKernelGGL(sumsq_kernel, grid, block, 0, (hipStream_t)stream, g, n, sumsq);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_duet_fuse_fwd(const float* gl, const float* ll, const int* src, const unsigned char* bw, float* out, int B,
+                                  int G, int V, void* stream) {
+  VLNI_CHECK(B > 0 && G > 0 && V > 0 && gl && ll && src && bw && out, VLNI_EINVAL, "duet_fuse_fwd: B=%d G=%d V=%d", B, G, V);
+  hipLaunchKernelGGL(duet_fuse_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, gl, ll, src, bw, out, G, V);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_duet_fuse_bwd(const float* dout, const int* src, const unsigned char* bw, float* dll, int B, int G, int V,
+                                  void* stream) {
+  VLNI_CHECK(B > 0 && G > 0 && V > 0 && dout && src && bw && dll, VLNI_EINVAL, "duet_fuse_bwd: B=%d G=%d V=%d", B, G, V);
+  hipLaunchKernelGGL(duet_fuse_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dout, src, bw, dll, G, V);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// Graph-replayable form of clip + AdamW: the step count, bias corrections and clip factor live in `state` (4 floats on the
+// device, zero-initialised by the caller), the learning rate in lr_dev[0]; nothing that changes per step is a launch argument.
+extern "C" int vlni_optim_prepare(const float* sumsq, float max_norm, float beta1, float beta2, float* state, void* stream) {
+  VLNI_CHECK(sumsq && state, VLNI_EINVAL, "optim_prepare: null pointer");
+  hipLaunchKernelGGL(optim_prepare_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, beta1, beta2, state);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_adamw_step_dev(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, const float* lr_dev,
+                                   float beta1, float beta2, float eps, float weight_decay, const float* state, void* stream) {
+  VLNI_CHECK(n > 0 && n % 4 == 0 && lr_dev && state, VLNI_EINVAL, "adamw_step_dev: n=%ld (multiple of 4), lr/state non-null", n);
+  dim3 grid((unsigned)std::min<long>(4096, (n / 4 + 255) / 256)), block(256);
+  hipLaunchKernelGGL(adamw_dev_kernel, grid, block, 0, (hipStream_t)stream, p, g, m, v, (__bf16*)bf16_shadow, n, lr_dev, beta1,
+                     beta2, eps, weight_decay, state);
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

@@ -39,6 +39,7 @@ struct GemmP {
   int atomic_f32;               // C is float, accumulate with atomics (split-K wgrad)
   int kt_per_split;
   int vec_ok;                   // every epilogue tensor allows 4-element vector accesses
+  int group_m;                  // tile rasterisation: m-tiles per group (see tile_origin)
   // optional SECOND problem with the same N, K and epilogue kind (the language / vision streams of a cross-modal
   // layer): tiles [0, tiles0) belong to problem 0, the rest to problem 1 -> one launch fills the chip instead of two tails
   int tiles0;
@@ -61,6 +62,20 @@ __device__ __forceinline__ void select_problem(GemmP& p, int& wgid) {
     p.bias = p.bias1; p.residual = p.residual1; p.ldr = p.ldr1; p.preact = p.preact1; p.ldp = p.ldp1;
     p.dact_src = p.dact_src1; p.ldd = p.ldd1; p.drop_seed = p.drop_seed1;
   }
+}
+
+// Tile order inside one problem: groups of `group_m` m-tiles; inside a group the m-tile index runs fastest, then the n-tile.
+// The 64 tiles an XCD works on at one time (32 CUs x 2 blocks) then span ~8 A row-panels x ~8 B row-panels (~3 MB) instead of
+// 3 A panels x EVERY B panel (> the 4 MiB L2 at N = 3072): operands are re-read from the XCD's L2, not from the Infinity Cache.
+__device__ __forceinline__ void tile_origin(const GemmP& p, int wgid, int tbm, int tbn, int& m0, int& n0) {
+  const int ntn = (p.N + tbn - 1) / tbn;
+  if (p.group_m <= 1) { m0 = (wgid / ntn) * tbm; n0 = (wgid % ntn) * tbn; return; }
+  const int ntm = (p.M + tbm - 1) / tbm;
+  const int per = p.group_m * ntn;
+  const int g = wgid / per, idx = wgid - g * per;
+  const int first = g * p.group_m, gsz = min(ntm - first, p.group_m);
+  m0 = (first + idx % gsz) * tbm;
+  n0 = (idx / gsz) * tbn;
 }
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROWB + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -213,8 +228,8 @@ __global__ __launch_bounds__(NT) void gemm_nt_kernel(GemmP p) {
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
   int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
   select_problem(p, wgid);
-  const int ntn = (p.N + BN - 1) / BN;
-  const int m0 = (wgid / ntn) * BM, n0 = (wgid % ntn) * BN;
+  int m0, n0;
+  tile_origin(p, wgid, BM, BN, m0, n0);
 
   const int nkt = (p.K + BK - 1) / BK;
   const int kt0 = blockIdx.z * p.kt_per_split;
@@ -291,8 +306,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_glds_kernel(GemmP p) {
   const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
   int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
   select_problem(p, wgid);
-  const int ntn = (p.N + BN - 1) / BN;
-  const int m0 = (wgid / ntn) * BM, n0 = (wgid % ntn) * BN;
+  int m0, n0;
+  tile_origin(p, wgid, BM, BN, m0, n0);
   constexpr int BK = ROWB / ES;
   const int nkt = p.K / BK;
   const int kt0 = blockIdx.z * p.kt_per_split;
@@ -351,6 +366,196 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_glds_kernel(GemmP p) {
   }
   __syncthreads();                                                        // all reads done before the epilogue reuses stage 0
   gemm_epilogue<T, NW>(p, dsmem, acc, m0, n0, tid, wr, wc, r, h);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LARGE-TILE LDS-DMA kernels. With 128x128 tiles every output element pulls (128+128)*K*2/16384 bytes through the
+// CU's vector-memory path; at K = 768 that path (L2 -> LDS, ~45-70 GB/s per CU sustained), not the MFMA, sets the
+// tile time. 256x128 / 128x256 tiles move 0.75x and 256x256 tiles 0.5x the bytes per output. 8 waves as WM x WN, a
+// wave owns (32*MI) x (32*NJ) outputs = MI*NJ accumulators; LDS stage = (TBM+TBN) rows of 128 B, NST stages
+// (256x256: 2 x 64 KiB; 256x128: 3 x 48 KiB), one raw s_barrier per k-tile behind a counted vmcnt. One block per CU.
+template <typename T> struct MmaG;
+template <> struct MmaG<__bf16> {
+  static constexpr int KSTEPS = 4;
+  template <int MI, int NJ>
+  __device__ static __forceinline__ void step(const char* As, const char* Bs, int kk, int rowA0, int rowB0, int r, int h,
+                                              f32x16 (&acc)[MI][NJ]) {
+    const int chunk = kk * 2 + h;
+    bf16x8 a[MI], b[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b[j] = *(const bf16x8*)(Bs + lds_off(rowB0 + j * 32 + r, chunk));
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a[i] = *(const bf16x8*)(As + lds_off(rowA0 + i * 32 + r, chunk));
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+};
+template <> struct MmaG<float> {
+  static constexpr int KSTEPS = 16;
+  template <int MI, int NJ>
+  __device__ static __forceinline__ void step(const char* As, const char* Bs, int kk, int rowA0, int rowB0, int r, int h,
+                                              f32x16 (&acc)[MI][NJ]) {
+    const int k = kk * 2 + h;
+    const int chunk = k >> 2, within = (k & 3) * 4;
+    float a[MI], b[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b[j] = *(const float*)(Bs + lds_off(rowB0 + j * 32 + r, chunk) + within);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a[i] = *(const float*)(As + lds_off(rowA0 + i * 32 + r, chunk) + within);
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+  }
+};
+
+template <typename T, int NST, int WM, int WN, int MI, int NJ>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_big_kernel(GemmP p) {
+  constexpr int ES = sizeof(T), NW = WM * WN, NTH = NW * 64;
+  constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, WROWS = MI * 32, WCOLS = NJ * 32;
+  constexpr int STAGE = (TBM + TBN) * ROWB;
+  constexpr int IA = TBM / 8 / NW, IB = TBN / 8 / NW;        // LDS-DMA instructions per wave per stage
+  static_assert(TBM % (8 * NW) == 0 && TBN % (8 * NW) == 0, "tile rows must split evenly over the waves");
+  static_assert(64 * TBN * 4 <= NST * STAGE, "epilogue scratch");
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  select_problem(p, wgid);
+  int m0, n0;
+  tile_origin(p, wgid, TBM, TBN, m0, n0);
+  constexpr int BK = ROWB / ES;
+  const int nk = p.K / BK;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN, r = lane & 31, h = lane >> 5;
+
+  const char* ga[IA];
+  const char* gb[IB];
+#pragma unroll
+  for (int i = 0; i < IA; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    ga[i] = p.A + ((long)min(m0 + row, p.M - 1) * p.lda) * ES + ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < IB; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    gb[i] = p.B + ((long)min(n0 + row, p.N - 1) * p.ldb) * ES + ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+  }
+  using gptr = const __attribute__((address_space(1))) void*;
+  using lptr = __attribute__((address_space(3))) void*;
+  auto issue = [&](int t, int stage) {
+    char* sa = dsmem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < IA; ++i) __builtin_amdgcn_global_load_lds((gptr)(ga[i] + (long)t * ROWB), (lptr)(sa + i * NW * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < IB; ++i)
+      __builtin_amdgcn_global_load_lds((gptr)(gb[i] + (long)t * ROWB), (lptr)(sa + TBM * ROWB + i * NW * 1024), 16, 0, 0);
+  };
+
+  f32x16 acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+
+  issue(0, 0);
+  if (NST == 3 && nk > 1) issue(1, 1);
+  int stage = 0;
+  for (int t = 0; t < nk; ++t) {
+    if (NST == 3 && t + 1 < nk) {
+      if constexpr (IA + IB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                          // tile t landed everywhere; stage (t-1)%NST is free
+    if (t + NST - 1 < nk) issue(t + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+    const char* As = dsmem + stage * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < MmaG<T>::KSTEPS; ++kk)
+      MmaG<T>::template step<MI, NJ>(As, As + TBM * ROWB, kk, wr * WROWS, wc * WCOLS, r, h, acc);
+    stage = stage == NST - 1 ? 0 : stage + 1;
+  }
+  __syncthreads();
+
+  // ---- epilogue: 64-row slabs of the tile go through LDS as [64][TBN] float32, then row-wise 4-column vectors ----
+  float* const e = (float*)dsmem;
+  constexpr int TPR = TBN / 4, RPP = NTH / TPR, NPASS = 64 / RPP;
+  const int c4 = (tid % TPR) * 4, gcol = n0 + c4;
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias && gcol < p.N) {
+    if (p.vec_ok) bv = *(const f32x4*)(p.bias + gcol);
+    else
+      for (int u = 0; u < 4; ++u) bv[u] = (gcol + u < p.N) ? p.bias[gcol + u] : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < TBM / 64; ++c) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int blk = wr * MI + i;                          // 32-row block of the tile held in acc[i][*]
+      if ((blk >> 1) == c) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int x = 0; x < 16; ++x)
+            e[((blk & 1) * 32 + (x & 3) + 8 * (x >> 2) + 4 * h) * TBN + wc * WCOLS + j * 32 + r] = acc[i][j][x];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+      const int rl = tid / TPR + RPP * k;
+      const int grow = m0 + c * 64 + rl;
+      if (grow >= p.M || gcol >= p.N) continue;
+      f32x4 v = *(const f32x4*)(e + rl * TBN + c4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = v[u] * p.alpha + bv[u];
+      if (p.vec_ok) {
+        if (p.preact) DT<T>::st4((T*)p.preact + (long)grow * p.ldp + gcol, v);
+        if (p.dact) {
+          const f32x4 z = DT<T>::ld4((const T*)p.dact_src + (long)grow * p.ldd + gcol);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] *= (p.dact == 1) ? gelu_grad_t<T>(z[u]) : (z[u] > 0.f ? 1.f : 0.f);
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = gelu_t<T>(v[u]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
+        }
+        if (p.drop_thr) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] *= drop_scale((unsigned)grow * (unsigned)p.N + gcol + u, p.drop_seed, p.drop_thr, p.drop_inv);
+        }
+        if (p.residual) v += DT<T>::ld4((const T*)p.residual + (long)grow * p.ldr + gcol);
+        DT<T>::st4((T*)p.C + (long)grow * p.ldc + gcol, v);
+      } else {
+        for (int u = 0; u < 4 && gcol + u < p.N; ++u) {
+          float w = v[u];
+          const long col = gcol + u;
+          if (p.preact) DT<T>::st((T*)p.preact + (long)grow * p.ldp + col, w);
+          if (p.dact) {
+            const float z = DT<T>::ld((const T*)p.dact_src + (long)grow * p.ldd + col);
+            w *= (p.dact == 1) ? gelu_grad_t<T>(z) : (z > 0.f ? 1.f : 0.f);
+          }
+          if (p.act == 1) w = gelu_t<T>(w);
+          else if (p.act == 2) w = fmaxf(w, 0.f);
+          if (p.drop_thr) w *= drop_scale((unsigned)grow * (unsigned)p.N + (unsigned)col, p.drop_seed, p.drop_thr, p.drop_inv);
+          if (p.residual) w += DT<T>::ld((const T*)p.residual + (long)grow * p.ldr + col);
+          DT<T>::st((T*)p.C + (long)grow * p.ldc + col, w);
+        }
+      }
+    }
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -649,6 +854,26 @@ static int gemm_check_one(int es, const void* A, long lda, const void* B, long l
   return VLNI_OK;
 }
 
+static int gemm_group_m(int tbm) {
+  static const int env = getenv("VLNI_GROUP_M") ? atoi(getenv("VLNI_GROUP_M")) : -1;
+  return env >= 0 ? env : 1024 / tbm;
+}
+
+template <typename T, int NST, int WM, int WN, int MI, int NJ>
+static void gemm_big_go(GemmP& p, hipStream_t st) {
+  constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, LDS = NST * (TBM + TBN) * ROWB;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<T, NST, WM, WN, MI, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  const int ntn = cdiv(p.N, TBN);
+  p.tiles0 = cdiv(p.M, TBM) * ntn;
+  const int tiles = p.tiles0 + (p.A1 ? cdiv(p.M1, TBM) * ntn : 0);
+  p.group_m = gemm_group_m(TBM);
+  hipLaunchKernelGGL((gemm_nt_big_kernel<T, NST, WM, WN, MI, NJ>), dim3(tiles), dim3(WM * WN * 64), LDS, st, p);
+}
+
 static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stream) {
   const int es = dtype == VLNI_F32 ? 4 : 2, bk = ROWB / es;
   const int nkt = cdiv(p.K, bk);
@@ -658,12 +883,25 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
   p.tiles0 = cdiv(p.M, BM) * ntn;
   const int tiles = p.tiles0 + (p.A1 ? cdiv(p.M1, BM) * ntn : 0);
   dim3 grid(tiles, 1, splits);
+  p.group_m = gemm_group_m(BM);
   static const bool no_glds = getenv("VLNI_NO_GLDS") != nullptr;
   const bool glds_ok = !no_glds && (p.K % bk == 0) && p.kt_per_split >= 3;
   if (variant == 0) variant = (glds_ok && (long)grid.x * grid.z <= 256) ? 3 : 1;
   if (!glds_ok) variant = 1;
+  if (variant >= 6 && (splits > 1 || p.atomic_f32)) variant = 1;       // large tiles: whole-K, plain stores only
   hipStream_t st = (hipStream_t)stream;
-  if (variant >= 2) {
+  if (variant >= 6) {
+    // 6: 256x128 tile, 3 stages; 7: 256x256 tile, 2 stages; 8: 128x256 tile, 3 stages (8 waves each)
+    if (dtype == VLNI_F32) {
+      if (variant == 6) gemm_big_go<float, 3, 4, 2, 2, 2>(p, st);
+      else if (variant == 7) gemm_big_go<float, 2, 2, 4, 4, 2>(p, st);
+      else gemm_big_go<float, 3, 2, 4, 2, 2>(p, st);
+    } else {
+      if (variant == 6) gemm_big_go<__bf16, 3, 4, 2, 2, 2>(p, st);
+      else if (variant == 7) gemm_big_go<__bf16, 2, 2, 4, 4, 2>(p, st);
+      else gemm_big_go<__bf16, 3, 2, 4, 2, 2>(p, st);
+    }
+  } else if (variant >= 2) {
     constexpr int ST = (BM + BN) * ROWB;
     const bool deep = variant == 3 || variant == 4, wide = variant >= 4;
     static bool attr = false;
@@ -702,7 +940,8 @@ static bool gemm_vec_ok(int es, int N, const void* C, long ldc, const void* resi
 }
 
 // variant: 0 = choose by shape, 1 = register-staged 32-KiB kernel (4 blocks/CU), 2 = LDS-DMA 2-stage (64 KiB),
-// 3 = LDS-DMA 3-stage (96 KiB), 4 / 5 = the 3- / 2-stage kernels with 8 waves per tile (2 waves per SIMD). All variants compute the same result; the host side may time them once per shape.
+// 3 = LDS-DMA 3-stage (96 KiB), 4 / 5 = the 3- / 2-stage kernels with 8 waves per tile (2 waves per SIMD), 6 / 7 / 8 = large
+// tiles 256x128 / 256x256 / 128x256 (one block per CU). All variants compute the same result; the host side may time them once per shape.
 extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
                               int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
                               const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,

@@ -27,6 +27,7 @@ class EpisodeTensors:
         self.steps = []
         for s in ep.steps:
             self.steps.append({k: (t(v) if hasattr(v, "dtype") else v) for k, v in s.items()})
+        self.step_ids = [torch.tensor([i], device=dev) for i in range(ep.T)]
         self.hist_masks = []
         for lens in ep.hist_lens:
             n = max(lens)
@@ -64,7 +65,7 @@ def run_episode(model, et, bypass=True, use_aux=True, train_ml=0.2, cosine_weigh
             ob_masks=s["ob_masks"], imagine_embeds=imagine_embeds, imagine_masks=et.imagine_masks)
         ml_loss = ml_loss + criterion(logits, s["target"])
         h = model("history", hist_img_feats=s["hist_img_feats"], hist_ang_feats=s["hist_ang_feats"],
-                  ob_step_ids=torch.tensor([t], device=et.txt_ids.device),
+                  ob_step_ids=et.step_ids[t],
                   hist_pano_img_feats=s["hist_pano_img_feats"],
                   hist_pano_ang_feats=s["hist_pano_ang_feats"])
         hist.append(h)

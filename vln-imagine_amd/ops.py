@@ -56,11 +56,12 @@ def _rows(t):
 # =====================================================================================
 #  raw kernel wrappers (no autograd)
 # =====================================================================================
-# Per-shape kernel choice: the three GEMM pipelines (register-staged 4 blocks/CU, LDS-DMA 2-stage, LDS-DMA 3-stage)
-# compute identical results; which is fastest depends on how the tile count fills 256 CUs. The first call of a shape
+# Per-shape kernel choice: the GEMM pipelines (register-staged 4 blocks/CU, LDS-DMA 2-/3-stage with 4 or 8 waves on 128x128
+# tiles, LDS-DMA large tiles 256x128 / 256x256 / 128x256) compute identical results; which is fastest depends on how the tile
+# count fills 256 CUs and on how many operand bytes each CU pulls per output. The first call of a shape
 # times each once with HIP events (a few hundred microseconds) and the winner is cached for the life of the process.
 AUTOTUNE = True
-GEMM_VARIANTS = (1, 2, 3, 4, 5)
+GEMM_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 8)
 _GEMM_BEST = {}
 
 
@@ -84,10 +85,12 @@ def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_s
         drop = None
     args = (a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K, drop)
     variant = 0
-    if AUTOTUNE and not atomic and M >= 512 and not torch.cuda.is_current_stream_capturing():
+    if AUTOTUNE and not atomic and M >= 512:
         key = (a.dtype, M, N, K, act, dact, residual is not None, preact is not None)
         variant = _GEMM_BEST.get(key)
-        if variant is None:
+        if variant is None and torch.cuda.is_current_stream_capturing():
+            variant = 0                                                     # no timing trials inside a graph capture
+        elif variant is None:
             best = (float("inf"), 0)
             for v in GEMM_VARIANTS:
                 _gemm_call(v, *args)                                    # warm
@@ -125,10 +128,12 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
     cargs = (_dt(a0), ptr2(a), ld2(a), ptr2(b), ld2(b), ptr2(outs), ld2(outs), _arr(ctypes.c_int, (M0, M1)), N, K,
              ptr2(bias), act, ptr2(residual), ld2(residual), ptr2(preact), ld2(preact), ptr2(dact_src), ld2(dact_src), dact)
     variant = 0
-    if AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+    if AUTOTUNE:
         key = (a0.dtype, M0, M1, N, K, act, dact, residual[0] is not None, preact[0] is not None)
         variant = _GEMM_BEST.get(key)
-        if variant is None:
+        if variant is None and torch.cuda.is_current_stream_capturing():
+            variant = 0
+        elif variant is None:
             best = (float("inf"), 0)
             for v in GEMM_VARIANTS:
                 _lib.call("vlni_gemm_nt_dual", *cargs, v, drop[0] if drop else 0.0, seeds, _st())
@@ -1081,6 +1086,33 @@ class _RowDot(torch.autograd.Function):
         _lib.call("vlni_rowdot_bwd", _dt(h2), dl.data_ptr(), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(m8),
                   dh.data_ptr(), dh.stride(0), dw.data_ptr(), _p(dbias), rows, H, _st())
         return dh.view(ctx.shp), dw.view(w.shape), dbias, None
+
+
+class _DuetFuse(torch.autograd.Function):
+    """fused = global + local logits scattered onto map nodes (plan = (src [B,G] int32, bw [B,V] uint8))."""
+
+    @staticmethod
+    def forward(ctx, gl, ll, src, bw):
+        gl, ll = _chk(gl, "global_logits").float().contiguous(), ll.float().contiguous()
+        (B, G), V = gl.shape, ll.shape[1]
+        assert src.shape == (B, G) and bw.shape == (B, V) and src.dtype == torch.int32 and bw.dtype == torch.uint8
+        out = torch.empty_like(gl)
+        _lib.call("vlni_duet_fuse_fwd", gl.data_ptr(), ll.data_ptr(), src.data_ptr(), bw.data_ptr(), out.data_ptr(), B, G, V, _st())
+        ctx.save_for_backward(src, bw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        src, bw = ctx.saved_tensors
+        dout = dout.float().contiguous()
+        (B, G), V = dout.shape, bw.shape[1]
+        dll = torch.empty((B, V), dtype=torch.float32, device=dout.device)
+        _lib.call("vlni_duet_fuse_bwd", dout.data_ptr(), src.data_ptr(), bw.data_ptr(), dll.data_ptr(), B, G, V, _st())
+        return dout, dll, None, None
+
+
+def duet_fuse(gl, ll, src, bw):
+    return _DuetFuse.apply(gl, ll, src, bw)
 
 
 class _CrossEntropySum(torch.autograd.Function):

@@ -73,7 +73,10 @@ class FlatTrainer:
         self.max_norm = max_norm
         self.step_no = 0
         self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.coef = torch.ones(1, dtype=torch.float32, device=dev)
+        # everything that changes from step to step lives on the device, so a captured step replays correctly:
+        # state = [clip factor, 1-beta1^t, 1-beta2^t, t]; lr_dev[0] = learning rate (set_lr() for schedules)
+        self.state = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
         self.chunk = chunk_mb * (1 << 20) // 4
         self.grad_comm_dtype = grad_comm_dtype
         ops.SHADOWS.invalidate()
@@ -92,17 +95,66 @@ class FlatTrainer:
         self.flush()
         allreduce_mean_(self.flat_g, self.chunk, self.grad_comm_dtype)
 
+    def set_lr(self, lr):
+        self.lr_dev.fill_(lr)
+
     def step(self):
         self.flush()
         st = torch.cuda.current_stream().cuda_stream
         self.step_no += 1
-        lr, b1, b2, eps, wd = self.hp
+        _, b1, b2, eps, wd = self.hp
         self.sumsq.zero_()
         _lib.call("vlni_sumsq", self.flat_g.data_ptr(), self.n, self.sumsq.data_ptr(), st)
-        _lib.call("vlni_clip_coef", self.sumsq.data_ptr(), self.max_norm, self.coef.data_ptr(), st)
-        _lib.call("vlni_adamw_step", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                  0, self.n, lr, b1, b2, eps, wd, self.step_no, self.coef.data_ptr(), st)
+        _lib.call("vlni_optim_prepare", self.sumsq.data_ptr(), self.max_norm, b1, b2, self.state.data_ptr(), st)
+        _lib.call("vlni_adamw_step_dev", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                  0, self.n, self.lr_dev.data_ptr(), b1, b2, eps, wd, self.state.data_ptr(), st)
         ops.SHADOWS.invalidate()
 
     def grad_norm(self):
         return float(self.sumsq.sqrt())
+
+    def capture(self, fwd_bwd, warmup=1):
+        """Captures the training step into two hipGraphs and returns a callable that replays them.
+
+        fwd_bwd() runs forward + backward (on fixed-shape, fixed-address inputs; refill them in place between calls) and
+        returns the loss tensor. Graph 1 = zero_grad + fwd_bwd + deferred weight-gradient flush (including the bf16 shadow
+        refresh of every parameter), graph 2 = clip + AdamW; the gradient all-reduce runs eagerly between the two, so RCCL is
+        never part of a capture. `warmup` REAL steps run first on a side stream (lazy initialisation, GEMM autotune).
+        Drop every reference to earlier losses / outputs before calling this: an autograd graph that is still alive keeps its
+        AccumulateGrad nodes on the old stream, which breaks the capture.
+        One replay costs two graph launches instead of ~3000 kernel launches from Python."""
+        return GraphedStep(self, fwd_bwd, warmup)
+
+
+class GraphedStep:
+    def __init__(self, trainer, fwd_bwd, warmup=1):
+        import gc
+        self.trainer = trainer
+        gc.collect()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                trainer.zero_grad()
+                fwd_bwd()
+                trainer.allreduce_grads()
+                trainer.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        ops.SHADOWS.invalidate()               # every shadow refresh must be recorded inside graph 1
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            trainer.zero_grad()
+            self.loss = fwd_bwd()
+            trainer.flush()
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+            trainer.step()
+        trainer.step_no -= 1                   # recorded, not executed
+
+    def __call__(self):
+        self.g_fb.replay()
+        allreduce_mean_(self.trainer.flat_g, self.trainer.chunk, self.trainer.grad_comm_dtype)
+        self.g_opt.replay()
+        self.trainer.step_no += 1
+        return self.loss
