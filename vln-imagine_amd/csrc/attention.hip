@@ -330,6 +330,33 @@ __device__ __forceinline__ void stage_bf16(char* dst, const __bf16* src, long ld
   }
 }
 
+// The same staging with compile-time trip counts, split into "issue every global load" and "write LDS": all loads of a phase
+// are in flight together (one exposed latency per phase instead of one per loop iteration), and the loads of the NEXT query
+// chunk are issued before the MFMA phase of the current one.
+template <int NTILE, int NTH>
+__device__ __forceinline__ void tile_load(uint4 (&v)[NTILE * 8 / NTH], const __bf16* src, long ld, int row0, int nvalid, int tid) {
+#pragma unroll
+  for (int i = 0; i < NTILE * 8 / NTH; ++i) {
+    const int idx = tid + i * NTH, row = idx >> 3, ch = idx & 7;
+    v[i] = row < nvalid ? *(const uint4*)(src + (long)(row0 + row) * ld + ch * 8) : make_uint4(0, 0, 0, 0);
+  }
+}
+template <int NTILE, int NTH>
+__device__ __forceinline__ void tile_store(char* dst, const uint4 (&v)[NTILE * 8 / NTH], int tid) {
+#pragma unroll
+  for (int i = 0; i < NTILE * 8 / NTH; ++i) {
+    const int idx = tid + i * NTH;
+    *(uint4*)(dst + boff(idx >> 3, idx & 7)) = v[i];
+  }
+}
+__device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b) {
+  const bf16x8 x = __builtin_bit_cast(bf16x8, a), y = __builtin_bit_cast(bf16x8, b);
+  float t = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t += (float)x[j] * (float)y[j];
+  return t;
+}
+
 // forward: block = 4 waves x 32 query rows; grid = (ceil(Sq/128), B*nh)
 template <int NKT>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
@@ -340,14 +367,17 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
   const int bh = blockIdx.y, b = bh / p.nh, hd = bh % p.nh;
   const int q0 = blockIdx.x * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
-  stage_bf16(Ks, (const __bf16*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, 256);
-  stage_bf16(Vs, (const __bf16*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, 256);
   const int qg = q0 + wave * 32 + r;
   bf16x8 qf[4];
   {
+    uint4 kreg[NKT], vreg[NKT];
+    tile_load<SKP, 256>(kreg, (const __bf16*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, tid);
+    tile_load<SKP, 256>(vreg, (const __bf16*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, tid);
     const __bf16* qp = (const __bf16*)p.q + ((long)b * p.Sq + min(qg, p.Sq - 1)) * p.ldq + hd * 64 + 8 * hh;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qp + 16 * kk);
+    tile_store<SKP, 256>(Ks, kreg, tid);
+    tile_store<SKP, 256>(Vs, vreg, tid);
   }
   __syncthreads();
   if (q0 + wave * 32 >= p.Sq) return;                 // whole wave beyond the last query row (no barrier after this point)
@@ -426,8 +456,10 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
 }
 
 // backward: block = NW waves (4, or 8 for 129..256 keys); wave w owns key tile w; grid = B*nh; query rows in chunks of 64
-template <int NKT, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(AttnP p) {
+// BIAS / DROP are compile-time: the per-element bias / dbias addresses and the dropout hash of 16 x 2 elements otherwise stay
+// live next to the accumulators and push the kernel to ~470 registers (one 4-wave block per CU).
+template <int NKT, int NW, bool BIAS, bool DROP>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_bf16_kernel(AttnP p) {
   constexpr int NTH = NW * 64;
   constexpr int SKP = NKT * 32, DSS = SKP * 2 + 16;       // dS row stride in bytes (odd number of 16-B slots)
   __shared__ __attribute__((aligned(16))) char smem[2 * SKP * 128 + 2 * 64 * 128 + 64 * DSS + 2 * 64 * 4];
@@ -441,8 +473,28 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(AttnP p) {
   const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1, half8 = 8 * (pp & 1);
-  stage_bf16(Ks, (const __bf16*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, NTH);
-  stage_bf16(Vs, (const __bf16*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, NTH);
+  constexpr int QPT = 64 * 8 / NTH;                       // 16-B pieces of a 64-row chunk per thread
+  const __bf16* const qsrc = (const __bf16*)p.q + (long)b * p.Sq * p.ldq + hd * 64;
+  const __bf16* const dosrc = (const __bf16*)p.dout + (long)b * p.Sq * p.lddo + hd * 64;
+  const __bf16* const osrc = (const __bf16*)p.out + (long)b * p.Sq * p.ldo + hd * 64;
+  const float* const lsesrc = p.lse + ((long)b * p.nh + hd) * p.Sq;
+  uint4 qreg[QPT], doreg[QPT], oreg[QPT];
+  float lsereg = 0.f;
+  auto chunk_load = [&](int q0) {                          // every global load of one 64-query chunk, nothing waits here
+    const int nq = min(64, p.Sq - q0);
+    tile_load<64, NTH>(qreg, qsrc, p.ldq, q0, nq, tid);
+    tile_load<64, NTH>(doreg, dosrc, p.lddo, q0, nq, tid);
+    tile_load<64, NTH>(oreg, osrc, p.ldo, q0, nq, tid);
+    lsereg = (tid < nq) ? lsesrc[q0 + tid] : 0.f;
+  };
+  {
+    uint4 kreg[SKP * 8 / NTH], vreg[SKP * 8 / NTH];
+    tile_load<SKP, NTH>(kreg, (const __bf16*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, tid);
+    tile_load<SKP, NTH>(vreg, (const __bf16*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, tid);
+    chunk_load(0);
+    tile_store<SKP, NTH>(Ks, kreg, tid);
+    tile_store<SKP, NTH>(Vs, vreg, tid);
+  }
   __syncthreads();
   const bool owner = wave < NKT;
   const int key = wave * 32 + r;
@@ -463,30 +515,24 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(AttnP p) {
 
   for (int q0 = 0; q0 < p.Sq; q0 += 64) {
     const int nq = min(64, p.Sq - q0);
-    stage_bf16(Qs, (const __bf16*)p.q + (long)b * p.Sq * p.ldq + hd * 64, p.ldq, q0, nq, 64, tid, NTH);
-    stage_bf16(dOs, (const __bf16*)p.dout + (long)b * p.Sq * p.lddo + hd * 64, p.lddo, q0, nq, 64, tid, NTH);
-    {
-      // delta[q] = <dO[q], O[q]>: 64/NW rows per wave, all loads issued before the first reduction
-      constexpr int RPW = 64 / NW;
-      float dl[RPW];
+    tile_store<64, NTH>(Qs, qreg, tid);
+    tile_store<64, NTH>(dOs, doreg, tid);
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int row = wave + NW * i;
-        const long qrow = (long)b * p.Sq + q0 + min(row, nq - 1);
-        dl[i] = (float)((const __bf16*)p.dout)[qrow * p.lddo + hd * 64 + lane] * (float)((const __bf16*)p.out)[qrow * p.ldo + hd * 64 + lane];
-      }
-      const float lv = (lane < RPW && wave + NW * lane < nq) ? p.lse[((long)b * p.nh + hd) * p.Sq + q0 + wave + NW * lane] : 0.f;
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const float t = wave_sum(dl[i]);
-        if (lane == 0) del_s[wave + NW * i] = (wave + NW * i < nq) ? t : 0.f;
-      }
-      if (lane < RPW) lse_s[wave + NW * lane] = lv;
+    for (int i = 0; i < QPT; ++i) {                        // delta[q] = <dO[q], O[q]>: the 8 pieces of a row sit in 8 adjacent lanes
+      float t = dot8_bf16(doreg[i], oreg[i]);
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      t += __shfl_xor(t, 4, 64);
+      if ((tid & 7) == 0) del_s[(tid + i * NTH) >> 3] = t;   // rows >= nq were loaded as zeros
     }
+    if (tid < 64) lse_s[tid] = lsereg;
     __syncthreads();
-
+    if (q0 + 64 < p.Sq) chunk_load(q0 + 64);               // in flight under the MFMA phases below
     if (owner) {
-#pragma unroll
+      // one base per chunk + 32-bit row offsets (64-bit per-element addresses cost ~80 registers)
+      const float* const bias_b = BIAS ? p.bias + ((long)b * p.Sq + q0) * p.Sk + key : nullptr;
+      float* const dbias_b = (BIAS && p.dbias) ? p.dbias + ((long)b * p.Sq + q0) * p.Sk + key : nullptr;
+#pragma unroll 1
       for (int qt = 0; qt < 2; ++qt) {
         f32x16 s, dp;
 #pragma unroll
@@ -502,10 +548,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(AttnP p) {
           float pv = 0.f, ds = 0.f, pdrop = 0.f;
           if (key < p.Sk && ql < nq) {
             float sv = s[x] * p.scale + kmv;
-            if (p.bias) sv += p.bias[((long)b * p.Sq + q0 + ql) * p.Sk + key];
+            if (BIAS) sv += bias_b[ql * p.Sk];
             pv = __expf(sv - lse_s[ql]);
             float dpx = dp[x];
-            if (p.drop_thr) {
+            if (DROP) {
               const float ms = drop_scale((unsigned)((b * p.nh + hd) * p.Sq + q0 + ql) * (unsigned)p.Sk + key, p.drop_seed,
                                           p.drop_thr, p.drop_inv);
               dpx *= ms;                      // dP = dP_dropped * mask / keep
@@ -514,7 +560,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(AttnP p) {
               pdrop = pv;
             }
             ds = pv * (dpx - del_s[ql]);
-            if (p.dbias) atomicAdd(p.dbias + ((long)b * p.Sq + q0 + ql) * p.Sk + key, ds);
+            if (BIAS && dbias_b) atomicAdd(dbias_b + ql * p.Sk, ds);
           }
           s[x] = pdrop;
           dp[x] = ds * p.scale;
@@ -576,7 +622,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(AttnP p) {
 template <int NKT>
 int launch_bf16(const AttnP& p, bool bwd, hipStream_t st) {
   constexpr int NW = NKT <= 4 ? 4 : 8;
-  if (bwd) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, NW>), dim3(p.B * p.nh), dim3(NW * 64), 0, st, p);
+  if (bwd) {
+    const bool bias = p.bias != nullptr || p.dbias != nullptr, drop = p.drop_thr != 0;
+    if (bias && p.bias == nullptr) return -1;
+    if (bias && drop) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, NW, true, true>), dim3(p.B * p.nh), dim3(NW * 64), 0, st, p);
+    else if (bias) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, NW, true, false>), dim3(p.B * p.nh), dim3(NW * 64), 0, st, p);
+    else if (drop) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, NW, false, true>), dim3(p.B * p.nh), dim3(NW * 64), 0, st, p);
+    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<NKT, NW, false, false>), dim3(p.B * p.nh), dim3(NW * 64), 0, st, p);
+  }
   else hipLaunchKernelGGL((attn_fwd_bf16_kernel<NKT>), dim3(cdiv(p.Sq, 128), p.B * p.nh), dim3(256), 0, st, p);
   return 0;
 }
@@ -597,7 +650,7 @@ int launch_fwd(const AttnP& p, hipStream_t st) {
   const size_t lds = (size_t)(2 * NKT * 32 * LD + 64 * LD) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL((attn_fwd_kernel<T, NKT>), dim3(cdiv(p.Sq, 64), p.B * p.nh), dim3(128), lds, st, p);
@@ -608,7 +661,7 @@ int launch_bwd(const AttnP& p, hipStream_t st) {
   const size_t lds = (size_t)(2 * NKT * 32 * LD + 2 * 64 * LD + 64 * (NKT * 32 + 1) + 128) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL((attn_bwd_kernel<T, NKT>), dim3(p.B * p.nh), dim3(256), lds, st, p);
