@@ -374,7 +374,7 @@ def test_wgrad_tn_bf16_exact_and_random(ops, M, N, K):
     assert _err(cs2, dy.double().sum(0)) < 2e-3 * max(1.0, dy.double().sum(0).abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
 def test_wgrad_tn_lds_dma_variants_exact(ops, variant):
     """LDS-DMA pipelines of the grouped transposing-read wgrad (zero page for row tails, MFMA-ones bias gradient): exact on
     small integers over several ragged segments."""

@@ -842,6 +842,133 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_glds_kernel(TnP p) {
   }
 }
 
+// 256 x 256 output tile of the same weight-gradient contraction: 8 waves as 2 (N) x 4 (K), a wave owns 128 x 64 outputs
+// (8 accumulators), half the L2->LDS bytes and half the LDS-read bytes per MFMA of the 128 x 128 tile. A stage holds four
+// [64 rows][128 cols] sub-tiles (A left/right, B left/right) in the layout of the kernel above; 2 stages = 128 KiB.
+template <int NST>
+__global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnP p) {
+  constexpr int BR = 64, SUB = BR * 256, STAGE = 4 * SUB, NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int ntk = (p.K + 255) / 256;
+  const int n0 = (wgid / ntk) * 256, k0 = (wgid % ntk) * 256;
+  const int nmt = p.mt_start[p.nseg];
+  const int mt0 = blockIdx.z * p.mt_per_split;
+  const int nk = min(nmt, mt0 + p.mt_per_split) - mt0;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, r = lane & 31, h = lane >> 5;
+
+  // a sub-tile is 16 LDS-DMA instructions (4 rows x 256 B each); 8 waves x 2 instructions per sub-tile
+  int srow[2], acol[2][2], bcol[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * NW + wave) * 4 + (lane >> 4);
+    const int c = (lane & 15) ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    srow[i] = row;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      acol[u][i] = (n0 + u * 128 + c * 8 < p.N) ? n0 + u * 128 + c * 8 : -1;
+      bcol[u][i] = (k0 + u * 128 + c * 8 < p.K) ? k0 + u * 128 + c * 8 : -1;
+    }
+  }
+  using gptr = const __attribute__((address_space(1))) void*;
+  using lptr = __attribute__((address_space(3))) void*;
+  int seg = 0;
+  auto issue = [&](int t, int stage) {
+    const int mt = mt0 + t;
+    while (mt >= p.mt_start[seg + 1]) ++seg;
+    const int segM = p.segM[seg], r0 = (mt - p.mt_start[seg]) * BR;
+    const __bf16* A = p.A[seg];
+    const __bf16* B = p.B[seg];
+    char* sa = dsmem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = r0 + srow[i];
+      const bool rok = row < segM;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const void* pa = (rok && acol[u][i] >= 0) ? (const void*)(A + (long)row * p.lda + acol[u][i]) : (const void*)g_zero_page;
+        const void* pb = (rok && bcol[u][i] >= 0) ? (const void*)(B + (long)row * p.ldb + bcol[u][i]) : (const void*)g_zero_page;
+        __builtin_amdgcn_global_load_lds((gptr)pa, (lptr)(sa + u * SUB + i * NW * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(sa + (2 + u) * SUB + i * NW * 1024), 16, 0, 0);
+      }
+    }
+  };
+  const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
+  const int frow = 8 * h + qq, half8 = 8 * (pp & 1);
+  const int cha = (16 * cb) / 8 + (pp >> 1);                         // + 4 * i: 32-column block i of A sub-tile wr
+  const int chb = ((wc & 1) * 64 + 16 * cb) / 8 + (pp >> 1);         // + 4 * j inside B sub-tile wc >> 1
+
+  f32x16 acc[4][2], acs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acs[i][x] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+  }
+  const bool do_cs = p.colsum != nullptr && k0 == 0 && wc == 0;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+  if (nk > 0) {
+    issue(0, 0);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (t + 1 < nk) issue(t + 1, stage ^ 1);
+      const char* As = dsmem + stage * STAGE + wr * SUB;
+      const char* Bs = dsmem + stage * STAGE + (2 + (wc >> 1)) * SUB;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 a[4], b[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = tr_frag(Bs, 16 * kk + frow, chb + 4 * j, half8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = tr_frag(As, 16 * kk + frow, cha + 4 * i, half8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        if (do_cs) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, acs[i], 0, 0, 0);
+        }
+      }
+      stage ^= 1;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = k0 + wc * 64 + j * 32 + r;
+    if (col >= p.K) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int row = n0 + wr * 128 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+        if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
+      }
+  }
+  if (do_cs && r == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) {
+        const int row = n0 + wr * 128 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+        if (row < p.N) atomicAdd(p.colsum + row, acs[i][x]);
+      }
+  }
+}
+
 }  // namespace
 
 static int gemm_check_one(int es, const void* A, long lda, const void* B, long ldb, long ldc, int M, int N, int K) {
@@ -1007,7 +1134,7 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
 // C[N,K] += sum_s A_s[M_s,N]^T B_s[M_s,K] (bf16 operands as they lie in memory, float32 atomic accumulation, split over
 // rows); colsum (optional, [N]) += column sums of all A_s (the bias gradient). nseg <= 16 row segments share lda/ldb.
 // Replaces autograd's weight-gradient matmuls (one launch per parameter per episode when the segments are the T steps).
-// variant: 0/1 = register-staged kernel, 2 = LDS-DMA 2-stage, 3 = 3-stage, 4 / 5 = 3- / 2-stage with 8 waves (identical sums up
+// variant: 0/1 = register-staged kernel, 2 = LDS-DMA 2-stage, 3 = 3-stage, 4 / 5 = 3- / 2-stage with 8 waves, 6 = 256 x 256 tiles (identical sums up
 // to float atomics order).
 extern "C" int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
                                            float* C, long ldc, int N, int K, float* colsum, int split, int variant, void* stream) {
@@ -1028,7 +1155,15 @@ extern "C" int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const
   p.mt_per_split = cdiv(nmt, split);
   dim3 grid(cdiv(N, BM) * cdiv(K, BN), 1, cdiv(nmt, p.mt_per_split));
   hipStream_t st = (hipStream_t)stream;
-  if (variant >= 2 && p.mt_per_split >= 3) {
+  if (variant == 6) {                       // 256 x 256 tiles, 2 x 64 KiB stages
+    constexpr int LDS = 2 * 4 * 64 * 256;
+    static bool attr6 = false;
+    if (!attr6) {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      attr6 = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_big_kernel<2>), dim3(cdiv(N, 256) * cdiv(K, 256), 1, grid.z), dim3(512), LDS, st, p);
+  } else if (variant >= 2 && p.mt_per_split >= 3) {
     constexpr int ST = 2 * 64 * 256;
     static bool attr = false;
     if (!attr) {

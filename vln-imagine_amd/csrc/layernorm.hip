@@ -55,15 +55,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
 }
 
 // dx = rstd * (g*dy - mean_H(g*dy) - xhat * mean_H(g*dy*xhat)); dgamma += sum_rows dy*xhat; dbeta += sum_rows dy
+// backward: 16 waves per block so that the 2*H float atomics per block (dgamma / dbeta, every block into the same 6 KiB)
+// are issued by <= 128 blocks instead of 512
+constexpr int BWAVES = 16;
 template <typename T, int NC>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx,
+__global__ __launch_bounds__(BWAVES * 64) void ln_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx,
                                                      const float* __restrict__ g, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, T* __restrict__ dx, long lddx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
                                                      const T* __restrict__ dres, long lddres, T* __restrict__ dxd,
                                                      long lddxd, unsigned dthr, unsigned dseed, float dinv) {
   constexpr int H = 256 * NC;
-  __shared__ float red[WAVES][2][H];
+  __shared__ float red[BWAVES][2][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gv[NC], pg[NC], pb[NC];
 #pragma unroll
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
     pg[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     pb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
+  for (int row = blockIdx.x * BWAVES + wave; row < rows; row += gridDim.x * BWAVES) {
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[NC], d[NC];
     float s1 = 0.f, s2 = 0.f;
@@ -116,10 +119,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, l
       red[wave][1][c * 256 + lane * 4 + j] = pb[c][j];
     }
   __syncthreads();
-  for (int i = threadIdx.x; i < H; i += 256) {
+  for (int i = threadIdx.x; i < H; i += BWAVES * 64) {
     float a = 0.f, bsum = 0.f;
 #pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
+    for (int w = 0; w < BWAVES; ++w) {
       a += red[w][0][i];
       bsum += red[w][1][i];
     }
@@ -197,16 +200,16 @@ __global__ __launch_bounds__(256) void sum_ln_fwd_kernel(SumP sp, const float* _
 }
 
 int ln_grid(int rows) { return max(1, min(cdiv(rows, WAVES), 2048)); }
-// backward ends with 2*H float atomics per block (dgamma/dbeta): keep the grid at ~2 blocks per CU
-int ln_bwd_grid(int rows) { return max(1, min(cdiv(rows, WAVES), 512)); }
+int ln_bwd_grid(int rows) { return max(1, min(cdiv(rows, BWAVES), 128)); }
 
 }  // namespace
 
-#define LN_DISPATCH(KERNEL, T, ...) LN_DISPATCH_G(ln_grid(rows), KERNEL, T, __VA_ARGS__)
-#define LN_DISPATCH_G(GRID, KERNEL, T, ...)                                                                      \
+#define LN_DISPATCH(KERNEL, T, ...) LN_DISPATCH_GB(ln_grid(rows), 256, KERNEL, T, __VA_ARGS__)
+#define LN_DISPATCH_G(GRID, KERNEL, T, ...) LN_DISPATCH_GB(GRID, BWAVES * 64, KERNEL, T, __VA_ARGS__)
+#define LN_DISPATCH_GB(GRID, BLOCK, KERNEL, T, ...)                                                              \
   do {                                                                                                   \
     const int nc = H / 256;                                                                              \
-    dim3 grid(GRID), block(256);                                                                         \
+    dim3 grid(GRID), block(BLOCK);                                                                       \
     hipStream_t st = (hipStream_t)stream;                                                                \
     if (nc == 3) hipLaunchKernelGGL((KERNEL<T, 3>), grid, block, 0, st, __VA_ARGS__);                    \
     else if (nc == 2) hipLaunchKernelGGL((KERNEL<T, 2>), grid, block, 0, st, __VA_ARGS__);               \

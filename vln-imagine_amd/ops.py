@@ -391,6 +391,7 @@ def _bgrad_to(params, dy):
 # queued during backward and reduced by ONE grouped transposing-read GEMM per parameter at flush time, i.e. one launch
 # with a T-times longer reduction instead of T short split-K launches. 288 GB of HBM make keeping dY alive free.
 DEFER_WGRAD = False
+TN_BIG = True            # 256 x 256 tiles for episode-long reductions (+10..26 % there, tools/tn_probe.py)
 TN_VARIANT = 5          # LDS-DMA 2-stage, 8 waves: fastest of the five on every episode-level shape (tools/tn_probe.py)
 _WQ = {}
 
@@ -405,11 +406,14 @@ def flush_wgrads():
             pa = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
             pb = (ctypes.c_void_p * n)(*[x.data_ptr() for _, x in chunk])
             pm = (ctypes.c_int * n)(*[d.shape[0] for d, _ in chunk])
-            tiles = ((N + 127) // 128) * ((K + 127) // 128)
             nmt = sum((d.shape[0] + 63) // 64 for d, _ in chunk)
-            split = max(1, min(8, nmt // 8))
+            variant, split = TN_VARIANT, max(1, min(8, nmt // 8))
+            if TN_BIG and nmt >= 256 and N >= 256 and K >= 256:
+                # long reductions (a whole episode of rows): 256 x 256 tiles, one block per CU, ~252 blocks in all
+                tiles = ((N + 255) // 256) * ((K + 255) // 256)
+                variant, split = 6, max(1, min(nmt // 8, round(252 / tiles)))
             _lib.call("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
-                      split, TN_VARIANT, _st())
+                      split, variant, _st())
     _WQ.clear()
 
 
