@@ -191,10 +191,12 @@ def main():
         torch.cuda.synchronize()
 
     log(f"model + episode ready on {dev}; warmup {args.warmup}, steps {args.steps}, dtype {args.dtype}")
+    eager_s = float("inf")
     for i in range(args.warmup):
         tw = time.perf_counter()
         loss = step()
         torch.cuda.synchronize()
+        eager_s = min(eager_s, time.perf_counter() - tw)
         log(f"warmup {i}: {1e3 * (time.perf_counter() - tw):.1f} ms loss {float(loss.detach()):.5f}")
     launch = "eager (one kernel launch per op from Python)"
     if args.graph:
@@ -206,16 +208,30 @@ def main():
         loss = None                                 # drop the last eager autograd graph (its AccumulateGrad nodes) before capturing
         import gc
         gc.collect()
+        slow, captured = True, None
         try:
-            step = trainer.capture(fwd_bwd, warmup=1)
-            for _ in range(2):
-                loss = step()
+            captured = trainer.capture(fwd_bwd, warmup=1)
+            loss = captured()
             torch.cuda.synchronize()
-            launch = "hipGraph replay (fwd+bwd+wgrad | clip+AdamW), all-reduce eager between"
-            log(f"step captured into hipGraphs; loss {float(loss):.5f}")
+            tg = time.perf_counter()
+            for _ in range(2):
+                loss = captured()
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg) / 2
+            log(f"step captured into hipGraphs; loss {float(loss.detach()):.5f}; replay {1e3 * tg:.1f} ms vs eager {1e3 * eager_s:.1f} ms")
+            slow = tg > 1.3 * eager_s                 # never seen on a dedicated GPU; two processes SHARING one GPU replay pathologically slowly
         except Exception as e:                      # keep measuring: fall back to the eager step and say so
-            log(f"graph capture failed ({type(e).__name__}: {e}); timing the eager step")
+            log(f"graph capture failed ({type(e).__name__}: {e})")
+        if world > 1:                                 # one decision for the whole job (every rank reaches this all-reduce)
+            flag = torch.tensor([1.0 if slow else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            slow = bool(flag.item() > 0)
+        if slow:
+            log("no usable graph replay on this box: timing the eager step")
             step = eager_step
+        else:
+            step = captured
+            launch = "hipGraph replay (fwd+bwd+wgrad | clip+AdamW), all-reduce eager between"
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -310,8 +326,12 @@ def main():
             trainer.step()
             return out["loss"]
 
+        eager_tb, eager_tb_s = step_tb, float("inf")
         for _ in range(max(2, args.warmup)):
+            tw = time.perf_counter()
             step_tb()
+            torch.cuda.synchronize()
+            eager_tb_s = min(eager_tb_s, time.perf_counter() - tw)
         if args.graph and launch.startswith("hipGraph"):
             import gc
             gc.collect()
@@ -320,11 +340,22 @@ def main():
                 out = run_episode_time_batched(model, et, criterion=ops.cross_entropy_sum)
                 out["loss"].backward()
                 return out["loss"]
+            slow, cap_tb = True, None
             try:
-                step_tb = trainer.capture(fwd_bwd_tb, warmup=1)
-                step_tb()
+                cap_tb = trainer.capture(fwd_bwd_tb, warmup=1)
+                cap_tb()
+                torch.cuda.synchronize()
+                tw = time.perf_counter()
+                cap_tb()
+                torch.cuda.synchronize()
+                slow = time.perf_counter() - tw > 1.3 * eager_tb_s
             except Exception as e:
                 log(f"time-batched graph capture failed ({type(e).__name__}: {e}); eager")
+            if world > 1:
+                flag = torch.tensor([1.0 if slow else 0.0], device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                slow = bool(flag.item() > 0)
+            step_tb = eager_tb if slow else cap_tb
         fence()
         t1 = time.perf_counter()
         for _ in range(args.steps):

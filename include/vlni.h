@@ -4,7 +4,7 @@
  * boundary the drop-in keeps is the Python module API (models.vilmodel_cmt.NavCMT,
  * models.vilmodel.GlocalTextPathNavCMT, ...). This header is the operator layer those modules call:
  * plain device pointers + explicit shapes/strides + a hipStream_t (as void*), no torch types, no
- * allocation inside, no global state except the thread-local error string.
+ * allocation inside, no global state except the thread-local error string and the optional dropout seed base.
  * Every function returns 0 (VLNI_OK) or a negative code; the message is vlni_last_error().
  * Row strides (`ld*`) are in ELEMENTS of the tensor's dtype. dtype: 0 = float32, 1 = bfloat16.
  * All reductions accumulate in float32. "R:" = VLN-HAMT/finetune_src/models/vilmodel_cmt.py,
@@ -25,6 +25,10 @@ extern "C" {
 
 const char* vlni_last_error(void);
 int vlni_version(void);
+/* Optional: a device-resident unsigned added to every dropout seed below (0 / never called = seeds used as given). Lets a
+   captured hipGraph draw new masks on every replay: a node of the graph advances *device_ptr, forward and backward nodes of the
+   same replay read the same value. The one piece of process-wide state besides the error string. */
+int vlni_set_dropout_seed_base(const unsigned* device_ptr);
 
 /* C[M,N] = epi(alpha * A[M,K] * B[N,K]^T): replaces nn.Linear forward (R:101-103,145,174,187,327-329,
  * 536-537, 956-960; D:598-655 MLP), its dgrad (B = transposed weight shadow) and, with

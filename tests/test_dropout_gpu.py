@@ -160,3 +160,76 @@ def test_dual_stream_blocks_equal_two_single_blocks(train):
         assert _err(res[0][i], res[1][i]) < 1e-5
     for g0, g1 in zip(res[0][4], res[1][4]):
         assert _err(g0, g1) < 1e-4 * max(1.0, g0.abs().max().item())
+
+
+def test_seed_base_shifts_every_seed():
+    """vlni_set_dropout_seed_base: mask(seed, base) == mask(seed + base, no base), for the mask kernel and a fused block."""
+    from vln_imagine_amd import ops
+    try:
+        ref = _mask(ops, (4096,), 0.3, 1000 + 77)
+        base = torch.full((1,), 77, dtype=torch.int32, device="cuda")
+        ops.set_seed_base(base)
+        assert torch.equal(_mask(ops, (4096,), 0.3, 1000), ref)
+        base.add_(1)
+        assert not torch.equal(_mask(ops, (4096,), 0.3, 1000), ref)
+        # a fused GEMM epilogue and an attention launch follow the base too
+        a = torch.randn(256, 768, device="cuda").bfloat16(); w = (torch.randn(768, 768, device="cuda") * 0.05).bfloat16()
+        q = torch.randn(2 * 40, 768, device="cuda").bfloat16()
+        km = torch.zeros(2, 40, device="cuda")
+        y_b = ops.gemm_nt(a, w, drop=(0.2, 500)).clone()
+        o_b, _ = ops.attn_fwd(q, q, q, 2, 40, 40, km, drop=(0.1, 900))
+        o_b = o_b.clone()
+        ops.set_seed_base(None)
+        y_s = ops.gemm_nt(a, w, drop=(0.2, 500 + 78))
+        o_s, _ = ops.attn_fwd(q, q, q, 2, 40, 40, km, drop=(0.1, 900 + 78))
+        assert torch.equal(y_b, y_s) and torch.equal(o_b, o_s)
+    finally:
+        ops.set_seed_base(None)
+
+
+def test_graph_replay_draws_fresh_masks(monkeypatch):
+    """A captured training step with dropout p > 0: every replay uses new masks (device seed base advanced in-graph) and equals
+    the eager step run with the same base value and the same host seed counter. torch's own dropouts (small tensors: embedding
+    outputs, heads) are switched off here: their Philox offsets are torch's business, the fused kernels' seeds are ours."""
+    monkeypatch.setattr(F, "dropout", lambda x, p=0.5, training=True, inplace=False: x)
+    from tests.golden.variants import hamt_variant_setup
+    from tests.test_hamt_gpu import build_product
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_T3_dense")
+    cfg.hidden_dropout_prob = cfg.attention_probs_dropout_prob = 0.1
+    et = EpisodeTensors(ep, "cuda")
+    try:
+        m = build_product(cfg).train()
+        tr = FlatTrainer(m, lr=1e-3)
+
+        def fwd_bwd(model=None):
+            ops.reseed(4242)                      # the host counter only matters while recording
+            loss = run_episode(model or m, et, criterion=ops.cross_entropy_sum, keep=False)["loss"]
+            loss.backward()
+            return loss
+
+        step = tr.capture(fwd_bwd, warmup=1)
+        p0, m0, v0, st0 = tr.flat_p.clone(), tr.m.clone(), tr.v.clone(), tr.state.clone()
+        l1 = float(step().detach())
+        base1 = int(step.seed_base.item())
+        p1 = tr.flat_p.clone()
+        l2 = float(step().detach())
+        assert int(step.seed_base.item()) == base1 + 7919 and abs(l1 - l2) > 1e-6      # new masks, new loss
+        # eager twin: same start, same base value, same host seeds -> same first step
+        m2 = build_product(cfg).train()
+        tr2 = FlatTrainer(m2, lr=1e-3)
+        tr2.flat_p.copy_(p0); tr2.m.copy_(m0); tr2.v.copy_(v0); tr2.state.copy_(st0)
+        ops.SHADOWS.invalidate()
+        step.seed_base.fill_(base1)
+        tr2.zero_grad()
+        le = fwd_bwd(m2)
+        tr2.step()
+        assert abs(float(le.detach()) - l1) < 2e-4 * max(1.0, abs(l1)), (float(le.detach()), l1)
+        d = (tr2.flat_p - p1).abs()
+        assert d.max().item() < 2.5e-3 and d.mean().item() < 1e-5, (d.max().item(), d.mean().item())
+    finally:
+        ops.set_seed_base(None)
+        ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
+        ops._WQ.clear()

@@ -46,6 +46,7 @@ struct AttnP {
   float* lse;           // [B, nh, Sq]
   int B, nh, Sq, Sk;
   float scale;
+  const unsigned* seed_base;                     // effective seed = drop_seed + *seed_base (vlni_set_dropout_seed_base)
   unsigned drop_thr, drop_seed; float drop_inv;   // attention-probability dropout (idx = ((b*nh+h)*Sq+q)*Sk+key)
   // backward only
   const void* dout; long lddo;
@@ -66,6 +67,7 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(AttnP p) {
   const int bh = blockIdx.y, b = bh / p.nh, hd = bh % p.nh;
   const int q0 = blockIdx.x * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
 
   stage_rows<T>(Ks, (const T*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, 128);
   stage_rows<T>(Vs, (const T*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, 128);
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(128) void attn_fwd_kernel(AttnP p) {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int x = 0; x < 16; ++x) s[kt][x] *= drop_scale(base + kt * 32 + acc_row(x, hh), p.drop_seed, p.drop_thr, p.drop_inv);
+      for (int x = 0; x < 16; ++x) s[kt][x] *= drop_scale(base + kt * 32 + acc_row(x, hh), dseed, p.drop_thr, p.drop_inv);
   }
 
   T* out = (T*)p.out + ((long)b * p.Sq + qg) * p.ldo + hd * 64;
@@ -164,6 +166,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
   float* del_s = lse_s + 64;              // [64]
   const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
 
   stage_rows<T>(Ks, (const T*)p.k + (long)b * p.Sk * p.ldk + hd * 64, p.ldk, 0, p.Sk, SKP, tid, 256);
   stage_rows<T>(Vs, (const T*)p.v + (long)b * p.Sk * p.ldv + hd * 64, p.ldv, 0, p.Sk, SKP, tid, 256);
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnP p) {
             pv = __expf(sv - lse_s[ql]);
             float dpx = dp[x];
             if (p.drop_thr) {
-              const float ms = drop_scale((unsigned)((b * p.nh + hd) * p.Sq + q0 + ql) * (unsigned)p.Sk + key, p.drop_seed,
+              const float ms = drop_scale((unsigned)((b * p.nh + hd) * p.Sq + q0 + ql) * (unsigned)p.Sk + key, dseed,
                                           p.drop_thr, p.drop_inv);
               dpx *= ms;                      // dP = dP_dropped * mask / keep
               pdrop = pv * ms;                // dV uses the dropped probabilities
@@ -367,6 +370,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
   const int bh = blockIdx.y, b = bh / p.nh, hd = bh % p.nh;
   const int q0 = blockIdx.x * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
   const int qg = q0 + wave * 32 + r;
   bf16x8 qf[4];
   {
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-      for (int x = 0; x < 16; ++x) s[kt][x] *= drop_scale(base + kt * 32 + acc_row(x, hh), p.drop_seed, p.drop_thr, p.drop_inv);
+      for (int x = 0; x < 16; ++x) s[kt][x] *= drop_scale(base + kt * 32 + acc_row(x, hh), dseed, p.drop_thr, p.drop_inv);
   }
 
   const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
@@ -472,6 +476,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_bf16_kernel(AttnP p) {
   float* del_s = lse_s + 64;
   const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
+  const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
   const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1, half8 = 8 * (pp & 1);
   constexpr int QPT = 64 * 8 / NTH;                       // 16-B pieces of a 64-row chunk per thread
   const __bf16* const qsrc = (const __bf16*)p.q + (long)b * p.Sq * p.ldq + hd * 64;
@@ -552,7 +557,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_bf16_kernel(AttnP p) {
             pv = __expf(sv - lse_s[ql]);
             float dpx = dp[x];
             if (DROP) {
-              const float ms = drop_scale((unsigned)((b * p.nh + hd) * p.Sq + q0 + ql) * (unsigned)p.Sk + key, p.drop_seed,
+              const float ms = drop_scale((unsigned)((b * p.nh + hd) * p.Sq + q0 + ql) * (unsigned)p.Sk + key, dseed,
                                           p.drop_thr, p.drop_inv);
               dpx *= ms;                      // dP = dP_dropped * mask / keep
               pdrop = pv * ms;                // dV uses the dropped probabilities
@@ -699,7 +704,7 @@ extern "C" int vlni_attn_fwd(int dtype, const void* q, long ldq, const void* k, 
   AttnP p = {};
   p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kmask = kmask; p.bias = bias;
   p.out = out; p.ldo = ldo; p.lse = lse; p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
-  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p);
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p); p.seed_base = vlni_seed_base();
   int rc = check_common("attn_fwd", dtype, p);
   if (rc) return rc;
   static const bool f32mfma = getenv("VLNI_ATTN_F32MFMA") != nullptr;
@@ -720,7 +725,7 @@ extern "C" int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, 
   p.q = q; p.k = k; p.v = v; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.kmask = kmask; p.bias = bias;
   p.out = (void*)out; p.ldo = ldo; p.lse = (float*)lse; p.B = B; p.nh = nh; p.Sq = Sq; p.Sk = Sk; p.scale = scale;
   p.dout = dout; p.lddo = lddo; p.dq = dq; p.dk = dk; p.dv = dv; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv; p.dbias = dbias;
-  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p);
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p); p.seed_base = vlni_seed_base();
   int rc = check_common("attn_bwd", dtype, p);
   if (rc) return rc;
   VLNI_CHECK(lddo % 4 == 0 && lddq % 4 == 0 && lddk % 4 == 0 && lddv % 4 == 0, VLNI_EINVAL, "attn_bwd: grad strides");

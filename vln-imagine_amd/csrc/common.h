@@ -18,6 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void vlni_set_error(const char* fmt, ...);
+const unsigned* vlni_seed_base();      // device pointer set by vlni_set_dropout_seed_base (or null)
 
 #define VLNI_CHECK(cond, code, ...)                 \
   do {                                              \
@@ -113,6 +114,7 @@ __host__ __device__ __forceinline__ unsigned drop_hash(unsigned idx, unsigned se
   return x;
 }
 // returns 0 (dropped) or 1/(1-p) (kept); thr = p * 2^32
+__device__ __forceinline__ unsigned eff_seed(unsigned seed, const unsigned* base) { return base ? seed + *base : seed; }
 __device__ __forceinline__ float drop_scale(unsigned idx, unsigned seed, unsigned thr, float inv_keep) {
   return drop_hash(idx, seed) >= thr ? inv_keep : 0.f;
 }

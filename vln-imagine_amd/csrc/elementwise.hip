@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(int act, const T* __restri
 // y = x * keep(seed, idx)/(1-p)  (x == null: writes the mask itself, for tests); idx = linear element index
 template <typename T>
 __global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long n, unsigned thr,
-                                                      unsigned seed, float inv) {
+                                                      unsigned seed0, float inv, const unsigned* sbase) {
+  const unsigned seed = eff_seed(seed0, sbase);
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long stride = (long)gridDim.x * blockDim.x;
   for (; i < n; i += stride) {
@@ -550,8 +551,8 @@ extern "C" int vlni_dropout(int dtype, const void* x, void* y, long n, float p, 
   dim3 grid((unsigned)std::min<long>(2048, (n + 255) / 256)), block(256);
   const unsigned thr = drop_thr(p);
   const float inv = 1.0f / (1.0f - p);
-  BY_DTYPE(dtype, hipLaunchKernelGGL((dropout_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y, n, thr, seed, inv),
-           hipLaunchKernelGGL((dropout_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, n, thr, seed, inv));
+  BY_DTYPE(dtype, hipLaunchKernelGGL((dropout_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y, n, thr, seed, inv, vlni_seed_base()),
+           hipLaunchKernelGGL((dropout_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, n, thr, seed, inv, vlni_seed_base()));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

@@ -35,7 +35,7 @@ struct GemmP {
   char* preact; long ldp;       // value before act (after bias), same dtype as C
   const char* dact_src; long ldd; int dact;   // multiply by act'(src) (1 gelu', 2 relu')
   float alpha;
-  unsigned drop_thr, drop_seed; float drop_inv;   // dropout on the epilogue value (after act / act'), before the residual
+  unsigned drop_thr, drop_seed; float drop_inv; const unsigned* seed_base;   // effective seed = drop_seed + *seed_base   // dropout on the epilogue value (after act / act'), before the residual
   int atomic_f32;               // C is float, accumulate with atomics (split-K wgrad)
   int kt_per_split;
   int vec_ok;                   // every epilogue tensor allows 4-element vector accesses
@@ -143,6 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16
   //      [64][128] float32 half-tile, then every thread handles 4 consecutive columns of a row: bias / act' / act /
   //      residual with 16-B (8-B bf16) global accesses, 32 threads per 128-column row (full cache lines).
   float* const e = (float*)smem;
+  const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
   const int c4 = (tid & 31) * 4;
   const int gcol = n0 + c4;
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -187,7 +188,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16
         }
         if (p.drop_thr) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] *= drop_scale((unsigned)grow * (unsigned)p.N + gcol + u, p.drop_seed, p.drop_thr, p.drop_inv);
+          for (int u = 0; u < 4; ++u) v[u] *= drop_scale((unsigned)grow * (unsigned)p.N + gcol + u, dseed, p.drop_thr, p.drop_inv);
         }
         if (p.residual) v += DT<T>::ld4((const T*)p.residual + (long)grow * p.ldr + gcol);
         DT<T>::st4((T*)p.C + (long)grow * p.ldc + gcol, v);
@@ -202,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16
           }
           if (p.act == 1) w = gelu_t<T>(w);
           else if (p.act == 2) w = fmaxf(w, 0.f);
-          if (p.drop_thr) w *= drop_scale((unsigned)grow * (unsigned)p.N + (unsigned)col, p.drop_seed, p.drop_thr, p.drop_inv);
+          if (p.drop_thr) w *= drop_scale((unsigned)grow * (unsigned)p.N + (unsigned)col, dseed, p.drop_thr, p.drop_inv);
           if (p.residual) w += DT<T>::ld((const T*)p.residual + (long)grow * p.ldr + col);
           DT<T>::st((T*)p.C + (long)grow * p.ldc + col, w);
         }
@@ -487,6 +488,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_big_kernel(GemmP p) {
 
   // ---- epilogue: 64-row slabs of the tile go through LDS as [64][TBN] float32, then row-wise 4-column vectors ----
   float* const e = (float*)dsmem;
+  const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
   constexpr int TPR = TBN / 4, RPP = NTH / TPR, NPASS = 64 / RPP;
   const int c4 = (tid % TPR) * 4, gcol = n0 + c4;
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_big_kernel(GemmP p) {
         }
         if (p.drop_thr) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] *= drop_scale((unsigned)grow * (unsigned)p.N + gcol + u, p.drop_seed, p.drop_thr, p.drop_inv);
+          for (int u = 0; u < 4; ++u) v[u] *= drop_scale((unsigned)grow * (unsigned)p.N + gcol + u, dseed, p.drop_thr, p.drop_inv);
         }
         if (p.residual) v += DT<T>::ld4((const T*)p.residual + (long)grow * p.ldr + gcol);
         DT<T>::st4((T*)p.C + (long)grow * p.ldc + gcol, v);
@@ -548,7 +550,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_big_kernel(GemmP p) {
           }
           if (p.act == 1) w = gelu_t<T>(w);
           else if (p.act == 2) w = fmaxf(w, 0.f);
-          if (p.drop_thr) w *= drop_scale((unsigned)grow * (unsigned)p.N + (unsigned)col, p.drop_seed, p.drop_thr, p.drop_inv);
+          if (p.drop_thr) w *= drop_scale((unsigned)grow * (unsigned)p.N + (unsigned)col, dseed, p.drop_thr, p.drop_inv);
           if (p.residual) w += DT<T>::ld((const T*)p.residual + (long)grow * p.ldr + col);
           DT<T>::st((T*)p.C + (long)grow * p.ldc + col, w);
         }
@@ -1085,7 +1087,7 @@ extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B,
   p.M = M; p.N = N; p.K = K; p.bias = bias; p.act = act; p.residual = (const char*)residual; p.ldr = ldr;
   p.preact = (char*)preact; p.ldp = ldp; p.dact_src = (const char*)dact_src; p.ldd = ldd; p.dact = dact;
   p.alpha = alpha; p.atomic_f32 = atomic_f32;
-  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p);
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p); p.seed_base = vlni_seed_base();
   p.vec_ok = gemm_vec_ok(es, N, C, ldc, residual, ldr, preact, ldp, dact_src, ldd, bias);
   return gemm_launch(dtype, p, split_k, variant, stream);
 }
@@ -1112,7 +1114,7 @@ extern "C" int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* ld
   p.residual = (const char*)at(residual, 0); p.ldr = al(ldr, 0);
   p.preact = (char*)at((const void* const*)preact, 0); p.ldp = al(ldp, 0);
   p.dact_src = (const char*)at(dact_src, 0); p.ldd = al(ldd, 0); p.dact = dact; p.alpha = 1.f; p.atomic_f32 = 0;
-  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed ? drop_seed[0] : 0; p.drop_inv = 1.0f / (1.0f - drop_p);
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed ? drop_seed[0] : 0; p.drop_inv = 1.0f / (1.0f - drop_p); p.seed_base = vlni_seed_base();
   p.A1 = (const char*)A[1]; p.lda1 = lda[1]; p.B1 = (const char*)B[1]; p.ldb1 = ldb[1]; p.C1 = (char*)C[1]; p.ldc1 = ldc[1];
   p.M1 = M[1]; p.bias1 = bias ? bias[1] : nullptr;
   p.residual1 = (const char*)at(residual, 1); p.ldr1 = al(ldr, 1);

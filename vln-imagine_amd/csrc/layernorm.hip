@@ -64,7 +64,8 @@ __global__ __launch_bounds__(BWAVES * 64) void ln_bwd_kernel(const T* __restrict
                                                      const float* __restrict__ rstd, T* __restrict__ dx, long lddx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
                                                      const T* __restrict__ dres, long lddres, T* __restrict__ dxd,
-                                                     long lddxd, unsigned dthr, unsigned dseed, float dinv) {
+                                                     long lddxd, unsigned dthr, unsigned dseed0, float dinv, const unsigned* sbase) {
+  const unsigned dseed = dxd ? eff_seed(dseed0, sbase) : 0u;
   constexpr int H = 256 * NC;
   __shared__ float red[BWAVES][2][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -250,11 +251,11 @@ extern "C" int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const vo
   if (dtype == VLNI_F32) {
     using TT = float;
     const float* d = (const float*)dy; const float* xx = (const float*)x; float* o = (float*)dx; const float* dr = (const float*)dres; float* dd = (float*)dx_drop;
-    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
+    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p), vlni_seed_base());
   } else {
     using TT = __bf16;
     const __bf16* d = (const __bf16*)dy; const __bf16* xx = (const __bf16*)x; __bf16* o = (__bf16*)dx; const __bf16* dr = (const __bf16*)dres; __bf16* dd = (__bf16*)dx_drop;
-    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p));
+    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p), vlni_seed_base());
   }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;

@@ -265,6 +265,17 @@ def reseed(seed):
     _SEED[0] = seed & 0x3FFFFFFF
 
 
+_SEED_BASE = [None]
+
+
+def set_seed_base(t):
+    """Registers a 1-element int32 CUDA tensor whose value every kernel adds to its dropout seed (None = off). A captured
+    training step advances it in-graph (train.GraphedStep), so each replay draws fresh masks."""
+    assert t is None or (t.is_cuda and t.dtype == torch.int32 and t.numel() == 1)
+    _lib.call("vlni_set_dropout_seed_base", 0 if t is None else t.data_ptr())
+    _SEED_BASE[0] = t
+
+
 def cast(x, dtype):
     if x.dtype == dtype:
         return x

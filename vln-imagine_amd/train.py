@@ -142,8 +142,12 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.SHADOWS.invalidate()               # every shadow refresh must be recorded inside graph 1
+        # dropout: the seeds recorded in the graph are constants, their device-resident base moves on every replay
+        self.seed_base = torch.zeros(1, dtype=torch.int32, device=trainer.flat_p.device)
+        ops.set_seed_base(self.seed_base)
         self.g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fb):
+            self.seed_base.add_(7919)
             trainer.zero_grad()
             self.loss = fwd_bwd()
             trainer.flush()
