@@ -43,12 +43,20 @@ class DuetOracle:
 
     def panorama(self, b):                                                     # D:1087-1131
         sd, p = self.sd, "img_embeddings"
-        e = (_ln(sd, p + ".img_layer_norm", _lin(sd, p + ".img_linear", b["view_img_fts"]))
+        img = _ln(sd, p + ".img_layer_norm", _lin(sd, p + ".img_linear", b["view_img_fts"]))
+        lens = b["view_lens"]
+        if b.get("obj_img_fts") is not None:                                   # D:1096-1114 (REVERIE / SOON objects)
+            q = "obj" if (p + ".obj_linear.weight") in sd else "img"
+            obj = _ln(sd, f"{p}.{q}_layer_norm", _lin(sd, f"{p}.{q}_linear", b["obj_img_fts"]))
+            per = [torch.cat([img[i, :int(lens[i])], obj[i, :int(b["obj_lens"][i])]], 0) for i in range(img.shape[0])]
+            S = max(x.shape[0] for x in per)
+            img = torch.stack([torch.cat([x, x.new_zeros(S - x.shape[0], x.shape[1])], 0) for x in per])      # O:46-68
+            lens = lens + b["obj_lens"]
+        e = (img
              + _ln(sd, p + ".loc_layer_norm", _lin(sd, p + ".loc_linear", b["loc_fts"]))
              + sd[p + ".nav_type_embedding.weight"][b["nav_types"]]
              + sd["embeddings.token_type_embeddings.weight"][1][None, None])
         e = _ln(sd, p + ".layer_norm", e)
-        lens = b["view_lens"]
         masks = torch.arange(e.shape[1])[None, :] < lens[:, None]             # O:36-44
         for i in range(self.cfg.num_pano_layers):
             e = prenorm_layer(sd, f"{p}.pano_encoder.layers.{i}", e, ~masks)
@@ -99,8 +107,34 @@ class DuetOracle:
                     row.append(gl[i, j])
             rows.append(torch.stack(row))
         fused = torch.stack(rows)
+        obj = None
+        if b.get("vp_obj_masks") is not None:                                  # D:1220-1225
+            obj = cls_head(sd, "og_head", v).squeeze(2).masked_fill(~b["vp_obj_masks"], -float("inf"))
         return {"gmap_embeds": g, "vp_embeds": v, "global_logits": gl, "local_logits": ll, "fused_logits": fused,
-                "obj_logits": None}
+                "obj_logits": obj}
+
+    def align_reverie(self, txt, txt_masks, img, img_masks):                   # D:781-888
+        """Imagination 0 of every sample vs the mean of all valid instruction tokens; negatives = other samples' means."""
+        cfg, typ, B = self.cfg, self.cfg.aux_loss_type, img.shape[0]
+        means = {b: txt[b][txt_masks[b]].mean(0) for b in range(B) if bool(txt_masks[b].any())}
+        rows, losses = [], []
+        for b in range(B):
+            assert bool(img_masks[b].reshape(-1)[0])
+            proj = self._h._proj(img[b, 0])
+            if b not in means:
+                rows.append(img[b])
+                continue
+            rows.append(torch.cat([proj[None], img[b, 1:]], 0))
+            if typ == "cosine":
+                losses.append(1 - F.cosine_similarity(proj, means[b], dim=-1))
+            else:
+                allt = torch.stack([means[b]] + [m for bb, m in means.items() if bb != b], 0)
+                sims = F.cosine_similarity(proj[None], allt)
+                if typ == "contrastive-InfoNCE":                               # D:657-687
+                    losses.append(F.cross_entropy((sims / cfg.infonce_temperature)[None], torch.zeros(1, dtype=torch.long)))
+                else:                                                          # D:890-921
+                    losses.append((1 - sims[0]) + F.relu(cfg.contrastive_margin_value + sims[1:] - sims[0]).mean())
+        return (torch.stack(losses).mean() if losses else 0), torch.stack(rows)
 
     def __call__(self, mode, b):
         cfg, sd = self.cfg, self.sd
@@ -114,6 +148,8 @@ class DuetOracle:
             return b["imagine_feats"] + sd["imagine_embeddings.type_embedding.weight"][0][None, None]
         if mode == "align_with_contrastive_loss":                              # D:1247-1263
             txt = b["align_txt_embeds"].detach() if cfg.fix_lang_inside_cosine_model else b["align_txt_embeds"]
+            if cfg.dataset == "reverie":
+                return self.align_reverie(txt, b["txt_masks"], b["align_imagine_embeds"], b["imagine_masks"])
             return self._h.align(txt, b["txt_masks"], b["align_imagine_embeds"], b["imagine_masks"],
                                  b["sub_instr_segs"], b["sub_instr_imag_flag"], b["noun_phrase_segs"])
         if mode == "panorama":

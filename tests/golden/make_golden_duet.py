@@ -63,6 +63,10 @@ def run_variant(name, over, epkw):
     g = {"loss": out["loss"].detach().numpy(), "ml_loss": out["ml_loss"].detach().numpy(),
          "aux": out["aux"].detach().numpy() if torch.is_tensor(out["aux"]) else np.float32(out["aux"]),
          "imagine_embeds": out["imagine_embeds"].detach().numpy()}
+    if "obj" in out:
+        g["og_loss"] = out["og_loss"].detach().numpy()
+        for t in range(ep.T):
+            g[f"obj{t}"] = out["obj"][t].detach().numpy()
     for k, v in synth.probe(out["txt_embeds"].detach().numpy()).items():
         g[f"txt_embeds.{k}"] = v
     for t in range(ep.T):

@@ -34,6 +34,10 @@ DUET_VARIANTS = {
     "c1_T3_dense": (dict(), dict(T=3, ragged=False)),
     "c1_infonce": (dict(aux_loss_type="contrastive-InfoNCE"), dict()),
     "c1_fixlang": (dict(fix_lang_embedding=True, update_lang_bert=False), dict()),
+    # REVERIE: object tokens in the panorama, object-grounding head, whole-instruction alignment (one imagination)
+    "c1_reverie": (dict(dataset="reverie", obj_feat_size=768), dict(I=1, O=5)),
+    "c1_reverie_infonce": (dict(dataset="reverie", obj_feat_size=2048, aux_loss_type="contrastive-InfoNCE",
+                                fix_lang_inside_cosine_model=False), dict(I=1, O=5, obj_feat=2048)),
 }
 DUET_C1 = dict(num_l_layers=2, num_pano_layers=2, num_x_layers=2)
 DUET_EP = dict(tag="golden", B=4, L=80, V=36, I=4, T=2, ragged=True)

@@ -35,6 +35,10 @@ def test_product_fp32_matches_reference_golden(name, golden_dir):
     _close(out["loss"].item(), g["loss"], TOL, "loss")
     _close(out["aux"].item(), g["aux"], TOL, "aux")
     _close(c(out["imagine_embeds"]), g["imagine_embeds"], TOL, "imagine_embeds")
+    if "og_loss" in g:                                            # REVERIE: object grounding head
+        _close(out["og_loss"].item(), g["og_loss"], TOL, "og_loss")
+        for t in range(ep.T):
+            _close(c(out["obj"][t]), g[f"obj{t}"], TOL, f"obj{t}")
     for t in range(ep.T):
         for nm in ("fused", "global", "local"):
             _close(c(out[nm][t]), g[f"{nm}{t}"], TOL, f"{nm}{t}")

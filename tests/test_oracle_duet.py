@@ -40,6 +40,10 @@ def test_oracle_matches_reference_golden(name, golden_dir):
     _close(out["loss"].item(), g["loss"], what="loss")
     _close(out["aux"].item(), g["aux"], what="aux")
     _close(out["imagine_embeds"].detach(), g["imagine_embeds"], what="imagine_embeds")
+    if "og_loss" in g:                                            # REVERIE: object grounding
+        _close(out["og_loss"].item(), g["og_loss"], what="og_loss")
+        for t in range(ep.T):
+            _close(out["obj"][t].detach(), g[f"obj{t}"], what=f"obj{t}")
     for t in range(ep.T):
         for nm in ("fused", "global", "local"):
             _close(out[nm][t].detach(), g[f"{nm}{t}"], what=f"{nm}{t}")

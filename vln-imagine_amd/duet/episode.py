@@ -16,7 +16,7 @@ class DuetEpisodeTensors:
         self.steps = [{k: (t(v) if hasattr(v, "dtype") else v) for k, v in s.items()} for s in ep.steps]
         # map-node sources as gather indices into the bank [zero row | avg_0, pano_0 | avg_1, pano_1 | ...]
         import numpy as np
-        widths = [int(s["view_lens"].max()) for s in ep.steps]
+        widths = [int((s["view_lens"] + s["obj_lens"]).max()) if "obj_lens" in s else int(s["view_lens"].max()) for s in ep.steps]
         base = np.concatenate([[1], 1 + np.cumsum([w + 1 for w in widths])])
         self.pano_widths, self.node_idx = widths, []
         for s in ep.steps:
@@ -39,19 +39,21 @@ def run_episode(model, et, use_aux=True, train_ml=0.2, cosine_weight=0.5, criter
     img = model("imagine", {"imagine_feats": et.imagine_feats, "imagine_masks": et.imagine_masks})
     aux = None
     if use_aux:
-        aux, img = model("align_with_contrastive_loss", {
-            "align_txt_embeds": txt, "txt_masks": et.txt_masks, "align_imagine_embeds": img,
-            "imagine_masks": et.imagine_masks, "sub_instr_segs": ep.sub_instr_segs,
-            "sub_instr_imag_flag": ep.sub_instr_imag_flag, "noun_phrase_segs": ep.noun_phrase_segs,
-            "obs_instr_ids": [f"i{b}" for b in range(et.B)]})
-    ml_loss = 0.0
+        batch = {"align_txt_embeds": txt, "txt_masks": et.txt_masks, "align_imagine_embeds": img,
+                 "imagine_masks": et.imagine_masks, "obs_instr_ids": [f"i{b}" for b in range(et.B)]}
+        if getattr(ep, "O", 0) == 0:             # REVERIE aligns with the whole instruction: no sub-instruction annotations
+            batch.update(sub_instr_segs=ep.sub_instr_segs, sub_instr_imag_flag=ep.sub_instr_imag_flag,
+                         noun_phrase_segs=ep.noun_phrase_segs)
+        aux, img = model("align_with_contrastive_loss", batch)
+    ml_loss, og_loss = 0.0, 0.0
     bank = None
     for t, s in enumerate(et.steps):
+        has_obj = "obj_img_fts" in s                                           # REVERIE (reverie/agent_obj.py:381-384)
         pano, pano_masks = model("panorama", {
-            "view_img_fts": s["view_img_fts"], "obj_img_fts": None, "loc_fts": s["loc_fts"],
-            "nav_types": s["nav_types"], "view_lens": s["view_lens"], "obj_lens": None})
-        lens = s["view_lens"].to(pano.dtype)
-        avg = (pano * pano_masks.unsqueeze(2)).sum(1) / lens[:, None]         # agent.py:468-469
+            "view_img_fts": s["view_img_fts"], "obj_img_fts": s.get("obj_img_fts"), "loc_fts": s["loc_fts"],
+            "nav_types": s["nav_types"], "view_lens": s["view_lens"], "obj_lens": s.get("obj_lens")})
+        plen = s["view_lens"] + s["obj_lens"] if has_obj else s["view_lens"]
+        avg = (pano * pano_masks.unsqueeze(2)).sum(1) / plen.to(pano.dtype)[:, None]      # agent.py:468-469
         assert pano.shape[1] == et.pano_widths[t]
         if bank is None:
             bank = [torch.zeros_like(avg).unsqueeze(1)]
@@ -62,7 +64,7 @@ def run_episode(model, et, use_aux=True, train_ml=0.2, cosine_weight=0.5, criter
         gmap_img = torch.gather(torch.cat(bank, 1), 1, idx.unsqueeze(2).expand(-1, -1, pano.shape[2]))
         vp_img = torch.cat([torch.zeros_like(pano[:, :1]), pano], 1)           # agent.py:164-166
         ones = torch.ones(et.B, 1, dtype=torch.bool, device=pano.device)
-        vlen1 = s["view_lens"] + 1
+        vlen1 = plen + 1
         vp_masks = torch.arange(vp_img.shape[1], device=pano.device)[None, :] < vlen1[:, None]
         nav = model("navigation", {
             "txt_embeds": txt, "txt_masks": et.txt_masks, "gmap_img_embeds": gmap_img,
@@ -70,15 +72,22 @@ def run_episode(model, et, use_aux=True, train_ml=0.2, cosine_weight=0.5, criter
             "gmap_pair_dists": s["gmap_pair_dists"], "gmap_visited_masks": s["gmap_visited_masks"],
             "gmap_vpids": s["gmap_vpids"], "vp_img_embeds": vp_img, "vp_pos_fts": s["vp_pos_fts"],
             "vp_masks": vp_masks, "vp_nav_masks": torch.cat([ones, s["nav_types"] == 1], 1),
-            "vp_obj_masks": None, "vp_cand_vpids": s["vp_cand_vpids"],
+            "vp_obj_masks": torch.cat([~ones, s["nav_types"] == 2], 1) if has_obj else None,
+            "vp_cand_vpids": s["vp_cand_vpids"],
             "imagine_embeds": img, "imagine_masks": et.imagine_masks})
         ml_loss = ml_loss + criterion(nav["fused_logits"], s["target"])
+        if has_obj:                                                            # object grounding CE, agent_obj.py:461-463
+            og_loss = og_loss + criterion(nav["obj_logits"], s["obj_target"])
+            if keep:
+                out.setdefault("obj", []).append(nav["obj_logits"])
         if keep:
             out["fused"].append(nav["fused_logits"]); out["global"].append(nav["global_logits"])
             out["local"].append(nav["local_logits"]); out["pano"].append(pano)
             out["gmap"].append(nav["gmap_embeds"]); out["vp"].append(nav["vp_embeds"])
     loss = ml_loss * train_ml / et.B
+    if torch.is_tensor(og_loss):
+        loss = loss + og_loss * train_ml / et.B                                # agent_obj.py:544-546
     if use_aux and torch.is_tensor(aux):
         loss = loss + cosine_weight * aux
-    out.update(loss=loss, ml_loss=ml_loss, aux=aux, txt_embeds=txt, imagine_embeds=img)
+    out.update(loss=loss, ml_loss=ml_loss, og_loss=og_loss, aux=aux, txt_embeds=txt, imagine_embeds=img)
     return out

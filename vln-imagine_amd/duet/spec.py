@@ -31,6 +31,8 @@ def param_shapes(cfg):
     p = "img_embeddings"
     _lin(d, p + ".img_linear", h, cfg.image_feat_size); _ln(d, p + ".img_layer_norm", h)
     _lin(d, p + ".loc_linear", h, cfg.angle_feat_size + 3); _ln(d, p + ".loc_layer_norm", h)
+    if cfg.obj_feat_size > 0 and cfg.obj_feat_size != cfg.image_feat_size:          # reference :464-468
+        _lin(d, p + ".obj_linear", h, cfg.obj_feat_size); _ln(d, p + ".obj_layer_norm", h)
     d[p + ".nav_type_embedding.weight"] = (3, h)
     _ln(d, p + ".layer_norm", h)
     for i in range(cfg.num_pano_layers):
@@ -59,6 +61,8 @@ def param_shapes(cfg):
     _cls(d, "local_sap_head", h)
     if cfg.glocal_fuse:
         _cls(d, "sap_fuse_linear", h, 2 * h)
+    if cfg.obj_feat_size > 0:                                                       # reference :1039-1040
+        _cls(d, "og_head", h)
     if cfg.imagine_enc_pano:
         if cfg.bypass_imag_encoder:
             d["imagine_embeddings.type_embedding.weight"] = (1, h)

@@ -202,9 +202,14 @@ class DuetEpisode:
     step's panorama embeddings (agent.py:468-479), a frontier node = one candidate view embedding of the step that
     first saw it. `node_src[t][b]` lists, per map node j >= 1, ("avg", step) or ("view", step, view_index)."""
 
-    def __init__(self, tag="ep0", B=4, L=80, V=36, I=4, T=2, ragged=True, feat=768, vocab=30522):
-        self.B, self.L, self.V, self.I, self.T = B, L, V, I, T
+    def __init__(self, tag="ep0", B=4, L=80, V=36, I=4, T=2, ragged=True, feat=768, vocab=30522, O=0, obj_feat=None):
+        """O > 0: REVERIE-style panoramas, up to O object tokens appended after each sample's views (nav_type 2), restating
+        VLN-DUET/map_nav_src/reverie/agent_obj.py:60-130 (_panorama_feature_variable) and :269-285 (_teacher_object)."""
+        self.B, self.L, self.V, self.I, self.T, self.O = B, L, V, I, T, O
         _build_text_imagine(self, tag, B, L, I, ragged, feat, vocab)
+        if O > 0:        # REVERIE: one imagination per instruction, always present (agent_obj.py:214-235)
+            self.imagine_masks = np.ones((B, I), bool)
+            self.imagine_feats = det_uniform(f"{tag}/imag", (B, I, feat), -0.5, 0.5)
         k = lambda s: f"{tag}/{s}"
         self.steps = []
         for t in range(T):
@@ -258,6 +263,30 @@ class DuetEpisode:
                 target[b] = opts[int(det_randint(kk(f"tgt{b}"), (1,), 0, len(opts))[0])]
             if ragged and t == T - 1 and B > 2:
                 target[2] = -100
+            if O > 0:
+                obj_lens = det_randint(kk("olen"), (B,), 1, O + 1) if ragged else np.full((B,), O, np.int64)
+                obj_lens[0] = O
+                S = V + O                                                 # sample 0 has V views and O objects
+                pmask = np.arange(S)[None, :] < (view_lens + obj_lens)[:, None]
+                nav_o = np.zeros((B, S), np.int64)
+                obj_target = np.full((B,), -100, np.int64)
+                for b in range(B):
+                    nav_o[b, :view_lens[b]] = nav[b, :view_lens[b]]
+                    nav_o[b, view_lens[b]:view_lens[b] + obj_lens[b]] = 2
+                    if int(det_randint(kk(f"ogt{b}"), (1,), 0, 3)[0]) > 0:            # 2 of 3 samples stand at a goal viewpoint
+                        obj_target[b] = 1 + view_lens[b] + int(det_randint(kk(f"ogi{b}"), (1,), 0, int(obj_lens[b]))[0])
+                omask = np.arange(O)[None, :] < obj_lens[:, None]
+                self.steps.append(dict(
+                    view_img_fts=(det_uniform(kk("view"), (B, V, feat), -0.5, 0.5) * vmask[..., None]).astype(np.float32),
+                    obj_img_fts=(det_uniform(kk("obj"), (B, O, obj_feat or feat), -0.5, 0.5) * omask[..., None]).astype(np.float32),
+                    loc_fts=(det_uniform(kk("loc"), (B, S, 7), -0.6, 0.6) * pmask[..., None]).astype(np.float32),
+                    nav_types=nav_o, view_lens=view_lens, obj_lens=obj_lens, obj_target=obj_target,
+                    gmap_vpids=gmap_vpids, gmap_lens=glens, gmap_masks=gm, gmap_step_ids=sid,
+                    gmap_pos_fts=(det_uniform(kk("gpos"), (B, G, 7), -0.6, 0.6) * gm[..., None]).astype(np.float32),
+                    gmap_pair_dists=pd.astype(np.float32), gmap_visited_masks=vis_m, node_src=node_src,
+                    vp_pos_fts=det_uniform(kk("vppos"), (B, S + 1, 14), -0.6, 0.6).astype(np.float32),
+                    vp_cand_vpids=[[None] + c for c in cand_vpids], target=target))
+                continue
             self.steps.append(dict(
                 view_img_fts=(det_uniform(kk("view"), (B, V, feat), -0.5, 0.5) * vmask[..., None]).astype(np.float32),
                 loc_fts=(det_uniform(kk("loc"), (B, V, 7), -0.6, 0.6) * vmask[..., None]).astype(np.float32),
