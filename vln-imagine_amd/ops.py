@@ -9,6 +9,7 @@ bidirectional cross-attention block) so that the backward pass is an explicit ke
 sequence with fused epilogues (bias, GELU / GELU', residual) instead of ~40 tiny nodes.
 """
 import ctypes
+import weakref
 import math
 
 import torch
@@ -293,40 +294,92 @@ def additive_mask(m):
 # =====================================================================================
 #  compute-dtype shadows of the float32 master weights
 # =====================================================================================
+def _packed_param(params):
+    """One [sum rows, ...] view over parameters that sit back to back in memory (train.FlatTrainer's arena), else None."""
+    p0 = params[0]
+    ptr, es, base = p0.data_ptr(), p0.element_size(), p0.untyped_storage().data_ptr()
+    for p in params:
+        if p.data_ptr() != ptr or not p.is_contiguous() or p.untyped_storage().data_ptr() != base:
+            return None                # neighbours by accident (separate allocations) do not count
+        ptr += p.numel() * es
+    rows = sum(p.shape[0] for p in params)
+    d = p0.detach()
+    return torch.as_strided(d, (rows,) + tuple(d.shape[1:]), d.stride(), d.storage_offset())
+
+
 class ShadowCache:
-    """Packed / cast / transposed copies of parameters, refreshed when a parameter's
-    version counter moves (optimizer step, load_state_dict). The float32 nn.Parameters stay
-    the single source of truth so state_dict keys match the reference checkpoints."""
+    """Packed / cast / transposed copies of parameters. The float32 nn.Parameters stay the single source of truth so
+    state_dict keys match the reference checkpoints.
+
+    Two staleness counters: `epoch` moves when parameters changed in a way nobody mirrored (load_state_dict, a test writing the
+    arena: call invalidate()), `opt_epoch` moves after every optimizer step. With train.FlatTrainer's arenas registered
+    (set_arena) the optimizer kernel itself keeps a bfloat16 mirror of the float32 arena, parameters that are neighbours in the
+    arena are packed by a VIEW, so after a step only the transposed copies (dgrad operands) are rebuilt - from the bf16 mirror."""
 
     def __init__(self):
         self._c = {}
         self.epoch = 0
+        self.opt_epoch = 0
+        self.arena = None              # (flat float32 params, flat bf16 mirror)
 
-    def invalidate(self):
-        """Call after parameters were updated behind autograd's back (the fused AdamW kernel writes the
-        arena through raw pointers, which does not move tensor version counters)."""
+    def set_arena(self, flat_p, flat_b):
+        self.arena = (flat_p, flat_b) if flat_p is not None else None
         self.epoch += 1
+
+    def invalidate(self, optimizer_step=False):
+        """optimizer_step=True: the fused AdamW kernel just rewrote the float32 arena AND its bf16 mirror (raw pointers: tensor
+        version counters do not move). Otherwise: parameters changed behind autograd's back, rebuild everything lazily."""
+        if optimizer_step and self.arena is not None:
+            self.opt_epoch += 1
+        else:
+            self.epoch += 1
+
+    def _mirror(self, params):
+        """bf16 view of `params` inside the arena mirror (they must be packed neighbours inside the arena), else None."""
+        if self.arena is None:
+            return None
+        flat_p, flat_b = self.arena
+        v = _packed_param(params) if len(params) > 1 else params[0].detach()
+        if v is None or not v.is_contiguous():
+            return None
+        off = (v.data_ptr() - flat_p.data_ptr()) // 4
+        if v.dtype != torch.float32 or off < 0 or off + v.numel() > flat_p.numel() or (v.data_ptr() - flat_p.data_ptr()) % 4:
+            return None
+        return v, flat_b[off:off + v.numel()].view(v.shape)
 
     def get(self, params, dtype, transposed=False):
         key = (id(params[0]), len(params), dtype, transposed)
         hit = self._c.get(key)
-        if hit is not None:
-            ver = hit[0]
-            if ver[0] == self.epoch and ver[1] == params[0]._version and ver[2] == params[0].data_ptr() and \
-                    (len(params) == 1 or ver[3] == sum(p._version for p in params[1:])):
-                return hit[1]
         ver = (self.epoch, params[0]._version, params[0].data_ptr(), sum(p._version for p in params[1:]))
+        if hit is not None and hit[4]() is not params[0]:
+            hit = None                 # a dead parameter's id was recycled
+        if hit is not None and hit[0] == ver and (hit[2] or hit[3] == self.opt_epoch):
+            return hit[1]
+        live = False                   # True: `t` aliases memory the optimizer keeps current (never stale within an epoch)
         with torch.no_grad():
             for p in params:
                 _chk(p, "parameter")
-            src = params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], 0)
-            if src.dim() == 1:
-                t = src if dtype == torch.float32 else cast(src, dtype)
-            elif transposed:
-                t = transpose_pad(src, src.shape[0], dtype)
+            mir = self._mirror(params) if dtype == torch.bfloat16 else None
+            if mir is not None and (hit is None or hit[0] != ver):
+                # (re)fill this slice of the mirror once per epoch; afterwards the optimizer kernel maintains it
+                _lib.call("vlni_cast", _DT[torch.float32], _DT[dtype], mir[0].data_ptr(), mir[1].data_ptr(), mir[0].numel(), _st())
+            if dtype == torch.float32 and not transposed:
+                t = params[0].detach() if len(params) == 1 else _packed_param(params)
+                live = t is not None
+                if t is None:
+                    t = torch.cat([p.detach() for p in params], 0)
+            elif mir is not None and not transposed:
+                t, live = mir[1], True
             else:
-                t = src if (dtype == torch.float32 and len(params) == 1) else cast(src, dtype)
-        self._c[key] = (ver, t)
+                src = mir[1] if mir is not None else \
+                    (params[0].detach() if len(params) == 1 else torch.cat([p.detach() for p in params], 0))
+                if src.dim() == 1:
+                    t = cast(src, dtype)
+                elif transposed:
+                    t = transpose_pad(src, src.shape[0], dtype)
+                else:
+                    t = cast(src, dtype)
+        self._c[key] = (ver, t, live, self.opt_epoch, weakref.ref(params[0]))
         return t
 
 

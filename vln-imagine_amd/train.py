@@ -79,7 +79,9 @@ class FlatTrainer:
         self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
         self.chunk = chunk_mb * (1 << 20) // 4
         self.grad_comm_dtype = grad_comm_dtype
-        ops.SHADOWS.invalidate()
+        # bf16 mirror of the parameter arena, kept current by the AdamW kernel (ops.ShadowCache hands out views of it)
+        self.flat_b = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        ops.SHADOWS.set_arena(self.flat_p, self.flat_b)
         ops.DIRECT_GRAD = True
         ops.DEFER_WGRAD = True
 
@@ -107,8 +109,8 @@ class FlatTrainer:
         _lib.call("vlni_sumsq", self.flat_g.data_ptr(), self.n, self.sumsq.data_ptr(), st)
         _lib.call("vlni_optim_prepare", self.sumsq.data_ptr(), self.max_norm, b1, b2, self.state.data_ptr(), st)
         _lib.call("vlni_adamw_step_dev", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                  0, self.n, self.lr_dev.data_ptr(), b1, b2, eps, wd, self.state.data_ptr(), st)
-        ops.SHADOWS.invalidate()
+                  self.flat_b.data_ptr(), self.n, self.lr_dev.data_ptr(), b1, b2, eps, wd, self.state.data_ptr(), st)
+        ops.SHADOWS.invalidate(optimizer_step=ops.SHADOWS.arena is not None and ops.SHADOWS.arena[0] is self.flat_p)
 
     def grad_norm(self):
         return float(self.sumsq.sqrt())
@@ -141,7 +143,7 @@ class GraphedStep:
                 trainer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ops.SHADOWS.invalidate()               # every shadow refresh must be recorded inside graph 1
+        ops.SHADOWS.invalidate(optimizer_step=True)      # the transposed-shadow rebuilds must be recorded inside graph 1
         # dropout: the seeds recorded in the graph are constants, their device-resident base moves on every replay
         self.seed_base = torch.zeros(1, dtype=torch.int32, device=trainer.flat_p.device)
         ops.set_seed_base(self.seed_base)
