@@ -261,7 +261,8 @@ def main():
             e0.record()
             r = orig(a, b, *p, **k)
             e1.record()
-            rec.append((2.0 * a.shape[0] * b.shape[0] * a.shape[1], e0, e1, (a.shape[0], b.shape[0], a.shape[1])))
+            n_ = b.t.shape[1] if isinstance(b, ops.KN) else b.shape[0]          # KN: dgrad operand W[K, N] (no transposed copy)
+            rec.append((2.0 * a.shape[0] * n_ * a.shape[1], e0, e1, (a.shape[0], n_, a.shape[1])))
             return r
 
         orig2 = ops.gemm_nt2
@@ -272,7 +273,8 @@ def main():
             r = orig2(a, b, *p, **k)
             e1.record()
             rows = a[0].shape[0] + a[1].shape[0]
-            rec.append((2.0 * rows * b[0].shape[0] * a[0].shape[1], e0, e1, (rows, b[0].shape[0], a[0].shape[1])))
+            n_ = b[0].t.shape[1] if isinstance(b[0], ops.KN) else b[0].shape[0]
+            rec.append((2.0 * rows * n_ * a[0].shape[1], e0, e1, (rows, n_, a[0].shape[1])))
             return r
 
         step = eager_step

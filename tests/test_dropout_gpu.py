@@ -166,6 +166,7 @@ def test_seed_base_shifts_every_seed():
     """vlni_set_dropout_seed_base: mask(seed, base) == mask(seed + base, no base), for the mask kernel and a fused block."""
     from vln_imagine_amd import ops
     try:
+        ops.set_seed_base(None)                   # a GraphedStep of an earlier test may still be registered
         ref = _mask(ops, (4096,), 0.3, 1000 + 77)
         base = torch.full((1,), 77, dtype=torch.int32, device="cuda")
         ops.set_seed_base(base)

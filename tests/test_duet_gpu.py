@@ -166,3 +166,29 @@ def test_logit_fusion_kernel_matches_reference_loop():
     assert (torch.isfinite(out).cpu() == fin).all() and torch.allclose(out.cpu()[fin], ref[fin], atol=1e-6)
     (out[fin.cuda()] * w.cuda()[fin.cuda()]).sum().backward()
     assert torch.allclose(gl_g.grad.cpu(), gl_r.grad, atol=1e-6) and torch.allclose(ll_g.grad.cpu(), ll_r.grad, atol=1e-6)
+
+
+def test_bf16_trainer_step_with_odd_sized_parameters():
+    """DUET has 1-element parameters (sprel_linear): the bf16 mirror of the arena must still hand out 16-byte aligned views."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = duet_variant_setup("c1_shipped")
+    et = DuetEpisodeTensors(ep, "cuda")
+    try:
+        m = build_product(cfg, torch.bfloat16)
+        tr = FlatTrainer(m, lr=1e-4)
+        losses = []
+        for _ in range(2):
+            tr.zero_grad()
+            loss = run_episode(m, et, criterion=ops.cross_entropy_sum, keep=False)["loss"]
+            loss.backward()
+            tr.step()
+            losses.append(float(loss.detach()))
+        assert all(np.isfinite(losses)) and all(p.data_ptr() % 32 == 0 for p in tr.params)
+        w = m.global_encoder.encoder.x_layers[0].visn_self_att.self.query.weight
+        mirror = ops._w((w,), torch.bfloat16)
+        assert mirror.data_ptr() % 16 == 0 and torch.equal(mirror, w.detach().bfloat16())     # AdamW keeps the mirror current
+    finally:
+        ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
+        ops._WQ.clear()
+        ops.SHADOWS.set_arena(None, None)

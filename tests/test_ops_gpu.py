@@ -432,3 +432,26 @@ def test_gemm_dual_launch_variants(ops, variant):
     finally:
         ops.AUTOTUNE, ops.GEMM_VARIANTS = saved
         ops._GEMM_BEST.clear()
+
+
+@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+def test_gemm_nn_weight_layout_matches_transposed_copy(ops, variant):
+    """dgrad straight from W[out, in] (transposing LDS reads, variant + 16) == the NT kernel on an explicit W^T copy, bit for bit,
+    incl. GELU' / residual epilogues, ragged rows and a partial column tile (zero page)."""
+    for (M, N, K) in ((333, 768, 768), (700, 640, 3072), (512, 3072, 768)):
+        a = _rand((M, K), torch.bfloat16, 51, 0.5)
+        w = _rand((K, N), torch.bfloat16, 52, 0.05)                      # [out = K, in = N]
+        wt = w.t().contiguous()
+        res, z = _rand((M, N), torch.bfloat16, 53, 0.5), _rand((M, N), torch.bfloat16, 54, 1.0)
+        for kw in (dict(), dict(residual=res), dict(dact_src=z, dact=1)):
+            r = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+            o = torch.empty_like(r)
+            ops._gemm_call(1, a, wt, r, None, 0, kw.get("residual"), None, kw.get("dact_src"), kw.get("dact", 0), 1.0, 1, False, M, N, K)
+            ops._gemm_call(16 + variant, a, w, o, None, 0, kw.get("residual"), None, kw.get("dact_src"), kw.get("dact", 0), 1.0, 1, False,
+                           M, N, K)
+            assert torch.equal(o, r), (variant, M, N, K, list(kw))
+    # front-end: KN operands through gemm_nt / gemm_nt2 (dual launch)
+    a0, a1 = _rand((5 * 86, 768), torch.bfloat16, 55, 0.5), _rand((5 * 44 + 3, 768), torch.bfloat16, 56, 0.5)
+    w0, w1 = _rand((768, 2304), torch.bfloat16, 57, 0.05), _rand((768, 2304), torch.bfloat16, 58, 0.05)
+    o0, o1 = ops.gemm_nt2((a0, a1), (ops.KN(w0), ops.KN(w1)))
+    assert torch.equal(o0, ops.gemm_nt(a0, w0.t().contiguous())) and torch.equal(o1, ops.gemm_nt(a1, ops.KN(w1)))

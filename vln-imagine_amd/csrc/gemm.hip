@@ -844,6 +844,100 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_glds_kernel(TnP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// "NN" form of the same contraction for bf16 dgrad:  C[M,N] = epi(A[M,K] * B[K,N])  with B = W exactly as the forward pass
+// stores it ([out, in] row-major): no transposed weight copy has to be rebuilt after every optimizer step. A is staged and
+// read like in gemm_nt_glds_kernel; the B tile is staged as it lies in memory ([64 k-rows][128 columns], 256-byte rows,
+// tr_off swizzle on the per-lane SOURCE chunk) and its fragments come from the transposing LDS read (ds_read_b64_tr_b16),
+// like the X operand of the weight-gradient kernel. Same stage size (32 KiB), same instruction counts, same epilogue.
+template <int NST, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nn_glds_kernel(GemmP p) {
+  using T = __bf16;
+  constexpr int ES = 2, BK = 64;
+  constexpr int WC = NW / 2, NJ = NW == 4 ? 2 : 1, WCOLS = 32 * NJ, IPW = 16 / NW;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  int wgid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  select_problem(p, wgid);
+  int m0, n0;
+  tile_origin(p, wgid, BM, BN, m0, n0);
+  const int nk = p.K / BK;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WC, wc = wave % WC, r = lane & 31, h = lane >> 5;
+
+  const char* ga[IPW];
+  const char* gb[IPW];
+  bool bok[IPW];
+#pragma unroll
+  for (int i = 0; i < IPW; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    ga[i] = p.A + ((long)min(m0 + row, p.M - 1) * p.lda) * ES + ((lane & 7) ^ ((row >> 1) & 7)) * 16;
+    const int krow = (i * NW + wave) * 4 + (lane >> 4);                    // 4 k-rows of 256 B per LDS-DMA instruction
+    const int c = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));   // logical 16-B chunk this LDS slot must hold
+    bok[i] = n0 + c * 8 < p.N;                                             // N is a multiple of 8: a chunk is all-in or all-out
+    gb[i] = p.B + ((long)krow * p.ldb + n0 + c * 8) * ES;
+  }
+  using gptr = const __attribute__((address_space(1))) void*;
+  using lptr = __attribute__((address_space(3))) void*;
+  auto issue = [&](int t, int stage) {
+    char* sa = dsmem + stage * STAGE + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      __builtin_amdgcn_global_load_lds((gptr)(ga[i] + (long)t * ROWB), (lptr)(sa + i * NW * 1024), 16, 0, 0);
+      const void* pb = bok[i] ? (const void*)(gb[i] + (long)t * BK * p.ldb * ES) : (const void*)g_zero_page;
+      __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(sa + BM * ROWB + i * NW * 1024), 16, 0, 0);
+    }
+  };
+  const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
+  const int frow = 8 * h + qq, half8 = 8 * (pp & 1);
+  const int chb = (wc * WCOLS + 16 * cb) / 8 + (pp >> 1);
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+
+  if (nk > 0) {
+    issue(0, 0);
+    if (NST == 3 && nk > 1) issue(1, 1);
+    int stage = 0;
+    for (int t = 0; t < nk; ++t) {
+      if (NST == 3 && t + 1 < nk) {
+        if (NW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      if (t + NST - 1 < nk) issue(t + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+      const char* As = dsmem + stage * STAGE;
+      const char* Bs = As + BM * ROWB;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 a[2], b[NJ];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = *(const bf16x8*)(As + lds_off(wr * 64 + i * 32 + r, kk * 2 + h));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) b[j] = tr_frag(Bs, 16 * kk + frow, chb + 4 * j, half8);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      stage = stage == NST - 1 ? 0 : stage + 1;
+    }
+  }
+  __syncthreads();
+  gemm_epilogue<T, NW>(p, dsmem, acc, m0, n0, tid, wr, wc, r, h);
+}
+
 // 256 x 256 output tile of the same weight-gradient contraction: 8 waves as 2 (N) x 4 (K), a wave owns 128 x 64 outputs
 // (8 accumulators), half the L2->LDS bytes and half the LDS-read bytes per MFMA of the 128 x 128 tile. A stage holds four
 // [64 rows][128 cols] sub-tiles (A left/right, B left/right) in the layout of the kernel above; 2 stages = 128 KiB.
@@ -973,13 +1067,15 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnP p) {
 
 }  // namespace
 
-static int gemm_check_one(int es, const void* A, long lda, const void* B, long ldb, long ldc, int M, int N, int K) {
+static int gemm_check_one(int es, const void* A, long lda, const void* B, long ldb, long ldc, int M, int N, int K, bool nn = false) {
   const int epc = 16 / es;
   VLNI_CHECK(M > 0 && N > 0 && K > 0, VLNI_EINVAL, "gemm_nt: empty problem %d %d %d", M, N, K);
   VLNI_CHECK(K % epc == 0 && lda % epc == 0 && ldb % epc == 0, VLNI_EINVAL,
              "gemm_nt: K/lda/ldb (%d/%ld/%ld) must be multiples of %d", K, lda, ldb, epc);
   VLNI_CHECK(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0, VLNI_EINVAL, "gemm_nt: A/B must be 16-B aligned");
-  VLNI_CHECK(lda >= K && ldb >= K && ldc >= N, VLNI_EINVAL, "gemm_nt: leading dims too small");
+  VLNI_CHECK(lda >= K && ldb >= (nn ? N : K) && ldc >= N, VLNI_EINVAL, "gemm_nt: leading dims too small");
+  VLNI_CHECK(!nn || (es == 2 && K % 64 == 0 && K >= 192 && N % 8 == 0), VLNI_EUNSUP,
+             "gemm_nt: the [K,N] weight layout needs bf16, K %% 64 == 0, K >= 192, N %% 8 == 0 (K=%d N=%d)", K, N);
   return VLNI_OK;
 }
 
@@ -1004,6 +1100,8 @@ static void gemm_big_go(GemmP& p, hipStream_t st) {
 }
 
 static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stream) {
+  const bool nn = variant >= 16;                 // B given as [K,N] (the forward weight itself): bf16 dgrad
+  variant &= 15;
   const int es = dtype == VLNI_F32 ? 4 : 2, bk = ROWB / es;
   const int nkt = cdiv(p.K, bk);
   p.kt_per_split = cdiv(nkt, split_k);
@@ -1019,7 +1117,23 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
   if (!glds_ok) variant = 1;
   if (variant >= 6 && (splits > 1 || p.atomic_f32)) variant = 1;       // large tiles: whole-K, plain stores only
   hipStream_t st = (hipStream_t)stream;
-  if (variant >= 6) {
+  if (nn) {
+    VLNI_CHECK(splits == 1 && !p.atomic_f32, VLNI_EUNSUP, "gemm_nt: [K,N] weight layout takes no split-K");
+    if (variant < 2 || variant > 5) variant = 5;
+    constexpr int ST = (BM + BN) * ROWB;
+    static bool attr_nn = false;
+    if (!attr_nn) {
+      (void)hipFuncSetAttribute((const void*)gemm_nn_glds_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
+      (void)hipFuncSetAttribute((const void*)gemm_nn_glds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
+      (void)hipFuncSetAttribute((const void*)gemm_nn_glds_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
+      (void)hipFuncSetAttribute((const void*)gemm_nn_glds_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
+      attr_nn = true;
+    }
+    if (variant == 2) hipLaunchKernelGGL((gemm_nn_glds_kernel<2, 4>), grid, dim3(256), 2 * ST, st, p);
+    else if (variant == 3) hipLaunchKernelGGL((gemm_nn_glds_kernel<3, 4>), grid, dim3(256), 3 * ST, st, p);
+    else if (variant == 4) hipLaunchKernelGGL((gemm_nn_glds_kernel<3, 8>), grid, dim3(512), 3 * ST, st, p);
+    else hipLaunchKernelGGL((gemm_nn_glds_kernel<2, 8>), grid, dim3(512), 2 * ST, st, p);
+  } else if (variant >= 6) {
     // 6: 256x128 tile, 3 stages; 7: 256x256 tile, 2 stages; 8: 128x256 tile, 3 stages (8 waves each)
     if (dtype == VLNI_F32) {
       if (variant == 6) gemm_big_go<float, 3, 4, 2, 2, 2>(p, st);
@@ -1071,13 +1185,15 @@ static bool gemm_vec_ok(int es, int N, const void* C, long ldc, const void* resi
 // variant: 0 = choose by shape, 1 = register-staged 32-KiB kernel (4 blocks/CU), 2 = LDS-DMA 2-stage (64 KiB),
 // 3 = LDS-DMA 3-stage (96 KiB), 4 / 5 = the 3- / 2-stage kernels with 8 waves per tile (2 waves per SIMD), 6 / 7 / 8 = large
 // tiles 256x128 / 256x256 / 128x256 (one block per CU). All variants compute the same result; the host side may time them once per shape.
+// variant + 16: B is given as [K,N] row-major (ldb >= N) - the forward weight itself, so bf16 dgrad needs no transposed weight
+// copy (pipelines 2..5; bf16, K % 64 == 0, K >= 192, N % 8 == 0).
 extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,
                               int K, const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
                               const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32,
                               int variant, float drop_p, unsigned drop_seed, void* stream) {
   VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt: bad dtype %d", dtype);
   const int es = dtype == VLNI_F32 ? 4 : 2;
-  int rc = gemm_check_one(es, A, lda, B, ldb, ldc, M, N, K);
+  int rc = gemm_check_one(es, A, lda, B, ldb, ldc, M, N, K, variant >= 16);
   if (rc) return rc;
   VLNI_CHECK(!(atomic_f32 && (bias || act || residual || preact || dact)), VLNI_EINVAL, "gemm_nt: atomic output takes no epilogue");
   VLNI_CHECK(split_k >= 1 && (split_k == 1 || atomic_f32), VLNI_EINVAL, "gemm_nt: split_k needs atomic_f32");
@@ -1102,7 +1218,7 @@ extern "C" int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* ld
   VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt_dual: bad dtype %d", dtype);
   const int es = dtype == VLNI_F32 ? 4 : 2;
   for (int i = 0; i < 2; ++i) {
-    int rc = gemm_check_one(es, A[i], lda[i], B[i], ldb[i], ldc[i], M[i], N, K);
+    int rc = gemm_check_one(es, A[i], lda[i], B[i], ldb[i], ldc[i], M[i], N, K, variant >= 16);
     if (rc) return rc;
   }
   VLNI_CHECK(drop_p >= 0.f && drop_p < 1.f, VLNI_EINVAL, "gemm_nt_dual: dropout p=%f", drop_p);

@@ -66,6 +66,21 @@ GEMM_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 8)
 _GEMM_BEST = {}
 
 
+class KN:
+    """Marks a weight handed to gemm_nt / gemm_nt2 as [K, N] row-major (the forward weight itself as the dgrad operand):
+    the launch uses the transposing-read "NN" kernels (variant + 16) instead of a transposed weight copy."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+NN_DGRAD = False         # True: bf16 dgrad straight from W[out, in] (no W^T shadows, half the shadow memory). Measured on the
+                         # bench step: the transposing-read kernels are ~6 % slower per dgrad launch (+1.3 ms) than the NT kernels on
+                         # W^T, which is more than the 88 transposes per step they remove (0.9 ms) - so off by default.
+NN_VARIANTS = (2, 3, 4, 5)
+
+
 def _gemm_call(variant, a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K, drop=None):
     _lib.call("vlni_gemm_nt_v", _dt(a), a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(),
               out.stride(0), M, N, K, _p(bias), act, _p(residual), residual.stride(0) if residual is not None else 0,
@@ -78,22 +93,28 @@ def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_s
             alpha=1.0, split_k=1, atomic=False, out_dtype=None, drop=None):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T); a, b same dtype, K-contiguous. drop = (p, seed): dropout after act, before residual."""
     M, K = a.shape
-    N = b.shape[0]
-    assert b.shape[1] == K and a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1
+    kn = isinstance(b, KN)
+    if kn:
+        b = b.t
+        N = b.shape[1]
+        assert b.shape[0] == K and a.dtype == b.dtype == torch.bfloat16 and a.stride(1) == 1 and b.stride(1) == 1 and not atomic
+    else:
+        N = b.shape[0]
+        assert b.shape[1] == K and a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32 if atomic else a.dtype, device=a.device)
     if drop is not None and drop[0] <= 0.0:
         drop = None
     args = (a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K, drop)
-    variant = 0
+    variant = 21 if kn else 0
     if AUTOTUNE and not atomic and M >= 512:
-        key = (a.dtype, M, N, K, act, dact, residual is not None, preact is not None)
+        key = (a.dtype, M, N, K, act, dact, residual is not None, preact is not None, kn)
         variant = _GEMM_BEST.get(key)
         if variant is None and torch.cuda.is_current_stream_capturing():
-            variant = 0                                                     # no timing trials inside a graph capture
+            variant = 21 if kn else 0                                       # no timing trials inside a graph capture
         elif variant is None:
             best = (float("inf"), 0)
-            for v in GEMM_VARIANTS:
+            for v in ([16 + u for u in NN_VARIANTS] if kn else GEMM_VARIANTS):
                 _gemm_call(v, *args)                                    # warm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -117,7 +138,14 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
     (a0, a1), (b0, b1) = a, b
     M0, K = a0.shape
     M1 = a1.shape[0]
-    N = b0.shape[0]
+    kn = isinstance(b0, KN)
+    if kn:
+        b0, b1 = b0.t, b1.t
+        b = (b0, b1)
+        N = b0.shape[1]
+        assert b0.shape[0] == K and a0.dtype == torch.bfloat16
+    else:
+        N = b0.shape[0]
     assert b1.shape == b0.shape and a1.shape[1] == K and a0.dtype == a1.dtype == b0.dtype == b1.dtype
     outs = (torch.empty((M0, N), dtype=a0.dtype, device=a0.device), torch.empty((M1, N), dtype=a0.dtype, device=a0.device))
     vp, lg = ctypes.c_void_p, ctypes.c_long
@@ -128,15 +156,15 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
     seeds = _arr(ctypes.c_uint, drop[1] if drop else (0, 0))
     cargs = (_dt(a0), ptr2(a), ld2(a), ptr2(b), ld2(b), ptr2(outs), ld2(outs), _arr(ctypes.c_int, (M0, M1)), N, K,
              ptr2(bias), act, ptr2(residual), ld2(residual), ptr2(preact), ld2(preact), ptr2(dact_src), ld2(dact_src), dact)
-    variant = 0
+    variant = 21 if kn else 0
     if AUTOTUNE:
-        key = (a0.dtype, M0, M1, N, K, act, dact, residual[0] is not None, preact[0] is not None)
+        key = (a0.dtype, M0, M1, N, K, act, dact, residual[0] is not None, preact[0] is not None, kn)
         variant = _GEMM_BEST.get(key)
         if variant is None and torch.cuda.is_current_stream_capturing():
-            variant = 0
+            variant = 21 if kn else 0
         elif variant is None:
             best = (float("inf"), 0)
-            for v in GEMM_VARIANTS:
+            for v in ([16 + u for u in NN_VARIANTS] if kn else GEMM_VARIANTS):
                 _lib.call("vlni_gemm_nt_dual", *cargs, v, drop[0] if drop else 0.0, seeds, _st())
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -387,6 +415,12 @@ SHADOWS = ShadowCache()
 
 
 def _w(params, dtype, transposed=False):
+    """Operand form of a (possibly row-packed) parameter. transposed=True is the dgrad operand: W^T [in, out] for the NT kernels,
+    or - bf16 with NN_DGRAD - the untransposed weight wrapped in KN for the transposing-read kernels (no copy to rebuild)."""
+    if transposed and NN_DGRAD and dtype == torch.bfloat16 and params[0].dim() == 2:
+        out_f = sum(p.shape[0] for p in params)
+        if out_f % 64 == 0 and out_f >= 192 and params[0].shape[1] % 8 == 0:
+            return KN(SHADOWS.get(params, dtype, False))
     return SHADOWS.get(params, dtype, transposed)
 
 

@@ -58,7 +58,7 @@ class FlatTrainer:
         offs, n = [], 0
         for p in self.params:
             offs.append(n)
-            n += (p.numel() + 3) // 4 * 4              # 16-byte aligned slots
+            n += (p.numel() + 7) // 8 * 8              # slots aligned to 16 bytes in the bf16 mirror too (32 B in float32)
         self.n = n
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
