@@ -14,7 +14,7 @@ def t(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 st = torch.cuda.current_stream().cuda_stream
-for (N, K, M, nseg) in [(768, 768, 8192, 6), (2304, 768, 8192, 6), (3072, 768, 8192, 6), (768, 3072, 8192, 6), (768, 768, 2560, 6), (768, 768, 5120, 1), (3072, 768, 5120, 1), (512, 768, 384, 1)]:
+for (N, K, M, nseg) in [(768, 768, 2752, 6), (2304, 768, 2752, 6), (3072, 768, 2752, 6), (768, 3072, 2752, 6), (2304, 768, 5120, 1), (3072, 768, 5120, 1), (768, 3072, 5120, 1), (2304, 768, 2304, 6), (3072, 768, 2304, 6)]:
     dys = [(torch.randn(M, N, device="cuda") * 0.1).bfloat16() for _ in range(nseg)]
     xs = [(torch.randn(M, K, device="cuda") * 0.5).bfloat16() for _ in range(nseg)]
     out = torch.zeros(N, K, device="cuda"); cs = torch.zeros(N, device="cuda")
@@ -22,7 +22,7 @@ for (N, K, M, nseg) in [(768, 768, 8192, 6), (2304, 768, 8192, 6), (3072, 768, 8
     pm = (ctypes.c_int * nseg)(*[M] * nseg)
     fl = 2.0 * N * K * M * nseg
     res = []
-    for variant, splits in ((5, (4, 8)), (6, (4, 7, 9, 14, 28))):
+    for variant, splits in ((5, (4, 8, 12)), (6, (2, 4, 7, 9, 14))):
         for split in splits:
             us = t(lambda: _lib.call("vlni_gemm_tn_bf16_grouped_v", nseg, pa, pb, pm, N, K, out.data_ptr(), K, N, K, cs.data_ptr(), split, variant, st))
             res.append(f"v{variant}s{split}:{us:4.0f}us/{fl/us/1e6:3.0f}TF")

@@ -494,6 +494,44 @@ TN_VARIANT = 5          # LDS-DMA 2-stage, 8 waves: fastest of the five on every
 _WQ = {}
 
 
+_TN_BEST = {}
+
+
+def _tn_choice(n, pa, pb, pm, N, K, nmt, dev):
+    """(kernel variant, row split) of a grouped weight-gradient launch. Which of the 128x128 LDS-DMA kernel (more, smaller blocks)
+    and the 256x256 tile (half the operand traffic, one block per CU) wins, and at which split, depends on the output size and on
+    the length of the reduction (tools/tn_probe.py): the first launch of a (N, K, rows) class times the candidates on a scratch
+    output and the winner is cached."""
+    default = (TN_VARIANT, max(1, min(8, nmt // 8)))
+    if not AUTOTUNE:
+        return default
+    key = (N, K, nmt // 16)
+    best = _TN_BEST.get(key)
+    if best is not None or torch.cuda.is_current_stream_capturing():
+        return best or default
+    t128 = ((N + 127) // 128) * ((K + 127) // 128)
+    cands = {(TN_VARIANT, max(1, min(s, nmt // 3))) for s in (4, 8, 12, max(1, round(512 / t128)))}
+    if TN_BIG and N >= 256 and K >= 256 and nmt >= 32:
+        t256 = ((N + 255) // 256) * ((K + 255) // 256)
+        s6 = max(1, min(nmt // 4, round(252 / t256)))
+        cands |= {(6, s6), (6, max(1, s6 // 2))}
+    scratch = torch.zeros((N, K), dtype=torch.float32, device=dev)
+    cs = torch.zeros((N,), dtype=torch.float32, device=dev)
+    timed = []
+    for v, sp in sorted(cands):
+        args = ("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, scratch.data_ptr(), K, N, K, cs.data_ptr(), sp, v, _st())
+        _lib.call(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call(*args); _lib.call(*args)
+        e1.record()
+        e1.synchronize()
+        timed.append((e0.elapsed_time(e1), v, sp))
+    _, v, sp = min(timed)
+    _TN_BEST[key] = (v, sp)
+    return v, sp
+
+
 def flush_wgrads():
     """Runs the queued weight/bias gradient reductions (must precede any read of the .grad arena)."""
     for wv, bv, segs in _WQ.values():
@@ -505,11 +543,7 @@ def flush_wgrads():
             pb = (ctypes.c_void_p * n)(*[x.data_ptr() for _, x in chunk])
             pm = (ctypes.c_int * n)(*[d.shape[0] for d, _ in chunk])
             nmt = sum((d.shape[0] + 63) // 64 for d, _ in chunk)
-            variant, split = TN_VARIANT, max(1, min(8, nmt // 8))
-            if TN_BIG and nmt >= 256 and N >= 256 and K >= 256:
-                # long reductions (a whole episode of rows): 256 x 256 tiles, one block per CU, ~252 blocks in all
-                tiles = ((N + 255) // 256) * ((K + 255) // 256)
-                variant, split = 6, max(1, min(nmt // 8, round(252 / tiles)))
+            variant, split = _tn_choice(n, pa, pb, pm, N, K, nmt, wv.device)
             _lib.call("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
                       split, variant, _st())
     _WQ.clear()
