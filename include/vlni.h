@@ -102,6 +102,10 @@ int vlni_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n, 
 /* dst[c][r] = src[r][c] (r < R), zero for R <= r < Rpad: wgrad operands and transposed weight shadows */
 int vlni_transpose(int src_dtype, int dst_dtype, const void* src, long lds, void* dst, long ldd, int R, int C, int Rpad,
                    void* stream);
+/* Many transposes in one launch (all transposed weight shadows after an optimizer step). table_dev: n entries of 56 bytes in
+   DEVICE memory {const void* src; void* dst; long lds; long ldd; int R, C, Rpad, tile0, tiles_c, 0}, tile0 = running sum of
+   ceil(C/64)*ceil(Rpad/64) over the entries before it; total_tiles = the grand total. dst (bfloat16) [c][r] = src[r][c]. */
+int vlni_transpose_batched(int src_dtype, const void* table_dev, int n, int total_tiles, void* stream);
 /* out[n] += sum_r x[r][n]: bias gradients */
 int vlni_colsum(int dtype, const void* x, long ldx, int rows, int N, float* out, void* stream);
 /* y = x W^T + b with K <= 16 float32 features (angle 4-d R:537,599; DUET 7-/14-d position D:1093,1140-1150) */

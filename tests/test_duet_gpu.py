@@ -188,6 +188,11 @@ def test_bf16_trainer_step_with_odd_sized_parameters():
         w = m.global_encoder.encoder.x_layers[0].visn_self_att.self.query.weight
         mirror = ops._w((w,), torch.bfloat16)
         assert mirror.data_ptr() % 16 == 0 and torch.equal(mirror, w.detach().bfloat16())     # AdamW keeps the mirror current
+        # transposed (dgrad) shadows: all rebuilt by ONE batched launch after an optimizer step
+        assert ops.SHADOWS._tr and ops.SHADOWS._tr_table is not None
+        for lyr in m.global_encoder.encoder.x_layers:
+            for w2 in (lyr.visn_inter.dense.weight, lyr.visn_output.dense.weight):
+                assert torch.equal(ops._w((w2,), torch.bfloat16, True), w2.detach().bfloat16().t())
     finally:
         ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
         ops._WQ.clear()

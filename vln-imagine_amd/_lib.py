@@ -48,6 +48,7 @@ SIGNATURES = {
     "vlni_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, P],
     "vlni_sumsq": [P, L, P, P],
     "vlni_clip_coef": [P, F, P, P],
+    "vlni_transpose_batched": [I, P, I, I, P],
     "vlni_set_dropout_seed_base": [P],
     "vlni_duet_fuse_fwd": [P, P, P, P, P, I, I, I, P],
     "vlni_duet_fuse_bwd": [P, P, P, P, I, I, I, P],

@@ -36,6 +36,34 @@ __global__ __launch_bounds__(256) void transpose_kernel(const S* __restrict__ sr
   }
 }
 
+// The same 64x64 tile transpose for MANY matrices in one launch (all transposed weight shadows after an optimizer step):
+// block -> entry by binary search over the entries' first-tile indices. dst is bfloat16.
+struct TrEntry { const void* src; void* dst; long lds, ldd; int R, C, Rpad, tile0, tiles_c, pad_; };
+template <typename S>
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const TrEntry* __restrict__ tab, int n) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const TrEntry e = tab[lo];
+  const int t = blockIdx.x - e.tile0;
+  const int r0 = (t / e.tiles_c) * 64, c0 = (t % e.tiles_c) * 64;
+  const S* src = (const S*)e.src;
+  __bf16* dst = (__bf16*)e.dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < e.R && c < e.C) ? DT<S>::ld(src + (long)r * e.lds + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < e.C && r < e.Rpad) DT<__bf16>::st(dst + (long)c * e.ldd + r, tile[tx][i]);
+  }
+}
+
 // out[n] += sum_r x[r][n]      (bias gradients).  grid.x over column groups of 256, grid.y over row slabs.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ldx, int rows, int N,
@@ -417,6 +445,18 @@ extern "C" int vlni_transpose(int src_dtype, int dst_dtype, const void* src, lon
   else if (src_dtype == VLNI_F32 && dst_dtype == VLNI_F32)
     hipLaunchKernelGGL((transpose_kernel<float, float>), grid, block, 0, st, (const float*)src, lds_, (float*)dst, ldd, R, C, Rpad);
   else { vlni_set_error("transpose: bad dtypes %d %d", src_dtype, dst_dtype); return VLNI_EINVAL; }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// table: n entries of 56 bytes in DEVICE memory {src*, dst*, long lds, long ldd, int R, C, Rpad, tile0, tiles_c, 0}, tile0 =
+// running sum of ceil(C/64)*ceil(Rpad/64), entries sorted by tile0; total_tiles = the grand total. dst[c][r] = src[r][c] (bf16 out).
+extern "C" int vlni_transpose_batched(int src_dtype, const void* table_dev, int n, int total_tiles, void* stream) {
+  VLNI_CHECK(table_dev && n > 0 && total_tiles > 0, VLNI_EINVAL, "transpose_batched: n=%d tiles=%d", n, total_tiles);
+  const TrEntry* tab = (const TrEntry*)table_dev;
+  if (src_dtype == VLNI_F32) hipLaunchKernelGGL((transpose_batched_kernel<float>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
+  else if (src_dtype == VLNI_BF16) hipLaunchKernelGGL((transpose_batched_kernel<__bf16>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
+  else { vlni_set_error("transpose_batched: bad dtype %d", src_dtype); return VLNI_EINVAL; }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

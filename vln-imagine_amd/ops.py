@@ -349,10 +349,44 @@ class ShadowCache:
         self.epoch = 0
         self.opt_epoch = 0
         self.arena = None              # (flat float32 params, flat bf16 mirror)
+        self._tr = {}                  # key -> (mirror view, transposed copy): refreshed together, one launch per optimizer step
+        self._tr_table = None          # device table of vlni_transpose_batched (+ n, total tiles); None = rebuild needed
 
     def set_arena(self, flat_p, flat_b):
         self.arena = (flat_p, flat_b) if flat_p is not None else None
         self.epoch += 1
+        self._tr, self._tr_table = {}, None
+
+    def prepare(self):
+        """Builds the device table of the batched transposed-shadow refresh (a host->device copy, so not inside a graph capture)."""
+        live = {k: v for k, v in self._tr.items() if k in self._c and self._c[k][4]() is not None and self._c[k][1] is v[1]}
+        if len(live) != len(self._tr):
+            self._tr, self._tr_table = live, None
+        if self._tr_table is not None or not self._tr or torch.cuda.is_current_stream_capturing():
+            return self._tr_table is not None
+        import struct
+        buf, tile0 = bytearray(), 0
+        for src, dst in self._tr.values():
+            R, C = src.shape
+            tiles_c = (C + 63) // 64
+            buf += struct.pack("<QQqqiiiiii", src.data_ptr(), dst.data_ptr(), src.stride(0), dst.stride(0), R, C, dst.shape[1], tile0,
+                               tiles_c, 0)
+            tile0 += tiles_c * ((dst.shape[1] + 63) // 64)
+        dev = next(iter(self._tr.values()))[0].device
+        tab = torch.frombuffer(buf, dtype=torch.uint8).to(dev)
+        self._tr_table = (tab, len(self._tr), tile0)
+        return True
+
+    def _refresh_transposed(self):
+        """One launch rebuilds every transposed shadow from the (current) bf16 mirror; False = not possible right now."""
+        if not self.prepare():
+            return False
+        tab, n, tiles = self._tr_table
+        _lib.call("vlni_transpose_batched", _DT[torch.bfloat16], tab.data_ptr(), n, tiles, _st())
+        for k in self._tr:
+            e = self._c[k]
+            self._c[k] = (e[0], e[1], e[2], self.opt_epoch, e[4])
+        return True
 
     def invalidate(self, optimizer_step=False):
         """optimizer_step=True: the fused AdamW kernel just rewrote the float32 arena AND its bf16 mirror (raw pointers: tensor
@@ -383,6 +417,8 @@ class ShadowCache:
             hit = None                 # a dead parameter's id was recycled
         if hit is not None and hit[0] == ver and (hit[2] or hit[3] == self.opt_epoch):
             return hit[1]
+        if hit is not None and hit[0] == ver and key in self._tr and self._refresh_transposed():
+            return hit[1]              # steady state: only the optimizer moved the parameters, the mirror is current
         live = False                   # True: `t` aliases memory the optimizer keeps current (never stale within an epoch)
         with torch.no_grad():
             for p in params:
@@ -405,6 +441,8 @@ class ShadowCache:
                     t = cast(src, dtype)
                 elif transposed:
                     t = transpose_pad(src, src.shape[0], dtype)
+                    if mir is not None:
+                        self._tr[key], self._tr_table = (mir[1], t), None
                 else:
                     t = cast(src, dtype)
         self._c[key] = (ver, t, live, self.opt_epoch, weakref.ref(params[0]))

@@ -143,7 +143,8 @@ class GraphedStep:
                 trainer.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        ops.SHADOWS.invalidate(optimizer_step=True)      # the transposed-shadow rebuilds must be recorded inside graph 1
+        ops.SHADOWS.prepare()                            # device table of the batched transposed-shadow refresh
+        ops.SHADOWS.invalidate(optimizer_step=True)      # the transposed-shadow rebuild must be recorded inside graph 1
         # dropout: the seeds recorded in the graph are constants, their device-resident base moves on every replay
         self.seed_base = torch.zeros(1, dtype=torch.int32, device=trainer.flat_p.device)
         ops.set_seed_base(self.seed_base)
