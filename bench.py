@@ -301,7 +301,7 @@ def main():
         traffic = None
         try:      # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/); never live
             pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-            if pmc and args.dtype == "bf16":
+            if pmc and args.dtype == "bf16" and args.model == "hamt" and not args.time_batched:      # collected on the default workload only
                 traffic = round(json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["bytes_per_launch"])
         except Exception:
             traffic = None

@@ -19,13 +19,14 @@ class DuetEpisodeTensors:
         widths = [int((s["view_lens"] + s["obj_lens"]).max()) if "obj_lens" in s else int(s["view_lens"].max()) for s in ep.steps]
         base = np.concatenate([[1], 1 + np.cumsum([w + 1 for w in widths])])
         self.pano_widths, self.node_idx = widths, []
-        for s in ep.steps:
+        for t_, s in enumerate(ep.steps):
             G = s["gmap_masks"].shape[1]
             idx = np.zeros((ep.B, G), np.int64)
             for b, srcs in enumerate(s["node_src"]):
                 for j, src in enumerate(srcs):
                     idx[b, j + 1] = base[src[1]] + (0 if src[0] == "avg" else 1 + src[2])
-            self.node_idx.append(t(idx))
+            S_t = int(base[t_ + 1])                                    # bank rows per sample once step t_'s panorama is in
+            self.node_idx.append(t((idx + np.arange(ep.B)[:, None] * S_t).reshape(-1)))
 
 
 def ce_sum(logits, target):
@@ -60,8 +61,8 @@ def run_episode(model, et, use_aux=True, train_ml=0.2, cosine_weight=0.5, criter
         bank += [avg.unsqueeze(1), pano]
         # node j of sample b = one row of an earlier step's panorama output (the agent's per-node python lists + pad_tensors_wgrad,
         # agent.py:100-134), here one gather
-        idx = et.node_idx[t]
-        gmap_img = torch.gather(torch.cat(bank, 1), 1, idx.unsqueeze(2).expand(-1, -1, pano.shape[2]))
+        rows = torch.cat(bank, 1)
+        gmap_img = rows.reshape(-1, rows.shape[2]).index_select(0, et.node_idx[t]).view(et.B, -1, rows.shape[2])
         vp_img = torch.cat([torch.zeros_like(pano[:, :1]), pano], 1)           # agent.py:164-166
         ones = torch.ones(et.B, 1, dtype=torch.bool, device=pano.device)
         vlen1 = plen + 1

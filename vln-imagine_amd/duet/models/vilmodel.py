@@ -58,6 +58,7 @@ AlignWithContrastiveLossWithNegativeSamplesReverie = AlignWithContrastiveLossRev
 
 
 CACHE_TEXT_KV = os.environ.get("VLNI_CACHE_TEXT_KV", "1") == "1"
+DUAL_BRANCHES = os.environ.get("VLNI_DUET_DUAL", "1") == "1"      # global + local encoder layers as dual-problem launches
 
 
 class GraphLXRTXLayer(nn.Module):
@@ -310,8 +311,21 @@ class GlocalTextPathNavCMT(nn.Module):
                     if kv.requires_grad:
                         kv.register_hook(self._drop_kv_cache)
             kv_g, kv_l = ent[2], ent[3]
-        gmap = ge.encoder(txt, lm, gmap.contiguous(), ops.additive_mask(gmap_masks), sprels, kvs=kv_g)
-        vp = le.encoder(txt, lm, vp.contiguous(), ops.additive_mask(vp_masks), kvs=kv_l)
+        gmap, vp = gmap.contiguous(), vp.contiguous()
+        gm, vm = ops.additive_mask(gmap_masks), ops.additive_mask(vp_masks)
+        if DUAL_BRANCHES and kv_g is not None:
+            # the global-map and local-viewpoint branches are independent and have the same layer shapes: layer i of both runs as
+            # dual-problem GEMM launches (each branch alone is 2-10 row tiles, far below one wave of CUs)
+            for i, (lg, ll) in enumerate(zip(ge.encoder.x_layers, le.encoder.x_layers)):
+                gmap, vp = ops.dual_xatt_q_block(gmap, vp, kv_g[i], kv_l[i], lm, _att(lg.visual_attention), _att(ll.visual_attention),
+                                                 drop0=_drop(lg.visual_attention), drop1=_drop(ll.visual_attention))
+                gmap, vp = ops.dual_self_att_block(gmap, vp, gm, vm, _att(lg.visn_self_att), _att(ll.visn_self_att),
+                                                   drop0=_drop(lg.visn_self_att), drop1=_drop(ll.visn_self_att), bias0=sprels)
+                gmap, vp = ops.dual_ffn_block(gmap, vp, _ffn(lg.visn_inter, lg.visn_output), _ffn(ll.visn_inter, ll.visn_output),
+                                              drop0=_drop(lg.visn_output), drop1=_drop(ll.visn_output))
+        else:
+            gmap = ge.encoder(txt, lm, gmap, gm, sprels, kvs=kv_g)
+            vp = le.encoder(txt, lm, vp, vm, kvs=kv_l)
         if self.sap_fuse_linear is None:
             fuse = 0.5
         else:

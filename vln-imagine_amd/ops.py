@@ -775,7 +775,7 @@ class _DualSelfAttBlock(torch.autograd.Function):
     projections run as dual-problem GEMM launches: y_i = LN_i(dense_i(attn(x_i Wq_i, x_i Wk_i, x_i Wv_i)) + x_i)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, km0, km1, eps, drop0, drop1, *P):
+    def forward(ctx, x0, x1, km0, km1, bias0, eps, drop0, drop1, *P):
         P0, P1 = P[:10], P[10:]
         (B, S0, H), S1 = x0.shape, x1.shape[1]
         a0, a1 = _rows(_chk(x0, "x0")), _rows(_chk(x1, "x1"))
@@ -783,26 +783,27 @@ class _DualSelfAttBlock(torch.autograd.Function):
         wqkv = [_w((Pi[0], Pi[2], Pi[4]), dt) for Pi in (P0, P1)]
         bqkv = [_w((Pi[1], Pi[3], Pi[5]), torch.float32) for Pi in (P0, P1)]
         q0, q1 = gemm_nt2((a0, a1), wqkv, bias=bqkv)
-        c0, lse0 = attn_fwd(q0[:, :H], q0[:, H:2 * H], q0[:, 2 * H:], B, S0, S0, km0, drop=(drop0[0], drop0[2]))
+        c0, lse0 = attn_fwd(q0[:, :H], q0[:, H:2 * H], q0[:, 2 * H:], B, S0, S0, km0, bias0, drop=(drop0[0], drop0[2]))
         c1, lse1 = attn_fwd(q1[:, :H], q1[:, H:2 * H], q1[:, 2 * H:], B, S1, S1, km1, drop=(drop1[0], drop1[2]))
         ph = max(drop0[1], drop1[1])
         pre0, pre1 = gemm_nt2((c0, c1), (_w((P0[6],), dt), _w((P1[6],), dt)), bias=(P0[7], P1[7]), residual=(a0, a1),
                               drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
         y0, m0, r0 = ln_fwd(pre0, P0[8], P0[9], eps)
         y1, m1, r1 = ln_fwd(pre1, P1[8], P1[9], eps)
-        ctx.save_for_backward(a0, a1, q0, q1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, km0, km1)
+        ctx.save_for_backward(a0, a1, q0, q1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, km0, km1, bias0)
         ctx.P, ctx.dims, ctx.drop = (P0, P1), (B, S0, S1, H), (drop0, drop1, ph)
         return y0.view(B, S0, H), y1.view(B, S1, H)
 
     @staticmethod
     def backward(ctx, dy0, dy1):
-        a0, a1, q0, q1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, km0, km1 = ctx.saved_tensors
+        a0, a1, q0, q1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, km0, km1, bias0 = ctx.saved_tensors
         P0, P1 = ctx.P
         B, S0, S1, H = ctx.dims
         drop0, drop1, ph = ctx.drop
         dt = a0.dtype
         ng = ctx.needs_input_grad
-        w0, w1 = any(ng[7:17]), any(ng[17:27])
+        w0, w1 = any(ng[8:18]), any(ng[18:28])
+        dbias0 = torch.zeros_like(bias0) if (bias0 is not None and ng[4]) else None
         dp0, dg0, db0, dm0 = _ln_bwd_to(_rows(dy0), pre0, P0[8], P0[9], m0, r0, w0, drop=(ph, drop0[2] + 1))
         dp1, dg1, db1, dm1 = _ln_bwd_to(_rows(dy1), pre1, P1[8], P1[9], m1, r1, w1, drop=(ph, drop1[2] + 1))
         g0, g1 = [None] * 8, [None] * 8
@@ -813,7 +814,7 @@ class _DualSelfAttBlock(torch.autograd.Function):
         dc0, dc1 = gemm_nt2((dm0, dm1), (_w((P0[6],), dt, True), _w((P1[6],), dt, True)))
         dq0, dq1 = torch.empty_like(q0), torch.empty_like(q1)
         attn_bwd(q0[:, :H], q0[:, H:2 * H], q0[:, 2 * H:], c0, dc0, lse0, dq0[:, :H], dq0[:, H:2 * H], dq0[:, 2 * H:],
-                 B, S0, S0, km0, drop=(drop0[0], drop0[2]))
+                 B, S0, S0, km0, bias0, dbias0, drop=(drop0[0], drop0[2]))
         attn_bwd(q1[:, :H], q1[:, H:2 * H], q1[:, 2 * H:], c1, dc1, lse1, dq1[:, :H], dq1[:, H:2 * H], dq1[:, 2 * H:],
                  B, S1, S1, km1, drop=(drop1[0], drop1[2]))
         if w0:
@@ -822,7 +823,61 @@ class _DualSelfAttBlock(torch.autograd.Function):
             (g1[0], g1[2], g1[4]), (g1[1], g1[3], g1[5]) = _wb_grad_to((P1[0], P1[2], P1[4]), (P1[1], P1[3], P1[5]), dq1, a1)
         dx0, dx1 = gemm_nt2((dq0, dq1), (_w((P0[0], P0[2], P0[4]), dt, True), _w((P1[0], P1[2], P1[4]), dt, True)),
                             residual=(dp0, dp1))
-        return (dx0.view(B, S0, H), dx1.view(B, S1, H), None, None, None, None, None) + tuple(g0) + (dg0, db0) + tuple(g1) + (dg1, db1)
+        return (dx0.view(B, S0, H), dx1.view(B, S1, H), None, None, dbias0, None, None, None) + tuple(g0) + (dg0, db0) + tuple(g1) \
+            + (dg1, db1)
+
+
+class _DualXAttQBlock(torch.autograd.Function):
+    """Two independent cross-attention blocks against already projected contexts (DUET's global-map and local-viewpoint branches
+    attend to the same text, vilmodel.py:384-399): y_i = LN_i(dense_i(attn(q = x_i Wq_i, kv_i)) + x_i), dual-problem GEMM launches."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, kv0, kv1, mask_c, eps, drop0, drop1, *P):
+        P0, P1 = P[:6], P[6:]                        # (wq, bq, wo, bo, g, b) per branch
+        (B, S0, H), S1 = x0.shape, x1.shape[1]
+        Sk = kv0.shape[0] // B
+        a0, a1 = _rows(_chk(x0, "x0")), _rows(_chk(x1, "x1"))
+        dt = x0.dtype
+        q0, q1 = gemm_nt2((a0, a1), (_w((P0[0],), dt), _w((P1[0],), dt)), bias=(P0[1], P1[1]))
+        c0, lse0 = attn_fwd(q0, kv0[:, :H], kv0[:, H:], B, S0, Sk, mask_c, drop=(drop0[0], drop0[2]))
+        c1, lse1 = attn_fwd(q1, kv1[:, :H], kv1[:, H:], B, S1, Sk, mask_c, drop=(drop1[0], drop1[2]))
+        ph = max(drop0[1], drop1[1])
+        pre0, pre1 = gemm_nt2((c0, c1), (_w((P0[2],), dt), _w((P1[2],), dt)), bias=(P0[3], P1[3]), residual=(a0, a1),
+                              drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
+        y0, m0, r0 = ln_fwd(pre0, P0[4], P0[5], eps)
+        y1, m1, r1 = ln_fwd(pre1, P1[4], P1[5], eps)
+        ctx.save_for_backward(a0, a1, q0, q1, kv0, kv1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, mask_c)
+        ctx.P, ctx.dims, ctx.drop = (P0, P1), (B, S0, S1, Sk, H), (drop0, drop1, ph)
+        return y0.view(B, S0, H), y1.view(B, S1, H)
+
+    @staticmethod
+    def backward(ctx, dy0, dy1):
+        a0, a1, q0, q1, kv0, kv1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, mask_c = ctx.saved_tensors
+        P0, P1 = ctx.P
+        B, S0, S1, Sk, H = ctx.dims
+        drop0, drop1, ph = ctx.drop
+        dt = a0.dtype
+        ng = ctx.needs_input_grad
+        w0, w1 = any(ng[8:14]), any(ng[14:20])
+        dp0, dg0, db0, dm0 = _ln_bwd_to(_rows(dy0), pre0, P0[4], P0[5], m0, r0, w0, drop=(ph, drop0[2] + 1))
+        dp1, dg1, db1, dm1 = _ln_bwd_to(_rows(dy1), pre1, P1[4], P1[5], m1, r1, w1, drop=(ph, drop1[2] + 1))
+        g0, g1 = [None] * 4, [None] * 4
+        if w0:
+            (g0[2],), (g0[3],) = _wb_grad_to((P0[2],), (P0[3],), dm0, c0)
+        if w1:
+            (g1[2],), (g1[3],) = _wb_grad_to((P1[2],), (P1[3],), dm1, c1)
+        dc0, dc1 = gemm_nt2((dm0, dm1), (_w((P0[2],), dt, True), _w((P1[2],), dt, True)))
+        dq0, dq1 = torch.empty_like(q0), torch.empty_like(q1)
+        dkv0, dkv1 = torch.empty_like(kv0), torch.empty_like(kv1)
+        attn_bwd(q0, kv0[:, :H], kv0[:, H:], c0, dc0, lse0, dq0, dkv0[:, :H], dkv0[:, H:], B, S0, Sk, mask_c, drop=(drop0[0], drop0[2]))
+        attn_bwd(q1, kv1[:, :H], kv1[:, H:], c1, dc1, lse1, dq1, dkv1[:, :H], dkv1[:, H:], B, S1, Sk, mask_c, drop=(drop1[0], drop1[2]))
+        if w0:
+            (g0[0],), (g0[1],) = _wb_grad_to((P0[0],), (P0[1],), dq0, a0)
+        if w1:
+            (g1[0],), (g1[1],) = _wb_grad_to((P1[0],), (P1[1],), dq1, a1)
+        dx0, dx1 = gemm_nt2((dq0, dq1), (_w((P0[0],), dt, True), _w((P1[0],), dt, True)), residual=(dp0, dp1))
+        return (dx0.view(B, S0, H), dx1.view(B, S1, H), dkv0 if ng[2] else None, dkv1 if ng[3] else None, None, None, None, None) \
+            + tuple(g0) + (dg0, db0) + tuple(g1) + (dg1, db1)
 
 
 class _DualFfnBlock(torch.autograd.Function):
@@ -1379,8 +1434,14 @@ def ffn_block(x, p, eps=1e-12, drop=NO_DROP):
     return _FfnBlock.apply(x, eps, drop, *p)
 
 
-def dual_self_att_block(x0, x1, km0, km1, p0, p1, eps=1e-12, drop0=NO_DROP, drop1=NO_DROP):
-    return _DualSelfAttBlock.apply(x0, x1, km0, km1, eps, drop0, drop1, *p0, *p1)
+def dual_self_att_block(x0, x1, km0, km1, p0, p1, eps=1e-12, drop0=NO_DROP, drop1=NO_DROP, bias0=None):
+    """bias0: optional additive [B, S0, S0] attention bias of stream 0 (DUET's graph_sprels), differentiable."""
+    return _DualSelfAttBlock.apply(x0, x1, km0, km1, bias0, eps, drop0, drop1, *p0, *p1)
+
+
+def dual_xatt_q_block(x0, x1, kv0, kv1, mask_c, p0, p1, eps=1e-12, drop0=NO_DROP, drop1=NO_DROP):
+    sel = lambda p: (p[0], p[1], p[6], p[7], p[8], p[9])
+    return _DualXAttQBlock.apply(x0, x1, kv0, kv1, mask_c, eps, drop0, drop1, *sel(p0), *sel(p1))
 
 
 def dual_ffn_block(x0, x1, p0, p1, eps=1e-12, drop0=NO_DROP, drop1=NO_DROP):
