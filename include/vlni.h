@@ -141,6 +141,14 @@ int vlni_cosine_bwd(int dtype, const void* x, const void* y, const float* gcos, 
 int vlni_dropout(int dtype, const void* x, void* y, long n, float p, unsigned seed, void* stream);
 /* dz = da * act'(z), act 1 gelu-erf / 2 relu (n multiple of 4) */
 int vlni_act_bwd(int dtype, int act, const void* da, const void* z, void* dz, long n, void* stream);
+/* Observation / panorama input tensors built on the device from a resident view-feature table [n_viewpoints][36][D] (float32 or
+   bfloat16): replaces the host-side numpy assembly + per-step host->device copy of r2r/agent_cmt.py:130-176 (HAMT
+   _cand_pano_feature_variable) and map_nav_src/r2r/agent.py:67-97 (DUET _panorama_feature_variable). Per slot (b, v):
+   view[b,v] < 0 -> zeros ([STOP], padding); else image = table[vp_row[b]][view[b,v]], angle = is_cand ? [sin h, cos h, sin e, cos e]*
+   of cand_he[b,v,:] : angle_table[base_view[b]][view[b,v]] (data_utils.py:481-534). out_img [B,V,D], out_ang [B,V,A] float32. */
+int vlni_build_views(int table_dtype, const void* table, const long* vp_row, const int* view, const float* cand_he,
+                     const unsigned char* is_cand, const int* base_view, const float* angle_table, float* out_img, float* out_ang,
+                     int B, int V, int D, int A, void* stream);
 /* DUET global/local logit fusion, replaces the per-sample python loop of VLN-DUET/map_nav_src/models/vilmodel.py:1198-1217:
    src[B,G]: local candidate index that IS map node g (>= 0), -2 = unvisited node without a candidate (takes the summed local
    logits of the visited candidates), -1 = nothing to add; bw[B,V]: candidate j is an already-visited viewpoint.

@@ -1,0 +1,91 @@
+"""GPU: the device-side observation builders (vln_imagine_amd/builders.py, vlni_build_views) against literal numpy restatements of the
+reference agents' host-side builders (VLN-HAMT/finetune_src/r2r/agent_cmt.py:130-176, VLN-DUET/map_nav_src/r2r/agent.py:67-97)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+D, A = 768, 4
+
+
+def _angle_feature(h, e):                                     # r2r/data_utils.py:481-484
+    return np.array([math.sin(h), math.cos(h), math.sin(e), math.cos(e)] * (A // 4), np.float32)
+
+
+def _fake_env(n_vp=5, B=4, seed=0):
+    """Observation dicts as R2RBatch._get_obs builds them (env.py:290-335): 'feature' = [36, D + A] with the angle table of the
+    current view appended, candidates carry the view feature at their pointId + their own angle feature."""
+    from vln_imagine_amd.builders import view_angle_table
+    rng = np.random.RandomState(seed)
+    feats = rng.uniform(-0.5, 0.5, (n_vp, 36, D)).astype(np.float32)
+    keys = [f"scan_{i}" for i in range(n_vp)]
+    table = view_angle_table(A)
+    obs = []
+    for b in range(B):
+        vp = int(rng.randint(n_vp))
+        base = int(rng.randint(36))
+        cands = []
+        for j in range(int(rng.randint(1, 6))):
+            pid = int(rng.randint(36))                          # two candidates may share a view
+            h, e = float(rng.uniform(-math.pi, math.pi)), float(rng.uniform(-0.5, 0.5))
+            cands.append({"pointId": pid, "heading": h, "elevation": e, "viewpointId": f"vp{b}_{j}",
+                          "feature": np.concatenate([feats[vp, pid], _angle_feature(h, e)])})
+        obs.append({"key": keys[vp], "viewIndex": base, "candidate": cands,
+                    "feature": np.concatenate([feats[vp], table[base]], 1)})
+    return feats, keys, obs
+
+
+def test_hamt_observation_builder_matches_reference_loop():
+    from vln_imagine_amd.builders import ResidentFeatures, ViewBuilder
+    feats, keys, obs = _fake_env()
+    # ---- agent_cmt.py:130-176, restated
+    ob_lens, img_l, ang_l, nav_l = [], [], [], []
+    for ob in obs:
+        ci, ca, ct = [], [], []
+        used = np.zeros((36,), bool)
+        for cc in ob["candidate"]:
+            ci.append(cc["feature"][:D]); ca.append(cc["feature"][D:]); used[cc["pointId"]] = True; ct.append(1)
+        ci.append(np.zeros((D,), np.float32)); ca.append(np.zeros((A,), np.float32)); ct.append(2)
+        pano = ob["feature"][~used]
+        img_l.append(np.concatenate([np.vstack(ci), pano[:, :D]], 0)); ang_l.append(np.concatenate([np.vstack(ca), pano[:, D:]], 0))
+        ct.extend([0] * (36 - used.sum())); nav_l.append(ct); ob_lens.append(len(ct))
+    V = max(ob_lens)
+    pad = lambda a: np.concatenate([a, np.zeros((V - a.shape[0], a.shape[1]), np.float32)], 0)
+    ref_img, ref_ang = np.stack([pad(a) for a in img_l]), np.stack([pad(a) for a in ang_l])
+    ref_nav = np.stack([np.array(t + [0] * (V - len(t))) for t in nav_l])
+    # ---- device builder
+    vb = ViewBuilder(ResidentFeatures(feats, keys), A)
+    img, ang, nav, lens, cand_lens = vb.hamt_observation(obs)
+    assert lens == ob_lens and cand_lens == [len(ob["candidate"]) + 1 for ob in obs]
+    assert np.array_equal(img.cpu().numpy(), ref_img) and np.array_equal(nav.cpu().numpy(), ref_nav)
+    assert np.abs(ang.cpu().numpy() - ref_ang).max() < 2e-6          # device sinf / cosf vs libm
+    # a bfloat16-resident table returns the rounded features
+    vb16 = ViewBuilder(ResidentFeatures(feats, keys, dtype=torch.bfloat16), A)
+    img16 = vb16.hamt_observation(obs)[0]
+    assert torch.equal(img16.cpu(), torch.from_numpy(ref_img).bfloat16().float())
+
+
+def test_duet_panorama_builder_matches_reference_loop():
+    from vln_imagine_amd.builders import ResidentFeatures, ViewBuilder
+    feats, keys, obs = _fake_env(seed=3)
+    img_l, loc_l, nav_l, lens = [], [], [], []
+    for ob in obs:                                               # map_nav_src/r2r/agent.py:67-97, restated
+        vi, va, nt, used = [], [], [], set()
+        for cc in ob["candidate"]:
+            vi.append(cc["feature"][:D]); va.append(cc["feature"][D:]); nt.append(1); used.add(cc["pointId"])
+        vi.extend([x[:D] for k, x in enumerate(ob["feature"]) if k not in used])
+        va.extend([x[D:] for k, x in enumerate(ob["feature"]) if k not in used])
+        nt.extend([0] * (36 - len(used)))
+        vi, va = np.stack(vi, 0), np.stack(va, 0)
+        img_l.append(vi); loc_l.append(np.concatenate([va, np.ones((len(vi), 3), np.float32)], 1)); nav_l.append(nt); lens.append(len(vi))
+    V = max(lens)
+    pad = lambda a: np.concatenate([a, np.zeros((V - a.shape[0], a.shape[1]), np.float32)], 0)
+    vb = ViewBuilder(ResidentFeatures(feats, keys), A)
+    out = vb.duet_panorama(obs)
+    assert out["view_lens"].tolist() == lens
+    assert np.array_equal(out["view_img_fts"].cpu().numpy(), np.stack([pad(a) for a in img_l]))
+    assert np.abs(out["loc_fts"].cpu().numpy() - np.stack([pad(a) for a in loc_l])).max() < 2e-6
+    assert np.array_equal(out["nav_types"].cpu().numpy(), np.stack([np.array(t + [0] * (V - len(t))) for t in nav_l]))
+    assert out["cand_vpids"] == [[c["viewpointId"] for c in ob["candidate"]] for ob in obs]

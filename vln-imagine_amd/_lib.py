@@ -50,6 +50,7 @@ SIGNATURES = {
     "vlni_clip_coef": [P, F, P, P],
     "vlni_transpose_batched": [I, P, I, I, P],
     "vlni_set_dropout_seed_base": [P],
+    "vlni_build_views": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "vlni_duet_fuse_fwd": [P, P, P, P, P, I, I, I, P],
     "vlni_duet_fuse_bwd": [P, P, P, P, I, I, I, P],
     "vlni_optim_prepare": [P, F, F, F, P, P],

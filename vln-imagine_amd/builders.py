@@ -1,0 +1,115 @@
+"""Device-side builders of the per-step model inputs.
+
+The reference agents assemble every step's observation tensors on the host: python loops over candidates, numpy concatenations of
+36 x 768 view features per sample, padding, then a ~7 MB host->device copy (VLN-HAMT/finetune_src/r2r/agent_cmt.py:130-176
+`_cand_pano_feature_variable`, VLN-DUET/map_nav_src/r2r/agent.py:67-97 `_panorama_feature_variable`). Here the view features of
+all viewpoints stay resident in HBM (`ResidentFeatures`, 288 GB hold every R2R scan many times over); per step the host only
+decides WHICH view goes into which slot (a few hundred integers) and one kernel (`vlni_build_views`) gathers the rows and fills the
+angle features. The slot layout and feature values are exactly the reference's (tests/test_builders_gpu.py restates its loops).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+
+def view_angle_table(angle_feat_size=4):
+    """[36 base views][36 views][A]: angle features of the discretised panorama relative to the agent's view, closed form of
+    r2r/data_utils.py:506-534 (view ix: heading (ix % 12) * 30 deg, elevation (ix // 12 - 1) * 30 deg; base elevation 0)."""
+    t = np.empty((36, 36, angle_feat_size), np.float32)
+    for base in range(36):
+        bh = (base % 12) * math.radians(30)
+        for ix in range(36):
+            h, e = (ix % 12) * math.radians(30) - bh, (ix // 12 - 1) * math.radians(30)
+            t[base, ix] = np.array([math.sin(h), math.cos(h), math.sin(e), math.cos(e)] * (angle_feat_size // 4), np.float32)
+    return t
+
+
+class ResidentFeatures:
+    """View features of every viewpoint, resident on the device: table [n, 36, D] (float32 or bfloat16) + key -> row index.
+    Built once from whatever the feature store is (the reference reads an HDF5 file keyed 'scan_viewpoint', r2r/data_utils.py:15-47)."""
+
+    def __init__(self, feats, keys, device="cuda", dtype=torch.float32):
+        feats = torch.as_tensor(feats)
+        assert feats.dim() == 3 and feats.shape[1] == 36 and len(keys) == feats.shape[0]
+        self.table = feats.to(device=device, dtype=dtype).contiguous()
+        self.index = {k: i for i, k in enumerate(keys)}
+        self.D = feats.shape[2]
+
+    def rows(self, keys):
+        return [self.index[k] for k in keys]
+
+
+class ViewBuilder:
+    """Builds [B, V, D] image features, [B, V, A] angle features and [B, V] nav types on the device.
+
+    `obs` is the reference's observation list reduced to what the builders read: per sample a dict with
+      'key' (scan_viewpoint), 'viewIndex' (the agent's current discretised view = base view of the angle table),
+      'candidate': list of {'pointId', 'heading', 'elevation'} (relative heading / elevation of the candidate, env.py:254,287)."""
+
+    def __init__(self, features, angle_feat_size=4):
+        self.f, self.A = features, angle_feat_size
+        self.angle_table = torch.from_numpy(view_angle_table(angle_feat_size)).to(features.table.device)
+
+    def _launch(self, rows, view, he, is_cand, base):
+        dev = self.f.table.device
+        B, V = view.shape
+        t = lambda a, d: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=d, non_blocking=True)
+        rows_t, view_t, he_t = t(np.asarray(rows), torch.long), t(view, torch.int32), t(he, torch.float32)
+        cand_t, base_t = t(is_cand, torch.uint8), t(np.asarray(base), torch.int32)
+        img = torch.empty((B, V, self.f.D), dtype=torch.float32, device=dev)
+        ang = torch.empty((B, V, self.A), dtype=torch.float32, device=dev)
+        _lib.call("vlni_build_views", ops._dt(self.f.table), self.f.table.data_ptr(), rows_t.data_ptr(), view_t.data_ptr(), he_t.data_ptr(),
+                  cand_t.data_ptr(), base_t.data_ptr(), self.angle_table.data_ptr(), img.data_ptr(), ang.data_ptr(), B, V, self.f.D, self.A,
+                  ops._st())
+        return img, ang
+
+    def hamt_observation(self, obs, views=36):
+        """HAMT `_cand_pano_feature_variable` (agent_cmt.py:130-176): candidates, [STOP] (zeros, nav type 2), the non-candidate
+        views in view order (nav type 0), zero padding. Returns (ob_img_fts, ob_ang_fts, ob_nav_types, ob_lens, ob_cand_lens)."""
+        B = len(obs)
+        lens = [len(ob["candidate"]) + 1 + views - len({c["pointId"] for c in ob["candidate"]}) for ob in obs]
+        V = max(lens)
+        view = np.full((B, V), -1, np.int32)
+        he = np.zeros((B, V, 2), np.float32)
+        is_cand = np.zeros((B, V), np.uint8)
+        nav = np.zeros((B, V), np.int64)
+        for i, ob in enumerate(obs):
+            n = len(ob["candidate"])
+            used = set()
+            for j, c in enumerate(ob["candidate"]):
+                view[i, j], he[i, j], is_cand[i, j], nav[i, j] = c["pointId"], (c["heading"], c["elevation"]), 1, 1
+                used.add(c["pointId"])
+            nav[i, n] = 2                                          # [STOP]: zero features
+            rest = [v for v in range(views) if v not in used]
+            view[i, n + 1:n + 1 + len(rest)] = rest
+        img, ang = self._launch(self.f.rows([ob["key"] for ob in obs]), view, he, is_cand, [ob["viewIndex"] for ob in obs])
+        return img, ang, torch.from_numpy(nav).to(img.device), lens, [len(ob["candidate"]) + 1 for ob in obs]
+
+    def duet_panorama(self, obs, views=36):
+        """DUET `_panorama_feature_variable` (map_nav_src/r2r/agent.py:67-97): candidate views first (nav type 1), then the
+        views no candidate uses (nav type 0); loc_fts = [angle(4), box (1, 1, 1)]. Returns the `panorama` batch entries."""
+        B = len(obs)
+        view = np.full((B, views), -1, np.int32)
+        he = np.zeros((B, views, 2), np.float32)
+        is_cand = np.zeros((B, views), np.uint8)
+        nav = np.zeros((B, views), np.int64)
+        lens, cand_vpids = [], []
+        for i, ob in enumerate(obs):
+            used, n = set(), 0
+            for c in ob["candidate"]:
+                view[i, n], he[i, n], is_cand[i, n], nav[i, n] = c["pointId"], (c["heading"], c["elevation"]), 1, 1
+                used.add(c["pointId"])
+                n += 1
+            rest = [v for v in range(views) if v not in used]
+            view[i, n:n + len(rest)] = rest
+            lens.append(n + len(rest))
+            cand_vpids.append([c.get("viewpointId") for c in ob["candidate"]])
+        V = max(lens)
+        img, ang = self._launch(self.f.rows([ob["key"] for ob in obs]), view[:, :V], he[:, :V], is_cand[:, :V], [ob["viewIndex"] for ob in obs])
+        valid = torch.from_numpy((view[:, :V] >= 0)).to(img.device)
+        loc = torch.cat([ang, valid.unsqueeze(2).expand(-1, -1, 3).to(ang.dtype)], 2)            # box features are all ones
+        return {"view_img_fts": img, "loc_fts": loc, "nav_types": torch.from_numpy(nav[:, :V]).to(img.device),
+                "view_lens": torch.tensor(lens, device=img.device), "cand_vpids": cand_vpids}

@@ -407,6 +407,40 @@ __global__ __launch_bounds__(64) void duet_fuse_bwd_kernel(const float* __restri
   }
 }
 
+// Observation / panorama tensors assembled ON THE DEVICE from a resident feature table (replaces the numpy
+// concatenations + 7 MB host->device copy per step of VLN-HAMT/finetune_src/r2r/agent_cmt.py:130-176 and
+// VLN-DUET/map_nav_src/r2r/agent.py:67-97). One block per output slot (b, v):
+//   view[b,v] >= 0: image row = table[vp_row[b]][view[b,v]][:]; angle = (cand_he given ? angle_feature(h, e) : angle_table[base_view[b]][view])
+//   view[b,v] <  0: zeros ([STOP] slot and padding)
+template <typename S>
+__global__ __launch_bounds__(256) void build_views_kernel(const S* __restrict__ table, const long* __restrict__ vp_row,
+                                                          const int* __restrict__ view, const float* __restrict__ cand_he,
+                                                          const unsigned char* __restrict__ is_cand, const int* __restrict__ base_view,
+                                                          const float* __restrict__ angle_table, float* __restrict__ out_img,
+                                                          float* __restrict__ out_ang, int V, int D, int A) {
+  const int slot = blockIdx.x, b = slot / V;
+  const int vw = view[slot];
+  float* oi = out_img + (long)slot * D;
+  if (vw < 0) {
+    for (int c = threadIdx.x; c < D; c += 256) oi[c] = 0.f;
+    if (threadIdx.x < A) out_ang[(long)slot * A + threadIdx.x] = 0.f;
+    return;
+  }
+  const S* src = table + ((long)vp_row[b] * 36 + vw) * D;
+  for (int c = threadIdx.x; c < D; c += 256) oi[c] = DT<S>::ld(src + c);
+  if (threadIdx.x < A) {
+    float v;
+    if (is_cand[slot]) {
+      const float hd = cand_he[2 * slot], el = cand_he[2 * slot + 1];
+      const int q = threadIdx.x & 3;                     // [sin h, cos h, sin e, cos e] repeated A/4 times
+      v = q == 0 ? sinf(hd) : q == 1 ? cosf(hd) : q == 2 ? sinf(el) : cosf(el);
+    } else {
+      v = angle_table[((long)base_view[b] * 36 + vw) * A + threadIdx.x];
+    }
+    out_ang[(long)slot * A + threadIdx.x] = v;
+  }
+}
+
 }  // namespace
 
 #define BY_DTYPE(dtype, CALL_F32, CALL_BF16)        \
@@ -616,6 +650,21 @@ extern "C" int vlni_sumsq(const float* g, long n, float* sumsq, void* stream) {
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
+extern "C" int vlni_build_views(int table_dtype, const void* table, const long* vp_row, const int* view, const float* cand_he,
+                                const unsigned char* is_cand, const int* base_view, const float* angle_table, float* out_img,
+                                float* out_ang, int B, int V, int D, int A, void* stream) {
+  VLNI_CHECK(B > 0 && V > 0 && D > 0 && A > 0 && A <= 256 && A % 4 == 0, VLNI_EINVAL, "build_views: B=%d V=%d D=%d A=%d", B, V, D, A);
+  VLNI_CHECK(table && vp_row && view && cand_he && is_cand && base_view && angle_table && out_img && out_ang, VLNI_EINVAL,
+             "build_views: null pointer");
+  BY_DTYPE(table_dtype,
+           hipLaunchKernelGGL((build_views_kernel<float>), dim3(B * V), dim3(256), 0, (hipStream_t)stream, (const float*)table, vp_row, view,
+                              cand_he, is_cand, base_view, angle_table, out_img, out_ang, V, D, A),
+           hipLaunchKernelGGL((build_views_kernel<__bf16>), dim3(B * V), dim3(256), 0, (hipStream_t)stream, (const __bf16*)table, vp_row, view,
+                              cand_he, is_cand, base_view, angle_table, out_img, out_ang, V, D, A));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
 extern "C" int vlni_duet_fuse_fwd(const float* gl, const float* ll, const int* src, const unsigned char* bw, float* out, int B,
                                   int G, int V, void* stream) {
   VLNI_CHECK(B > 0 && G > 0 && V > 0 && gl && ll && src && bw && out, VLNI_EINVAL, "duet_fuse_fwd: B=%d G=%d V=%d", B, G, V);
