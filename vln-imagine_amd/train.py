@@ -100,6 +100,15 @@ class FlatTrainer:
     def set_lr(self, lr):
         self.lr_dev.fill_(lr)
 
+    def close(self):
+        """Undoes the process-wide switches the constructor flipped (direct gradient accumulation, deferred weight gradients,
+        the registered parameter arena, a registered dropout seed base). The parameters keep pointing into the arenas."""
+        ops._WQ.clear()
+        ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
+        if ops.SHADOWS.arena is not None and ops.SHADOWS.arena[0] is self.flat_p:
+            ops.SHADOWS.set_arena(None, None)
+        ops.set_seed_base(None)
+
     def step(self):
         self.flush()
         st = torch.cuda.current_stream().cuda_stream
