@@ -472,6 +472,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_big_kernel(GemmP p) {
     if (NST == 3 && t + 1 < nk) {
       if constexpr (IA + IB == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       else if constexpr (IA + IB == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (IA + IB == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1135,14 +1136,22 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
     else hipLaunchKernelGGL((gemm_nn_glds_kernel<2, 8>), grid, dim3(512), 2 * ST, st, p);
   } else if (variant >= 6) {
     // 6: 256x128 tile, 3 stages; 7: 256x256 tile, 2 stages; 8: 128x256 tile, 3 stages (8 waves each)
+    // 9 / 10 / 11: SMALL tiles 64x128 / 128x64 / 64x64 (4 waves, 3 stages, 2-3 blocks per CU) for launches that do not fill one
+    // round of 128x128 tiles: their time is one tile's latency, so more and shorter tiles win (history encoder, M = 2.3 k rows)
     if (dtype == VLNI_F32) {
       if (variant == 6) gemm_big_go<float, 3, 4, 2, 2, 2>(p, st);
       else if (variant == 7) gemm_big_go<float, 2, 2, 4, 4, 2>(p, st);
-      else gemm_big_go<float, 3, 2, 4, 2, 2>(p, st);
+      else if (variant == 8) gemm_big_go<float, 3, 2, 4, 2, 2>(p, st);
+      else if (variant == 9) gemm_big_go<float, 3, 2, 2, 1, 2>(p, st);
+      else if (variant == 10) gemm_big_go<float, 3, 2, 2, 2, 1>(p, st);
+      else gemm_big_go<float, 3, 2, 2, 1, 1>(p, st);
     } else {
       if (variant == 6) gemm_big_go<__bf16, 3, 4, 2, 2, 2>(p, st);
       else if (variant == 7) gemm_big_go<__bf16, 2, 2, 4, 4, 2>(p, st);
-      else gemm_big_go<__bf16, 3, 2, 4, 2, 2>(p, st);
+      else if (variant == 8) gemm_big_go<__bf16, 3, 2, 4, 2, 2>(p, st);
+      else if (variant == 9) gemm_big_go<__bf16, 3, 2, 2, 1, 2>(p, st);
+      else if (variant == 10) gemm_big_go<__bf16, 3, 2, 2, 2, 1>(p, st);
+      else gemm_big_go<__bf16, 3, 2, 2, 1, 1>(p, st);
     }
   } else if (variant >= 2) {
     constexpr int ST = (BM + BN) * ROWB;
