@@ -117,6 +117,100 @@ template <> struct Mma<float> {
   }
 };
 
+// LDS-only workgroup barrier for the epilogues: __syncthreads() fences, and in a kernel that uses LDS-DMA hipcc turns that fence into
+// s_waitcnt vmcnt(0) - i.e. every barrier would also wait for the round trip of the global STORES issued just before it.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// One 64-row slab of the tile, staged in LDS as float32 [64][TBN_]: every thread finishes 4 consecutive columns of NPASS rows.
+// Per group of <= 4 passes the order is: all global loads (GELU' source, residual) -> all LDS reads -> math -> all stores, so no
+// store ever sits between a load and its use and no LDS read waits for a store round trip (measured: 8.4 k -> ~3 k cycles per tile).
+template <typename T, int TBN_, int NTH>
+__device__ __forceinline__ void epilogue_slab(const GemmP& p, const float* e, int row0, int n0, int tid, const f32x4& bv, unsigned dseed) {
+  constexpr int TPR = TBN_ / 4, RPP = NTH / TPR, NPASS = 64 / RPP, GP = NPASS < 4 ? NPASS : 4;
+  const int c4 = (tid % TPR) * 4, gcol = n0 + c4, rl0 = tid / TPR;
+  if (gcol >= p.N) return;
+  if (p.vec_ok) {
+#pragma unroll
+    for (int g = 0; g < NPASS; g += GP) {
+      f32x4 z[GP], rs[GP], v[GP];
+      if (p.dact) {
+#pragma unroll
+        for (int k = 0; k < GP; ++k) {
+          const int grow = min(row0 + rl0 + RPP * (g + k), p.M - 1);
+          z[k] = DT<T>::ld4((const T*)p.dact_src + (long)grow * p.ldd + gcol);
+        }
+      }
+      if (p.residual) {
+#pragma unroll
+        for (int k = 0; k < GP; ++k) {
+          const int grow = min(row0 + rl0 + RPP * (g + k), p.M - 1);
+          rs[k] = DT<T>::ld4((const T*)p.residual + (long)grow * p.ldr + gcol);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < GP; ++k) v[k] = *(const f32x4*)(e + (rl0 + RPP * (g + k)) * TBN_ + c4);
+      // all the math first (it consumes every loaded register), then nothing but stores: no wait of any kind between the stores
+      f32x4 pre[GP];
+#pragma unroll
+      for (int k = 0; k < GP; ++k) {
+        const int grow = row0 + rl0 + RPP * (g + k);
+        f32x4 w = v[k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = w[u] * p.alpha + bv[u];
+        pre[k] = w;
+        if (p.dact) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[u] *= (p.dact == 1) ? gelu_grad_t<T>(z[k][u]) : (z[k][u] > 0.f ? 1.f : 0.f);
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[u] = gelu_t<T>(w[u]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[u] = fmaxf(w[u], 0.f);
+        }
+        if (p.drop_thr) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) w[u] *= drop_scale((unsigned)grow * (unsigned)p.N + gcol + u, dseed, p.drop_thr, p.drop_inv);
+        }
+        if (p.residual) w += rs[k];
+        v[k] = w;
+      }
+#pragma unroll
+      for (int k = 0; k < GP; ++k) {
+        const int grow = row0 + rl0 + RPP * (g + k);
+        if (grow >= p.M) continue;
+        if (p.preact) DT<T>::st4((T*)p.preact + (long)grow * p.ldp + gcol, pre[k]);
+        DT<T>::st4((T*)p.C + (long)grow * p.ldc + gcol, v[k]);
+      }
+    }
+  } else {
+    for (int k = 0; k < NPASS; ++k) {
+      const int rl = rl0 + RPP * k, grow = row0 + rl;
+      if (grow >= p.M) continue;
+      const f32x4 v = *(const f32x4*)(e + rl * TBN_ + c4);
+      for (int u = 0; u < 4 && gcol + u < p.N; ++u) {
+        float w = v[u] * p.alpha + bv[u];
+        const long col = gcol + u;
+        if (p.preact) DT<T>::st((T*)p.preact + (long)grow * p.ldp + col, w);
+        if (p.dact) {
+          const float zz = DT<T>::ld((const T*)p.dact_src + (long)grow * p.ldd + col);
+          w *= (p.dact == 1) ? gelu_grad_t<T>(zz) : (zz > 0.f ? 1.f : 0.f);
+        }
+        if (p.act == 1) w = gelu_t<T>(w);
+        else if (p.act == 2) w = fmaxf(w, 0.f);
+        if (p.drop_thr) w *= drop_scale((unsigned)grow * (unsigned)p.N + (unsigned)col, dseed, p.drop_thr, p.drop_inv);
+        if (p.residual) w += DT<T>::ld((const T*)p.residual + (long)grow * p.ldr + col);
+        DT<T>::st((T*)p.C + (long)grow * p.ldc + col, w);
+      }
+    }
+  }
+}
+
 template <typename T, int NW>      // NW waves: 2 (M) x NW/2 (N); a wave owns 64 rows x (256/NW) columns
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16 (&acc)[2][NW == 4 ? 2 : 1], int m0, int n0,
                                               int tid, int wr, int wc, int r, int h) {
@@ -144,8 +238,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16
   //      residual with 16-B (8-B bf16) global accesses, 32 threads per 128-column row (full cache lines).
   float* const e = (float*)smem;
   const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
-  const int c4 = (tid & 31) * 4;
-  const int gcol = n0 + c4;
+  const int gcol = n0 + (tid & 31) * 4;
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (p.bias && gcol < p.N) {
     if (p.vec_ok) bv = *(const f32x4*)(p.bias + gcol);
@@ -163,53 +256,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, char* smem, f32x16
           for (int x = 0; x < 16; ++x)
             e[(i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h) * BN + wc * WCOLS + j * 32 + r] = acc[i][j][x];
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NPASS; ++k) {
-      const int rl = (tid >> 5) + RPP * k;
-      const int grow = m0 + half * 64 + rl;
-      if (grow >= p.M || gcol >= p.N) continue;
-      f32x4 v = *(const f32x4*)(e + rl * BN + c4);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = v[u] * p.alpha + bv[u];
-      if (p.vec_ok) {
-        if (p.preact) DT<T>::st4((T*)p.preact + (long)grow * p.ldp + gcol, v);
-        if (p.dact) {
-          const f32x4 z = DT<T>::ld4((const T*)p.dact_src + (long)grow * p.ldd + gcol);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] *= (p.dact == 1) ? gelu_grad_t<T>(z[u]) : (z[u] > 0.f ? 1.f : 0.f);
-        }
-        if (p.act == 1) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = gelu_t<T>(v[u]);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
-        }
-        if (p.drop_thr) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] *= drop_scale((unsigned)grow * (unsigned)p.N + gcol + u, dseed, p.drop_thr, p.drop_inv);
-        }
-        if (p.residual) v += DT<T>::ld4((const T*)p.residual + (long)grow * p.ldr + gcol);
-        DT<T>::st4((T*)p.C + (long)grow * p.ldc + gcol, v);
-      } else {
-        for (int u = 0; u < 4 && gcol + u < p.N; ++u) {
-          float w = v[u];
-          const long col = gcol + u;
-          if (p.preact) DT<T>::st((T*)p.preact + (long)grow * p.ldp + col, w);
-          if (p.dact) {
-            const float z = DT<T>::ld((const T*)p.dact_src + (long)grow * p.ldd + col);
-            w *= (p.dact == 1) ? gelu_grad_t<T>(z) : (z > 0.f ? 1.f : 0.f);
-          }
-          if (p.act == 1) w = gelu_t<T>(w);
-          else if (p.act == 2) w = fmaxf(w, 0.f);
-          if (p.drop_thr) w *= drop_scale((unsigned)grow * (unsigned)p.N + (unsigned)col, dseed, p.drop_thr, p.drop_inv);
-          if (p.residual) w += DT<T>::ld((const T*)p.residual + (long)grow * p.ldr + col);
-          DT<T>::st((T*)p.C + (long)grow * p.ldc + col, w);
-        }
-      }
-    }
-    __syncthreads();
+    lds_barrier();
+    epilogue_slab<T, BN, NW * 64>(p, e, m0 + half * 64, n0, tid, bv, dseed);
+    lds_barrier();
   }
 }
 
@@ -490,8 +539,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_big_kernel(GemmP p) {
   // ---- epilogue: 64-row slabs of the tile go through LDS as [64][TBN] float32, then row-wise 4-column vectors ----
   float* const e = (float*)dsmem;
   const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
-  constexpr int TPR = TBN / 4, RPP = NTH / TPR, NPASS = 64 / RPP;
-  const int c4 = (tid % TPR) * 4, gcol = n0 + c4;
+  const int gcol = n0 + (tid % (TBN / 4)) * 4;
   f32x4 bv = {0.f, 0.f, 0.f, 0.f};
   if (p.bias && gcol < p.N) {
     if (p.vec_ok) bv = *(const f32x4*)(p.bias + gcol);
@@ -511,53 +559,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_big_kernel(GemmP p) {
             e[((blk & 1) * 32 + (x & 3) + 8 * (x >> 2) + 4 * h) * TBN + wc * WCOLS + j * 32 + r] = acc[i][j][x];
       }
     }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NPASS; ++k) {
-      const int rl = tid / TPR + RPP * k;
-      const int grow = m0 + c * 64 + rl;
-      if (grow >= p.M || gcol >= p.N) continue;
-      f32x4 v = *(const f32x4*)(e + rl * TBN + c4);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = v[u] * p.alpha + bv[u];
-      if (p.vec_ok) {
-        if (p.preact) DT<T>::st4((T*)p.preact + (long)grow * p.ldp + gcol, v);
-        if (p.dact) {
-          const f32x4 z = DT<T>::ld4((const T*)p.dact_src + (long)grow * p.ldd + gcol);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] *= (p.dact == 1) ? gelu_grad_t<T>(z[u]) : (z[u] > 0.f ? 1.f : 0.f);
-        }
-        if (p.act == 1) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = gelu_t<T>(v[u]);
-        } else if (p.act == 2) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u], 0.f);
-        }
-        if (p.drop_thr) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) v[u] *= drop_scale((unsigned)grow * (unsigned)p.N + gcol + u, dseed, p.drop_thr, p.drop_inv);
-        }
-        if (p.residual) v += DT<T>::ld4((const T*)p.residual + (long)grow * p.ldr + gcol);
-        DT<T>::st4((T*)p.C + (long)grow * p.ldc + gcol, v);
-      } else {
-        for (int u = 0; u < 4 && gcol + u < p.N; ++u) {
-          float w = v[u];
-          const long col = gcol + u;
-          if (p.preact) DT<T>::st((T*)p.preact + (long)grow * p.ldp + col, w);
-          if (p.dact) {
-            const float z = DT<T>::ld((const T*)p.dact_src + (long)grow * p.ldd + col);
-            w *= (p.dact == 1) ? gelu_grad_t<T>(z) : (z > 0.f ? 1.f : 0.f);
-          }
-          if (p.act == 1) w = gelu_t<T>(w);
-          else if (p.act == 2) w = fmaxf(w, 0.f);
-          if (p.drop_thr) w *= drop_scale((unsigned)grow * (unsigned)p.N + (unsigned)col, dseed, p.drop_thr, p.drop_inv);
-          if (p.residual) w += DT<T>::ld((const T*)p.residual + (long)grow * p.ldr + col);
-          DT<T>::st((T*)p.C + (long)grow * p.ldc + col, w);
-        }
-      }
-    }
-    __syncthreads();
+    lds_barrier();
+    epilogue_slab<T, TBN, NTH>(p, e, m0 + c * 64, n0, tid, bv, dseed);
+    lds_barrier();
   }
 }
 
