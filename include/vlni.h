@@ -40,7 +40,7 @@ int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, vo
                  const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32, void* stream);
 
 /* Same with an explicit kernel variant: 0 auto, 1 register-staged 32 KiB, 2 / 3 LDS-DMA 2- / 3-stage, 4 / 5 the same with 8 waves,
-   6 / 7 / 8 LDS-DMA large tiles 256x128 / 256x256 / 128x256, 9 / 10 / 11 small tiles 64x128 / 128x64 / 64x64; results identical.
+   6 / 7 / 8 LDS-DMA large tiles 256x128 / 256x256 / 128x256, 9 / 10 / 11 small tiles 64x128 / 128x64 / 64x64, 12 / 13 tiles 192x128 / 128x192 (two blocks per CU); results identical.
    variant + 16: B is given as [K,N] row-major with ldb >= N, i.e. the forward weight W[out,in] itself as the dgrad operand
    (dX = dY * W) - no transposed weight copy; bf16 only, K % 64 == 0, K >= 192, N % 8 == 0, pipelines 2..5. */
 int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,

@@ -395,7 +395,7 @@ def test_wgrad_tn_lds_dma_variants_exact(ops, variant):
     assert torch.equal(cs.cpu(), sum(d.sum(0) for d in dys))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_gemm_variants_identical(ops, variant):
     """All GEMM pipelines (register-staged, LDS-DMA 2/3-stage with 4 or 8 waves, large tiles 256x128 / 256x256 / 128x256) give
     bit-identical results, incl. epilogues and ragged tile edges."""
@@ -411,7 +411,7 @@ def test_gemm_variants_identical(ops, variant):
             assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (variant, dtype, M, N, K)
 
 
-@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_gemm_dual_launch_variants(ops, variant):
     """Two problems in one launch (language + vision stream) == two single launches, for every tile geometry."""
     saved = (ops.AUTOTUNE, ops.GEMM_VARIANTS)

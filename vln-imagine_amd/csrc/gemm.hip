@@ -128,11 +128,13 @@ __device__ __forceinline__ void lds_barrier() {
 // One 64-row slab of the tile, staged in LDS as float32 [64][TBN_]: every thread finishes 4 consecutive columns of NPASS rows.
 // Per group of <= 4 passes the order is: all global loads (GELU' source, residual) -> all LDS reads -> math -> all stores, so no
 // store ever sits between a load and its use and no LDS read waits for a store round trip (measured: 8.4 k -> ~3 k cycles per tile).
-template <typename T, int TBN_, int NTH>
+template <typename T, int TBN_, int NTH, int GPMAX = 4>
 __device__ __forceinline__ void epilogue_slab(const GemmP& p, const float* e, int row0, int n0, int tid, const f32x4& bv, unsigned dseed) {
-  constexpr int TPR = TBN_ / 4, RPP = NTH / TPR, NPASS = 64 / RPP, GP = NPASS < 4 ? NPASS : 4;
+  constexpr int TPR = TBN_ / 4;                                  // threads per row
+  constexpr int RPP0 = NTH / TPR, RPP = RPP0 >= 16 ? 16 : RPP0 >= 8 ? 8 : RPP0 >= 4 ? 4 : 2;    // rows per pass: a power of two dividing 64
+  constexpr int NPASS = 64 / RPP, GP = NPASS < GPMAX ? NPASS : GPMAX;
   const int c4 = (tid % TPR) * 4, gcol = n0 + c4, rl0 = tid / TPR;
-  if (gcol >= p.N) return;
+  if (gcol >= p.N || rl0 >= RPP) return;                         // (192-column tiles leave 512 - 48 * 8 threads without a row)
   if (p.vec_ok) {
 #pragma unroll
     for (int g = 0; g < NPASS; g += GP) {
@@ -462,7 +464,7 @@ template <> struct MmaG<float> {
 };
 
 template <typename T, int NST, int WM, int WN, int MI, int NJ>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_nt_big_kernel(GemmP p) {
+__global__ __launch_bounds__(WM * WN * 64, (NST * (WM * MI + WN * NJ) * 32 * ROWB <= 80 * 1024) ? (WM * WN / 2) : 1) void gemm_nt_big_kernel(GemmP p) {
   constexpr int ES = sizeof(T), NW = WM * WN, NTH = NW * 64;
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, WROWS = MI * 32, WCOLS = NJ * 32;
   constexpr int STAGE = (TBM + TBN) * ROWB;
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_nt_big_kernel(GemmP p) {
       }
     }
     lds_barrier();
-    epilogue_slab<T, TBN, NTH>(p, e, m0 + c * 64, n0, tid, bv, dseed);
+    epilogue_slab<T, TBN, NTH, 2>(p, e, m0 + c * 64, n0, tid, bv, dseed);
     lds_barrier();
   }
 }
@@ -1140,6 +1142,8 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
     else hipLaunchKernelGGL((gemm_nn_glds_kernel<2, 8>), grid, dim3(512), 2 * ST, st, p);
   } else if (variant >= 6) {
     // 6: 256x128 tile, 3 stages; 7: 256x256 tile, 2 stages; 8: 128x256 tile, 3 stages (8 waves each)
+    // 12 / 13: 192x128 / 128x192 tiles, 2 stages = 80 KiB -> TWO blocks fill the CU's 160 KiB of LDS: 17 % fewer operand bytes per
+    // flop than 128x128 through the CU's vector-memory pipe (the bound here) while keeping the 2-blocks-per-CU overlap of epilogues
     // 9 / 10 / 11: SMALL tiles 64x128 / 128x64 / 64x64 (4 waves, 3 stages, 2-3 blocks per CU) for launches that do not fill one
     // round of 128x128 tiles: their time is one tile's latency, so more and shorter tiles win (history encoder, M = 2.3 k rows)
     if (dtype == VLNI_F32) {
@@ -1148,6 +1152,8 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
       else if (variant == 8) gemm_big_go<float, 3, 2, 4, 2, 2>(p, st);
       else if (variant == 9) gemm_big_go<float, 3, 2, 2, 1, 2>(p, st);
       else if (variant == 10) gemm_big_go<float, 3, 2, 2, 2, 1>(p, st);
+      else if (variant == 12) gemm_big_go<float, 2, 2, 4, 3, 1>(p, st);
+      else if (variant == 13) gemm_big_go<float, 2, 4, 2, 1, 3>(p, st);
       else gemm_big_go<float, 3, 2, 2, 1, 1>(p, st);
     } else {
       if (variant == 6) gemm_big_go<__bf16, 3, 4, 2, 2, 2>(p, st);
@@ -1155,6 +1161,8 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
       else if (variant == 8) gemm_big_go<__bf16, 3, 2, 4, 2, 2>(p, st);
       else if (variant == 9) gemm_big_go<__bf16, 3, 2, 2, 1, 2>(p, st);
       else if (variant == 10) gemm_big_go<__bf16, 3, 2, 2, 2, 1>(p, st);
+      else if (variant == 12) gemm_big_go<__bf16, 2, 2, 4, 3, 1>(p, st);
+      else if (variant == 13) gemm_big_go<__bf16, 2, 4, 2, 1, 3>(p, st);
       else gemm_big_go<__bf16, 3, 2, 2, 1, 1>(p, st);
     }
   } else if (variant >= 2) {

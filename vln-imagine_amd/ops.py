@@ -62,7 +62,7 @@ def _rows(t):
 # count fills 256 CUs and on how many operand bytes each CU pulls per output. The first call of a shape
 # times each once with HIP events (a few hundred microseconds) and the winner is cached for the life of the process.
 AUTOTUNE = True
-GEMM_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)
+GEMM_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)
 _GEMM_BEST = {}
 
 
