@@ -15,7 +15,7 @@ out = [f"# rocprofv3 --kernel-trace --stats ({tag})", "",
        "launches; the first warm-up step also holds the per-shape GEMM autotune trials, ~8 variants x 3 launches per shape)", "",
        f"bench line under the profiler: {line['value']} episodes/s, {line['ms_per_step']} ms/step",
        f"kernel time total {tot/1e6:.1f} ms over {steps} steps = {tot/1e6/steps:.2f} ms/step",
-       f"dominant kernel family gemm_nt* (one contraction, eight pipelines): {nt_calls/steps:.0f} launches/step, average "
+       f"dominant kernel family gemm_nt* (one contraction, thirteen pipelines): {nt_calls/steps:.0f} launches/step, average "
        f"{nt_ns/nt_calls/1e3:.1f} us per launch (rocprof, all launches incl. autotune trials) vs roofline.avg_launch_us "
        f"{line['roofline']['avg_launch_us']} us (HIP events around each launch of one eager step inside bench.py, behind a 50-ms spin "
        "kernel so that the pairs bracket the kernels only; each pair still adds ~2 us)", "",
