@@ -130,11 +130,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # "nccl" IS RCCL on ROCm; VLNI_DIST_BACKEND=gloo + VLNI_ONE_GPU=1 rehearse the multi-rank path on a 1-GPU box
-        dist.init_process_group(os.environ.get("VLNI_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
@@ -142,6 +137,13 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # "nccl" IS RCCL on ROCm; VLNI_DIST_BACKEND=gloo + VLNI_ONE_GPU=1 rehearse the multi-rank path on a 1-GPU box
+        backend = os.environ.get("VLNI_DIST_BACKEND", "nccl")
+        kw = {"device_id": dev} if backend == "nccl" else {}       # bind the communicator to this rank's GPU up front
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
 
     from vln_imagine_amd import ops, synth
     from vln_imagine_amd.hamt.config import HamtConfig
