@@ -1,0 +1,32 @@
+"""Which torch-native (aten) ops still run in one bench step, and from where (python source line)? torch.profiler with stacks."""
+import sys, os, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from vln_imagine_amd import ops, synth
+from vln_imagine_amd.hamt.config import HamtConfig
+from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+from vln_imagine_amd.train import FlatTrainer
+import bench
+cfg = HamtConfig()
+model = bench.make_model(cfg, torch.bfloat16, torch.device("cuda"))
+tr = FlatTrainer(model)
+et = EpisodeTensors(synth.HamtEpisode(tag="hp", B=8, L=80, V=37, I=6, T=6, ragged=False), "cuda")
+def step():
+    tr.zero_grad()
+    out = run_episode(model, et, criterion=ops.cross_entropy_sum, keep=False)
+    out["loss"].backward()
+    tr.step()
+for _ in range(3): step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+    step()
+torch.cuda.synchronize()
+cnt = collections.Counter()
+for ev in prof.events():
+    if ev.name.startswith("aten::") and ev.name not in ("aten::empty", "aten::view", "aten::as_strided", "aten::reshape", "aten::empty_like", "aten::empty_strided",
+                                                          "aten::slice", "aten::select", "aten::expand", "aten::detach", "aten::_unsafe_view", "aten::unsqueeze", "aten::squeeze", "aten::transpose", "aten::t", "aten::alias", "aten::result_type", "aten::to", "aten::contiguous", "aten::is_nonzero", "aten::item", "aten::_local_scalar_dense", "aten::lift_fresh", "aten::permute", "aten::unbind", "aten::narrow", "aten::split", "aten::chunk", "aten::flatten", "aten::view_as", "aten::size", "aten::stride", "aten::numel", "aten::dim", "aten::resize_", "aten::set_", "aten::record_stream", "aten::clone", "aten::ones_like", "aten::zeros_like", "aten::new_zeros", "aten::new_empty", "aten::expand_as", "aten::unflatten", "aten::unsafe_split", "aten::_reshape_alias"):
+        src = next((s for s in (ev.stack or []) if "vln-imagine_amd" in s or "vln_imagine_amd" in s), "backward/engine")
+        cnt[(ev.name, src.split("/")[-1][:70])] += 1
+for (name, src), n in cnt.most_common(45):
+    print(f"{n:4d} {name:28s} {src}")

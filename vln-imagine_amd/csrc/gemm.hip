@@ -7,14 +7,22 @@
 // replacing the nn.Linear / torch.matmul calls of
 //   VLN-HAMT/finetune_src/models/vilmodel_cmt.py:101-103,145,174,187,327-329 and their autograd.
 //
-// Geometry (64-wide waves): 128x128 output tile, 256 threads = 4 waves in 2x2, each wave a 64x64
-// sub-tile = 2x2 MFMA 32x32 accumulators (64 acc VGPRs). A k-tile is 128 BYTES of K per row for
-// both dtypes (bf16: BK=64 -> v_mfma_f32_32x32x16_bf16; f32: BK=32 -> v_mfma_f32_32x32x2_f32, the
-// exact-fp32 parity path). Global->register->LDS staging in 16-B chunks with an XOR swizzle
-// (chunk ^ ((row>>1)&7)) so the ds_read_b128 fragment reads of 16 different rows hit 16 different
-// 16-B slots of the 256-B bank row; two LDS stages, next tile's global loads issued before the MFMAs
-// of the current one (issue-early / write-late), one barrier per k-tile. Tiles are dealt to XCDs in
-// contiguous chunks (bijective remap) so the N-tiles sharing an A row-panel hit one L2.
+// Base geometry (64-wide waves): 128x128 output tile, 4 waves in 2x2, each wave a 64x64 sub-tile = 2x2 MFMA 32x32
+// accumulators (64 acc VGPRs). A k-tile is 128 BYTES of K per row for both dtypes (bf16: BK=64 ->
+// v_mfma_f32_32x32x16_bf16; f32: BK=32 -> v_mfma_f32_32x32x2_f32, the exact-fp32 parity path), staged in 16-B chunks with an
+// XOR swizzle (chunk ^ ((row>>1)&7)) so the ds_read_b128 fragment reads of 16 different rows hit 16 different 16-B slots of
+// the 256-B bank row. Tiles are dealt to XCDs in contiguous chunks of a grouped order (bijective remap, tile_origin) so the
+// tiles an XCD runs together share operand panels in its L2.
+//
+// Kernels in this file (variant numbers of vlni_gemm_nt_v; all bit-identical):
+//   gemm_nt_kernel        (1)      register-staged, one 32-KiB LDS stage, 4 blocks per CU
+//   gemm_nt_glds_kernel   (2-5)    LDS-DMA (global_load_lds_dwordx4) into 2 or 3 stages, counted vmcnt + raw s_barrier, 4 or 8 waves
+//   gemm_nt_big_kernel    (6-13)   the same pipeline for any WM x WN wave grid and MI x NJ accumulators per wave:
+//                                  256x128 / 256x256 / 128x256 (one block per CU), 64x128 / 128x64 / 64x64 (under-filled launches),
+//                                  192x128 / 128x192 (two 40-KiB stages: two blocks per CU with 17 % fewer operand bytes per flop)
+//   gemm_nn_glds_kernel   (+16)    B given as [K,N]: transposing LDS reads on the weight itself (bf16 dgrad without a W^T copy)
+//   gemm_tn_*_kernel               weight gradients dY^T X straight from row-major dY and X (ds_read_b64_tr_b16), grouped segments
+// What bounds them on the K = 768 shapes of this workload is the CU's vector-memory pipe (~66 GB/s per CU), see DESIGN.md section 6.
 #include <stdlib.h>
 
 #include "common.h"
