@@ -445,6 +445,8 @@ class ShadowCache:
                         self._tr[key], self._tr_table = (mir[1], t), None
                 else:
                     t = cast(src, dtype)
+        if not any(p.requires_grad for p in params):
+            live = True                # frozen parameters: no optimizer step ever touches them
         self._c[key] = (ver, t, live, self.opt_epoch, weakref.ref(params[0]))
         return t
 
