@@ -19,14 +19,15 @@ def step():
     tr.step()
 for _ in range(3): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU], with_stack=True, experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
     step()
 torch.cuda.synchronize()
 cnt = collections.Counter()
 for ev in prof.events():
     if ev.name.startswith("aten::") and ev.name not in ("aten::empty", "aten::view", "aten::as_strided", "aten::reshape", "aten::empty_like", "aten::empty_strided",
                                                           "aten::slice", "aten::select", "aten::expand", "aten::detach", "aten::_unsafe_view", "aten::unsqueeze", "aten::squeeze", "aten::transpose", "aten::t", "aten::alias", "aten::result_type", "aten::to", "aten::contiguous", "aten::is_nonzero", "aten::item", "aten::_local_scalar_dense", "aten::lift_fresh", "aten::permute", "aten::unbind", "aten::narrow", "aten::split", "aten::chunk", "aten::flatten", "aten::view_as", "aten::size", "aten::stride", "aten::numel", "aten::dim", "aten::resize_", "aten::set_", "aten::record_stream", "aten::clone", "aten::ones_like", "aten::zeros_like", "aten::new_zeros", "aten::new_empty", "aten::expand_as", "aten::unflatten", "aten::unsafe_split", "aten::_reshape_alias"):
-        src = next((s for s in (ev.stack or []) if "vln-imagine_amd" in s or "vln_imagine_amd" in s), "backward/engine")
-        cnt[(ev.name, src.split("/")[-1][:70])] += 1
-for (name, src), n in cnt.most_common(45):
+        st = [s for s in (ev.stack or []) if ("imagine_amd" in s or "bench.py" in s) and "aten_ops" not in s]
+        src = st[0] if st else ("backward/engine" if not ev.stack else ev.stack[0])
+        cnt[(ev.name, src.split("/")[-1][:90])] += 1
+for (name, src), n in cnt.most_common(70):
     print(f"{n:4d} {name:28s} {src}")

@@ -315,8 +315,27 @@ def cast(x, dtype):
 
 
 def additive_mask(m):
-    """bool/0-1 mask [B,S] -> float32 additive (1-m)*-10000 (vilmodel_cmt.py:1010-1012)."""
+    """bool/0-1 mask [B,S] -> float32 additive (1-m)*-10000 (vilmodel_cmt.py:1010-1012). One kernel for bool masks."""
+    if m.dtype == torch.bool:
+        return torch.where(m, _ZERO_NEG[0], _ZERO_NEG[1])
     return (1.0 - m.to(torch.float32)) * NEG_MASK
+
+
+class _Consts:
+    """float32 scalar tensors per device for torch.where (python scalars would make it a float64 -> float32 round trip)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def __getitem__(self, i):
+        dev = torch.cuda.current_device()
+        c = self._c.get(dev)
+        if c is None:
+            c = self._c[dev] = (torch.zeros((), dtype=torch.float32, device="cuda"), torch.full((), NEG_MASK, dtype=torch.float32, device="cuda"))
+        return c[i]
+
+
+_ZERO_NEG = _Consts()
 
 
 # =====================================================================================
@@ -1195,7 +1214,7 @@ class _SmallKLinear(torch.autograd.Function):
         _lib.call("vlni_smallk_linear_fwd", _DT[out_dtype], x2.data_ptr(), x2.stride(0), w.data_ptr(), _p(b), y.data_ptr(),
                   y.stride(0), x2.shape[0], N, K, _st())
         ctx.save_for_backward(x2, w)
-        ctx.has_b = b is not None
+        ctx.has_b, ctx.b = b is not None, b
         return y.view(shp[:-1] + (N,))
 
     @staticmethod
@@ -1203,6 +1222,11 @@ class _SmallKLinear(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         N, K = w.shape
         dy2 = _rows(dy)
+        b = ctx.b
+        if _direct(w) and (b is None or _direct(b)):         # accumulate straight into the gradient arena
+            _lib.call("vlni_smallk_linear_bwd", _dt(dy2), dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0),
+                      w.grad.data_ptr(), _p(b.grad if b is not None else None), x2.shape[0], N, K, _st())
+            return None, None, None, None
         dw = torch.zeros_like(w)
         db = torch.zeros((N,), dtype=torch.float32, device=w.device) if ctx.has_b else None
         _lib.call("vlni_smallk_linear_bwd", _dt(dy2), dy2.data_ptr(), dy2.stride(0), x2.data_ptr(), x2.stride(0),
