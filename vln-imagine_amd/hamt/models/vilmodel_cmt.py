@@ -235,7 +235,7 @@ class HistoryEmbeddings(_FeatEmbed):
         B = img.shape[0]
         ti, ta = self._feat(img, ang, "", dt)
         if pos_ids.numel() == 1:                          # one step for the whole batch (the agent's per-step call)
-            row = self.position_embeddings.weight[pos_ids].reshape(1, -1) + self.type_embedding.weight
+            row = self.position_embeddings.weight.index_select(0, pos_ids.reshape(-1)) + self.type_embedding.weight
             srcs = [(ti, "dense", None), (ta, "dense", None), (row, "bcast", None)]
         else:                                             # per-row step ids (time-batched teacher forcing)
             srcs = [(ti, "dense", None), (ta, "dense", None), (self.type_embedding.weight, "bcast", None),

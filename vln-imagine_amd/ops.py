@@ -1327,7 +1327,7 @@ class _RowDot(torch.autograd.Function):
         _lib.call("vlni_rowdot_fwd", _dt(h2), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(bias), _p(m8), out.data_ptr(),
                   rows, H, _st())
         ctx.save_for_backward(h2, w, m8)
-        ctx.shp, ctx.has_b = shp, bias is not None
+        ctx.shp, ctx.has_b, ctx.bias = shp, bias is not None, bias
         return out.view(shp[:-1])
 
     @staticmethod
@@ -1336,6 +1336,11 @@ class _RowDot(torch.autograd.Function):
         rows, H = h2.shape
         dl = dl.reshape(-1).float().contiguous()
         dh = torch.empty_like(h2)
+        bias = ctx.bias
+        if _direct(w) and (bias is None or _direct(bias)):        # the kernel adds (atomics) straight into the gradient arena
+            _lib.call("vlni_rowdot_bwd", _dt(h2), dl.data_ptr(), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(m8),
+                      dh.data_ptr(), dh.stride(0), w.grad.data_ptr(), _p(bias.grad if bias is not None else None), rows, H, _st())
+            return dh.view(ctx.shp), None, None, None
         dw = torch.zeros((H,), dtype=torch.float32, device=h2.device)
         dbias = torch.zeros((1,), dtype=torch.float32, device=h2.device) if ctx.has_b else None
         _lib.call("vlni_rowdot_bwd", _dt(h2), dl.data_ptr(), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(m8),
