@@ -1178,7 +1178,7 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
     const bool deep = variant == 3 || variant == 4, wide = variant >= 4;
     static bool attr = false;
     if (!attr) {
-#define VLNI_ATTR(TT, NS, W) hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<TT, NS, W>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * ST)
+#define VLNI_ATTR(TT, NS, W) (void)hipFuncSetAttribute((const void*)gemm_nt_glds_kernel<TT, NS, W>, hipFuncAttributeMaxDynamicSharedMemorySize, NS * ST)
       VLNI_ATTR(float, 3, 4); VLNI_ATTR(__bf16, 3, 4); VLNI_ATTR(float, 2, 4); VLNI_ATTR(__bf16, 2, 4);
       VLNI_ATTR(float, 3, 8); VLNI_ATTR(__bf16, 3, 8); VLNI_ATTR(float, 2, 8); VLNI_ATTR(__bf16, 2, 8);
 #undef VLNI_ATTR
@@ -1314,10 +1314,10 @@ extern "C" int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const
     constexpr int ST = 2 * 64 * 256;
     static bool attr = false;
     if (!attr) {
-      hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
-      hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
-      hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
-      hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
+      (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
+      (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
+      (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * ST);
+      (void)hipFuncSetAttribute((const void*)gemm_tn_glds_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST);
       attr = true;
     }
     if (variant == 2) hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 4>), grid, dim3(256), 2 * ST, st, p);
