@@ -569,11 +569,11 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev):
     if best is not None or torch.cuda.is_current_stream_capturing():
         return best or default
     t128 = ((N + 127) // 128) * ((K + 127) // 128)
-    cands = {(TN_VARIANT, max(1, min(s, nmt // 3))) for s in (4, 8, 12, max(1, round(512 / t128)))}
+    cands = {(TN_VARIANT, max(1, min(s, nmt // 3))) for s in (2, 3, 4, 6, 8, 12, max(1, round(512 / t128)))}
     if TN_BIG and N >= 256 and K >= 256 and nmt >= 32:
         t256 = ((N + 255) // 256) * ((K + 255) // 256)
         s6 = max(1, min(nmt // 4, round(252 / t256)))
-        cands |= {(6, s6), (6, max(1, s6 // 2))}
+        cands |= {(6, s6), (6, max(1, s6 // 2)), (6, max(1, (3 * s6) // 4))}
     scratch = torch.zeros((N, K), dtype=torch.float32, device=dev)
     cs = torch.zeros((N,), dtype=torch.float32, device=dev)
     timed = []
