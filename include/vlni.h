@@ -149,6 +149,34 @@ int vlni_act_bwd(int dtype, int act, const void* da, const void* z, void* dz, lo
 int vlni_build_views(int table_dtype, const void* table, const long* vp_row, const int* view, const float* cand_he,
                      const unsigned char* is_cand, const int* base_view, const float* angle_table, float* out_img, float* out_ang,
                      int B, int V, int D, int A, void* stream);
+/* DUET's topological map resident on the device, batched over the B episodes of a rank; replaces the per-episode python
+   dict graph of VLN-DUET/map_nav_src/models/graph_utils.py:43-161 and the python double loops of r2r/agent.py:98-207.
+   Per episode: pos [G][3] float64, dis [G][G] float64 (95959595 = nothing known), via [G][G] int32 (intermediate node of a relaxed
+   pair, -1 = direct edge / nothing), seen [G] (FloydGraph.visited). G <= 256 node slots; the host assigns slots to viewpoint names.
+   vlni_graph_init      fills dis / via / seen.
+   vlni_graph_observe   GraphMap.update_graph (graph_utils.py:107-113): cur[B] = slot of the current viewpoint (-1: episode ended, no
+                        change), cand[B][C] candidate slots (-1 pad) with positions; edge kept if shorter, then every pair is relaxed
+                        through cur; n_nodes[B] = slots in use after this observation. cand_dist[B][C] (optional) = edge lengths
+                        computed by the caller: the reference squares with python `**`, i.e. libm pow, which is one ulp off
+                        x*x for ~0.1 % of the inputs; NULL = exact float64 sqrt(dx*dx + dy*dy + dz*dz) on the device.
+   vlni_graph_pos_fts   GraphMap.get_pos_fts (graph_utils.py:130-153) for nodes[B][N] (-1 = the [stop] token -> 0 1 0 1 0 0 0,
+                        -2 = padding row -> zeros): A angle features of (heading, elevation) relative to heading[b] / elevation[b]
+                        (angles cast to float32 first, as the reference does) + line distance / 30, shortest distance / 30, hops / 10;
+                        hops = len(FloydGraph.path), expanded lazily from `via`.  Row r of episode b goes to out + b*ld_batch + r*ld_row
+                        (so the 14-wide vp_pos_fts of r2r/agent.py:178-195 is two calls).  status[0] becomes 1 + b if a hop-count walk of
+                        episode b did not terminate (inconsistent map); the caller zeroes it.
+   vlni_graph_pair_dists  gmap_pair_dists of r2r/agent.py:135-139,157-160: out[B][N][N] float32, 0 on the diagonal, for [stop] and padding.
+   vlni_gather_rows_or_zero  out[i] = rows[i] >= 0 ? table[rows[i]][0:D] : 0 (float32 out, float32 / bfloat16 table): the slot fill of
+                        _create_diffusion_imaginations_v2 (VLN-HAMT/finetune_src/r2r/agent_cmt.py:286-309) from a resident table. */
+int vlni_graph_init(double* dis, int* via, unsigned char* seen, int B, int G, void* stream);
+int vlni_graph_observe(double* pos, double* dis, int* via, unsigned char* seen, const int* cur, const int* cand,
+                       const double* cur_pos, const double* cand_pos, const double* cand_dist, const int* n_nodes, int B, int G, int C,
+                       void* stream);
+int vlni_graph_pos_fts(const double* pos, const double* dis, const int* via, const int* cur, const int* nodes, const double* heading,
+                       const double* elevation, float* out, long ld_row, long ld_batch, int* status, int B, int G, int N, int A,
+                       void* stream);
+int vlni_graph_pair_dists(const double* dis, const int* nodes, float* out, int B, int G, int N, void* stream);
+int vlni_gather_rows_or_zero(int dtype, const void* table, long ld, const long* rows, float* out, int n, int D, void* stream);
 /* DUET global/local logit fusion, replaces the per-sample python loop of VLN-DUET/map_nav_src/models/vilmodel.py:1198-1217:
    src[B,G]: local candidate index that IS map node g (>= 0), -2 = unvisited node without a candidate (takes the summed local
    logits of the visited candidates), -1 = nothing to add; bw[B,V]: candidate j is an already-visited viewpoint.

@@ -49,3 +49,21 @@ def duet_variant_setup(name):
     kw = dict(DUET_EP)
     kw.update(epkw)
     return cfg, synth.DuetEpisode(**kw)
+
+# seeded exploration behind tests/golden/graph_walk.npz (make_golden_graph.py)
+WALK = dict(tag="walk0", B=4, T=7, n=48, k=4)
+
+# end-to-end DUET rollout with real topological maps (make_golden_rollout.py): walk + text / imagination inputs
+ROLLOUT = dict(walk=dict(tag="roll0", B=4, T=5, n=40, k=4, revisit=False), stop_early={1: 3}, text=dict(tag="roll0", B=4, L=80, V=36, I=4, T=1))
+
+
+def rollout_setup():
+    """(walk, view features [n, 36, 768], keys, text episode) - closed form, identical wherever it is built."""
+    from vln_imagine_amd import synth
+    w = synth.GraphWalk(**ROLLOUT["walk"])
+    for b, n in ROLLOUT["stop_early"].items():
+        w.length[b] = min(w.length[b], n)
+    n = ROLLOUT["walk"]["n"]
+    feats = synth.det_uniform("roll0/views", (n, 36, 768), -0.5, 0.5)
+    keys = [f"scan_vp{v:03d}" for v in range(n)]
+    return w, feats, keys, synth.DuetEpisode(**ROLLOUT["text"])

@@ -28,7 +28,9 @@ def _fake_env(n_vp=5, B=4, seed=0):
         base = int(rng.randint(36))
         cands = []
         for j in range(int(rng.randint(1, 6))):
-            pid = int(rng.randint(36))                          # two candidates may share a view
+            pid = int(rng.randint(36))
+            if j == 1 and b % 2 == 0:
+                pid = cands[0]["pointId"]                       # two candidates may share a view (then a panorama has > 36 tokens)
             h, e = float(rng.uniform(-math.pi, math.pi)), float(rng.uniform(-0.5, 0.5))
             cands.append({"pointId": pid, "heading": h, "elevation": e, "viewpointId": f"vp{b}_{j}",
                           "feature": np.concatenate([feats[vp, pid], _angle_feature(h, e)])})

@@ -51,6 +51,11 @@ SIGNATURES = {
     "vlni_transpose_batched": [I, P, I, I, P],
     "vlni_set_dropout_seed_base": [P],
     "vlni_build_views": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "vlni_graph_init": [P, P, P, I, I, P],
+    "vlni_graph_observe": [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "vlni_graph_pos_fts": [P, P, P, P, P, P, P, P, L, L, P, I, I, I, I, P],
+    "vlni_graph_pair_dists": [P, P, P, I, I, I, P],
+    "vlni_gather_rows_or_zero": [I, P, L, P, P, I, I, P],
     "vlni_duet_fuse_fwd": [P, P, P, P, P, I, I, I, P],
     "vlni_duet_fuse_bwd": [P, P, P, P, I, I, I, P],
     "vlni_optim_prepare": [P, F, F, F, P, P],

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvlni.so")
-SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "attention.hip"]
+SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "attention.hip", "graphmap.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -92,10 +92,11 @@ class ViewBuilder:
         """DUET `_panorama_feature_variable` (map_nav_src/r2r/agent.py:67-97): candidate views first (nav type 1), then the
         views no candidate uses (nav type 0); loc_fts = [angle(4), box (1, 1, 1)]. Returns the `panorama` batch entries."""
         B = len(obs)
-        view = np.full((B, views), -1, np.int32)
-        he = np.zeros((B, views, 2), np.float32)
-        is_cand = np.zeros((B, views), np.uint8)
-        nav = np.zeros((B, views), np.int64)
+        W = max(len(ob["candidate"]) + views - len({c["pointId"] for c in ob["candidate"]}) for ob in obs)   # candidates may share a view
+        view = np.full((B, W), -1, np.int32)
+        he = np.zeros((B, W, 2), np.float32)
+        is_cand = np.zeros((B, W), np.uint8)
+        nav = np.zeros((B, W), np.int64)
         lens, cand_vpids = [], []
         for i, ob in enumerate(obs):
             used, n = set(), 0
@@ -113,3 +114,39 @@ class ViewBuilder:
         loc = torch.cat([ang, valid.unsqueeze(2).expand(-1, -1, 3).to(ang.dtype)], 2)            # box features are all ones
         return {"view_img_fts": img, "loc_fts": loc, "nav_types": torch.from_numpy(nav[:, :V]).to(img.device),
                 "view_lens": torch.tensor(lens, device=img.device), "cand_vpids": cand_vpids}
+
+
+class ImaginationTable:
+    """Every instruction's imagination features resident on the device + the per-sub-instruction 'True' / 'False' generated flags;
+    `batch(instr_ids)` is `_create_diffusion_imaginations_v2` (VLN-HAMT/finetune_src/r2r/agent_cmt.py:247-313, same function in
+    VLN-DUET/map_nav_src/r2r/agent.py): slot s of sample b holds the instruction's next stored imagination iff its flag is 'True',
+    zeros otherwise; an instruction without any generated imagination counts as length 0. The reference reads each instruction's
+    [n_true, >= D] array from an HDF5 file keyed 'pathid_instridx' (r2r/data_utils.py:33-47) and pads on the host every batch."""
+
+    def __init__(self, features, generated_flags, feat_size=768, device="cuda", dtype=torch.float32):
+        self.flags, self.D = generated_flags, feat_size
+        self.first, rows, n = {}, [], 0
+        for iid, fl in generated_flags.items():
+            k = sum(f == "True" for f in fl)
+            if k:
+                a = np.asarray(features[iid])[:, :feat_size].astype(np.float32)
+                assert a.shape == (k, feat_size), f"{iid}: {a.shape} stored imaginations for {k} 'True' flags"   # agent_cmt.py:303
+                rows.append(a)
+            self.first[iid] = n
+            n += k
+        self.table = torch.from_numpy(np.concatenate(rows, 0) if rows else np.zeros((1, feat_size), np.float32)).to(device=device, dtype=dtype)
+
+    def batch(self, instr_ids):
+        flags = [self.flags[i] for i in instr_ids]
+        lens = [0 if all(f == "False" for f in fl) else len(fl) for fl in flags]
+        B, I = len(instr_ids), max(lens)
+        rows = np.full((B, I), -1, np.int64)
+        for b, (iid, fl) in enumerate(zip(instr_ids, flags)):
+            on = np.flatnonzero([f == "True" for f in fl])
+            rows[b, on] = self.first[iid] + np.arange(len(on))
+        dev = self.table.device
+        out = torch.empty((B, I, self.D), dtype=torch.float32, device=dev)
+        rows_t = torch.from_numpy(rows).to(dev)
+        _lib.call("vlni_gather_rows_or_zero", ops._dt(self.table), self.table.data_ptr(), self.D, rows_t.data_ptr(), out.data_ptr(), B * I,
+                  self.D, ops._st())
+        return out, rows_t >= 0

@@ -296,3 +296,67 @@ class DuetEpisode:
                 gmap_pair_dists=pd.astype(np.float32), gmap_visited_masks=vis_m, node_src=node_src,
                 vp_pos_fts=det_uniform(kk("vppos"), (B, V + 1, 14), -0.6, 0.6).astype(np.float32),
                 vp_cand_vpids=[[None] + c for c in cand_vpids], target=target))
+
+
+class GraphWalk:
+    """Seeded exploration of a synthetic building: what DUET's environment hands the agent per step, reduced to what the
+    topological map and the navigation builders read (VLN-DUET/map_nav_src/r2r/env.py:213-262 observation fields `viewpoint`,
+    `position`, `heading`, `elevation`, `candidate[].{viewpointId, position, pointId, heading, elevation}`).
+
+    World: `n` viewpoints on a jittered grid over two floors, each linked to its `k` nearest neighbours (symmetrised).
+    Walk: B agents, T steps; each step moves to a neighbour (unvisited first, so maps grow; sometimes back, so nodes are re-observed
+    and shorter edges / new relaxations occur). Positions are python floats like the simulator's."""
+
+    def __init__(self, tag="walk0", B=4, T=6, n=48, k=4, revisit=True):
+        """revisit=False: ground-truth-like paths that never return to a seen viewpoint; an agent with no fresh neighbour stops
+        there (`length[b]` = observations before its [stop])."""
+        self.B, self.T = B, T
+        self.length = [T] * B
+        side = int(math.ceil(math.sqrt(n / 2)))
+        xy = det_uniform(f"{tag}/jit", (n, 2), -0.8, 0.8).astype(np.float64)
+        self.pos = []
+        for v in range(n):
+            f, r = divmod(v, side * side)
+            self.pos.append((float(2.5 * (r % side) + xy[v, 0]), float(2.5 * (r // side) + xy[v, 1]), float(3.0 * f + 0.1 * xy[v, 0])))
+        P = np.array(self.pos)
+        d = np.sqrt(((P[:, None] - P[None]) ** 2).sum(-1))
+        np.fill_diagonal(d, np.inf)
+        self.adj = [set(np.argsort(d[v])[:k].tolist()) for v in range(n)]
+        for v in range(n):
+            for u in list(self.adj[v]):
+                self.adj[u].add(v)
+        self.adj = [sorted(a) for a in self.adj]
+        self.name = lambda v: f"vp{v:03d}"
+        self.steps = []                                      # steps[t][b] = observation dict
+        cur = det_randint(f"{tag}/start", (B,), 0, n).tolist()
+        been = [{c} for c in cur]
+        for t in range(T):
+            obs = []
+            for b in range(B):
+                v = cur[b]
+                heading = float(det_uniform(f"{tag}/h{t}_{b}", (1,), 0.0, 2 * math.pi)[0])
+                elevation = float(det_uniform(f"{tag}/e{t}_{b}", (1,), -0.5, 0.5)[0])
+                cands = []
+                for j, u in enumerate(self.adj[v]):
+                    dx, dy, dz = (self.pos[u][a] - self.pos[v][a] for a in range(3))
+                    rel_h = math.atan2(dx, dy) - heading
+                    rel_e = math.atan2(dz, math.hypot(dx, dy)) - elevation
+                    cands.append({"viewpointId": self.name(u), "position": self.pos[u], "heading": rel_h, "elevation": rel_e,
+                                  "pointId": int((round(math.degrees(rel_h) / 30) % 12) + 12 * (1 + (rel_e > 0.26) - (rel_e < -0.26)))})
+                obs.append({"instr_id": f"{tag}_{b}", "viewpoint": self.name(v), "position": self.pos[v], "heading": heading,
+                            "elevation": elevation, "candidate": cands, "viewIndex": int(det_randint(f"{tag}/vi{t}_{b}", (1,), 0, 36)[0]),
+                            "key": f"scan_{self.name(v)}"})
+            self.steps.append(obs)
+            for b in range(B):
+                fresh = [u for u in self.adj[cur[b]] if u not in been[b]]
+                r = int(det_randint(f"{tag}/mv{t}_{b}", (1,), 0, 1 << 20)[0])
+                if not revisit:
+                    if not fresh or self.length[b] <= t:
+                        self.length[b] = min(self.length[b], t + 1)      # stays where it is from now on
+                        continue
+                    cur[b] = fresh[r % len(fresh)]
+                    been[b].add(cur[b])
+                    continue
+                pool = fresh if fresh and r % 4 != 0 else self.adj[cur[b]]
+                cur[b] = pool[r % len(pool)]
+                been[b].add(cur[b])
