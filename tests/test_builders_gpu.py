@@ -91,3 +91,32 @@ def test_duet_panorama_builder_matches_reference_loop():
     assert np.abs(out["loc_fts"].cpu().numpy() - np.stack([pad(a) for a in loc_l])).max() < 2e-6
     assert np.array_equal(out["nav_types"].cpu().numpy(), np.stack([np.array(t + [0] * (V - len(t))) for t in nav_l]))
     assert out["cand_vpids"] == [[c["viewpointId"] for c in ob["candidate"]] for ob in obs]
+
+
+def test_hamt_candidate_and_history_builders_match_reference_loops():
+    from vln_imagine_amd.builders import ResidentFeatures, ViewBuilder
+    feats, keys, obs = _fake_env(seed=7, B=6)
+    B = len(obs)
+    vb = ViewBuilder(ResidentFeatures(feats, keys), A)
+    # _candidate_variable, agent_cmt.py:178-196 restated
+    lens = [len(ob["candidate"]) + 1 for ob in obs]
+    ci, ca, cn = np.zeros((B, max(lens), D), np.float32), np.zeros((B, max(lens), A), np.float32), np.zeros((B, max(lens)), np.int64)
+    for i, ob in enumerate(obs):
+        for j, cc in enumerate(ob["candidate"]):
+            ci[i, j], ca[i, j], cn[i, j] = cc["feature"][:D], cc["feature"][D:], 1
+        cn[i, lens[i] - 1] = 2
+    img, ang, nav, got_lens = vb.hamt_candidates(obs)
+    assert got_lens == lens and np.array_equal(img.cpu().numpy(), ci) and np.array_equal(nav.cpu().numpy(), cn)
+    assert np.abs(ang.cpu().numpy() - ca).max() < 2e-6
+    # _history_variable + prev_act_angle, agent_cmt.py:198-215,589-594 restated
+    next_ids = [(-1 if i % 3 == 0 else len(ob["candidate"]) - 1) for i, ob in enumerate(obs)]
+    hi = np.stack([ob["feature"][ob["viewIndex"], :D] for ob in obs])
+    hp, ha = np.stack([ob["feature"][:, :D] for ob in obs]), np.stack([ob["feature"][:, D:] for ob in obs])
+    pa = np.zeros((B, A), np.float32)
+    for i, nid in enumerate(next_ids):
+        if nid != -1:
+            pa[i] = obs[i]["candidate"][nid]["feature"][-A:]
+    g_hi, g_hp, g_ha, g_pa = vb.hamt_history(obs, next_ids)
+    assert np.array_equal(g_hi.cpu().numpy(), hi) and np.array_equal(g_hp.cpu().numpy(), hp)
+    assert np.abs(g_ha.cpu().numpy() - ha).max() < 2e-6 and np.abs(g_pa.cpu().numpy() - pa).max() < 2e-6
+    assert not g_pa[0].any()

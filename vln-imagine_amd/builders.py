@@ -88,6 +88,41 @@ class ViewBuilder:
         img, ang = self._launch(self.f.rows([ob["key"] for ob in obs]), view, he, is_cand, [ob["viewIndex"] for ob in obs])
         return img, ang, torch.from_numpy(nav).to(img.device), lens, [len(ob["candidate"]) + 1 for ob in obs]
 
+    def hamt_candidates(self, obs):
+        """HAMT `_candidate_variable` (agent_cmt.py:178-196, `ob_type == 'cand'`): the candidates, then [END] (zeros, nav type 2)."""
+        B = len(obs)
+        lens = [len(ob["candidate"]) + 1 for ob in obs]
+        V = max(lens)
+        view = np.full((B, V), -1, np.int32)
+        he = np.zeros((B, V, 2), np.float32)
+        is_cand = np.zeros((B, V), np.uint8)
+        nav = np.zeros((B, V), np.int64)
+        for i, ob in enumerate(obs):
+            for j, c in enumerate(ob["candidate"]):
+                view[i, j], he[i, j], is_cand[i, j], nav[i, j] = c["pointId"], (c["heading"], c["elevation"]), 1, 1
+            nav[i, lens[i] - 1] = 2
+        img, ang = self._launch(self.f.rows([ob["key"] for ob in obs]), view, he, is_cand, [ob["viewIndex"] for ob in obs])
+        return img, ang, torch.from_numpy(nav).to(img.device), lens
+
+    def hamt_history(self, obs, next_ids=None, views=36):
+        """HAMT `_history_variable` + the previous-action angle (agent_cmt.py:198-215,589-594), one launch: the view the agent looks
+        through, the whole panorama with its angle table, and the angle feature of the candidate it moves to (`next_ids[b]`, -1 or
+        None = no move -> zeros). Returns (hist_img_feats [B, D], hist_pano_img_feats [B, 36, D], hist_pano_ang_feats [B, 36, A],
+        prev_act_angle [B, A])."""
+        B, V = len(obs), views + 2
+        view = np.full((B, V), -1, np.int32)
+        he = np.zeros((B, V, 2), np.float32)
+        is_cand = np.zeros((B, V), np.uint8)
+        view[:, :views] = np.arange(views)[None, :]
+        for i, ob in enumerate(obs):
+            view[i, views] = ob["viewIndex"]
+            nid = -1 if next_ids is None else int(next_ids[i])
+            if nid >= 0:
+                c = ob["candidate"][nid]
+                view[i, views + 1], he[i, views + 1], is_cand[i, views + 1] = c["pointId"], (c["heading"], c["elevation"]), 1
+        img, ang = self._launch(self.f.rows([ob["key"] for ob in obs]), view, he, is_cand, [ob["viewIndex"] for ob in obs])
+        return img[:, views], img[:, :views], ang[:, :views], ang[:, views + 1]
+
     def duet_panorama(self, obs, views=36):
         """DUET `_panorama_feature_variable` (map_nav_src/r2r/agent.py:67-97): candidate views first (nav type 1), then the
         views no candidate uses (nav type 0); loc_fts = [angle(4), box (1, 1, 1)]. Returns the `panorama` batch entries."""
