@@ -374,8 +374,9 @@ def test_wgrad_tn_bf16_exact_and_random(ops, M, N, K):
     assert _err(cs2, dy.double().sum(0)) < 2e-3 * max(1.0, dy.double().sum(0).abs().max().item())
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
-def test_wgrad_tn_lds_dma_variants_exact(ops, variant):
+@pytest.mark.parametrize("split", [1, 3, 5])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
+def test_wgrad_tn_lds_dma_variants_exact(ops, variant, split):
     """LDS-DMA pipelines of the grouped transposing-read wgrad (zero page for row tails, MFMA-ones bias gradient): exact on
     small integers over several ragged segments."""
     import ctypes
@@ -389,7 +390,7 @@ def test_wgrad_tn_lds_dma_variants_exact(ops, variant):
     n = len(Ms)
     pa = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dd]); pb = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xx])
     pm = (ctypes.c_int * n)(*Ms)
-    _lib.call("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, out.data_ptr(), K, N, K, cs.data_ptr(), 3, variant,
+    _lib.call("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, out.data_ptr(), K, N, K, cs.data_ptr(), split, variant,
               torch.cuda.current_stream().cuda_stream)
     assert torch.equal(out.cpu(), sum(d.t() @ x for d, x in zip(dys, xs)))
     assert torch.equal(cs.cpu(), sum(d.sum(0) for d in dys))

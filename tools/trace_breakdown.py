@@ -15,5 +15,5 @@ for s, e, k in seg:
     agg[key][1] += e - s
 tot = sum(v[1] for v in agg.values())
 print(f"{nsteps} steps: kernel time {tot/1e6/nsteps:.2f} ms/step, span {(seg[-1][1]-seg[0][0])/1e6/nsteps:.2f} ms/step")
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:26]:
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"  {k:50s} {v[0]/nsteps:7.1f} calls {v[1]/1e6/nsteps:7.3f} ms  avg {v[1]/v[0]/1e3:7.1f} us")

@@ -11,7 +11,7 @@ import torch  # noqa: F401  MUST precede the dlopen below: libvlni.so needs liba
 #                            own the device: the second reports "no ROCm-capable device").
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlni.so")
+LIB_PATH = os.environ.get("VLNI_LIB_PATH") or os.path.join(_HERE, "libvlni.so")   # override: A/B runs against another build
 
 P, L, I, F, U = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ctypes.c_uint
 

@@ -25,6 +25,8 @@
 // What bounds them on the K = 768 shapes of this workload is the CU's vector-memory pipe (~66 GB/s per CU), see DESIGN.md section 6.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -602,6 +604,19 @@ struct TnP {
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int tr_off(int row, int ch) { return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+// LDS-DMA issued as inline asm in the kernels that read their tiles with the transposing LDS read: hipcc's waitcnt pass treats the
+// ds_read_tr BUILTIN as a read that may alias an outstanding global_load_lds BUILTIN and puts s_waitcnt vmcnt(0) in front of the
+// first one - which serialises every stage's global -> LDS copy with the MFMAs it was meant to overlap (measured on the 256 x 256
+// weight-gradient tile: 4.3 k cycles per 64-row step instead of 3.3 k). As asm the copy is invisible to that pass (its completion is
+// awaited by the explicit s_waitcnt vmcnt(N) + s_barrier these kernels carry anyway) while the reads stay builtins, so the compiler
+// still counts lgkmcnt for them. lds_addr must be wave-uniform: lane l's 16 bytes land at lds_addr + 16 * l.
+__device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_u32(const char* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int row_lo, int ch, int half8) {
   using lds_ptr = __attribute__((address_space(3))) s16x4*;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(tile + tr_off(row_lo, ch) + half8));
@@ -762,24 +777,25 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_glds_kernel(TnP p) {
     acol[i] = (n0 + c * 8 < p.N) ? n0 + c * 8 : -1;
     bcol[i] = (k0 + c * 8 < p.K) ? k0 + c * 8 : -1;
   }
-  using gptr = const __attribute__((address_space(1))) void*;
-  using lptr = __attribute__((address_space(3))) void*;
   int seg = 0;
+  const char* zp = (const char*)g_zero_page;            // pinned in scalar registers: otherwise re-loaded (GOT) inside the loop
+  asm volatile("" : "+s"(zp));
+  const unsigned lds0 = lds_u32(dsmem);
   auto issue = [&](int t, int stage) {
     const int mt = mt0 + t;
     while (mt >= p.mt_start[seg + 1]) ++seg;                 // tiles are issued in increasing order
     const int segM = p.segM[seg], r0 = (mt - p.mt_start[seg]) * BR;
     const __bf16* A = p.A[seg];
     const __bf16* B = p.B[seg];
-    char* sa = dsmem + stage * STAGE + wave * 1024;
+    const unsigned sa = lds0 + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       const int row = r0 + srow[i];
       const bool rok = row < segM;
-      const void* pa = (rok && acol[i] >= 0) ? (const void*)(A + (long)row * p.lda + acol[i]) : (const void*)g_zero_page;
-      const void* pb = (rok && bcol[i] >= 0) ? (const void*)(B + (long)row * p.ldb + bcol[i]) : (const void*)g_zero_page;
-      __builtin_amdgcn_global_load_lds((gptr)pa, (lptr)(sa + i * NW * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(sa + BR * 256 + i * NW * 1024), 16, 0, 0);
+      const void* pa = (rok && acol[i] >= 0) ? (const void*)(A + (long)row * p.lda + acol[i]) : (const void*)zp;
+      const void* pb = (rok && bcol[i] >= 0) ? (const void*)(B + (long)row * p.ldb + bcol[i]) : (const void*)zp;
+      lds_dma16(pa, sa + i * NW * 1024);
+      lds_dma16(pb, sa + BR * 256 + i * NW * 1024);
     }
   };
   const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
@@ -801,6 +817,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_glds_kernel(TnP p) {
   bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+  auto frags = [&](const char* As, const char* Bs, int kk, bf16x8 (&a)[2], bf16x8 (&b)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a[i] = tr_frag(As, 16 * kk + frow, cha + 4 * i, half8);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) b[j] = tr_frag(Bs, 16 * kk + frow, chb + 4 * j, half8);
+  };
+  auto mma = [&](const bf16x8 (&a)[2], const bf16x8 (&b)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    if (do_cs) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, acs[i], 0, 0, 0);
+    }
+  };
 
   if (nk > 0) {
     issue(0, 0);
@@ -815,24 +847,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_glds_kernel(TnP p) {
       }
       __builtin_amdgcn_s_barrier();
       if (t + NST - 1 < nk) issue(t + NST - 1, stage == 0 ? NST - 1 : stage - 1);
+      // k-step kk + 1's fragments are requested before k-step kk's MFMAs issue (two fragment sets)
       const char* As = dsmem + stage * STAGE;
       const char* Bs = As + BR * 256;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 a[2], b[NJ];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) a[i] = tr_frag(As, 16 * kk + frow, cha + 4 * i, half8);
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) b[j] = tr_frag(Bs, 16 * kk + frow, chb + 4 * j, half8);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        if (do_cs) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, acs[i], 0, 0, 0);
-        }
-      }
+      bf16x8 a0[2], b0[NJ], a1[2], b1[NJ];
+      frags(As, Bs, 0, a0, b0);
+      frags(As, Bs, 1, a1, b1);
+      mma(a0, b0);
+      frags(As, Bs, 2, a0, b0);
+      mma(a1, b1);
+      frags(As, Bs, 3, a1, b1);
+      mma(a0, b0);
+      mma(a1, b1);
       stage = stage == NST - 1 ? 0 : stage + 1;
     }
   }
@@ -898,12 +924,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_nn_glds_kernel(GemmP p) {
   }
   using gptr = const __attribute__((address_space(1))) void*;
   using lptr = __attribute__((address_space(3))) void*;
+  const char* zp = (const char*)g_zero_page;            // pinned in scalar registers: otherwise re-loaded (GOT) inside the loop
+  asm volatile("" : "+s"(zp));
   auto issue = [&](int t, int stage) {
     char* sa = dsmem + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
       __builtin_amdgcn_global_load_lds((gptr)(ga[i] + (long)t * ROWB), (lptr)(sa + i * NW * 1024), 16, 0, 0);
-      const void* pb = bok[i] ? (const void*)(gb[i] + (long)t * BK * p.ldb * ES) : (const void*)g_zero_page;
+      const void* pb = bok[i] ? (const void*)(gb[i] + (long)t * BK * p.ldb * ES) : (const void*)zp;
       __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(sa + BM * ROWB + i * NW * 1024), 16, 0, 0);
     }
   };
@@ -956,6 +984,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_nn_glds_kernel(GemmP p) {
 // 256 x 256 output tile of the same weight-gradient contraction: 8 waves as 2 (N) x 4 (K), a wave owns 128 x 64 outputs
 // (8 accumulators), half the L2->LDS bytes and half the LDS-read bytes per MFMA of the 128 x 128 tile. A stage holds four
 // [64 rows][128 cols] sub-tiles (A left/right, B left/right) in the layout of the kernel above; 2 stages = 128 KiB.
+// The LDS-DMA is issued as asm (lds_dma16 above) so the next stage's copy stays in flight under the MFMAs; k-step kk + 1's
+// twelve fragment reads are requested before k-step kk's eight MFMAs. The bias gradient (column sums of A) costs ONE extra
+// MFMA per k-step and wave: the four waves that share an A half each take one of its four 32-row blocks.
 template <int NST>
 __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnP p) {
   constexpr int BR = 64, SUB = BR * 256, STAGE = 4 * SUB, NW = 8;
@@ -973,8 +1004,10 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnP p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3, r = lane & 31, h = lane >> 5;
 
-  // a sub-tile is 16 LDS-DMA instructions (4 rows x 256 B each); 8 waves x 2 instructions per sub-tile
-  int srow[2], acol[2][2], bcol[2][2];
+  // a sub-tile is 16 LDS-DMA instructions (4 rows x 256 B each); 8 waves x 2 instructions per sub-tile.
+  // per-lane element offsets inside a 64-row tile of A / B (-1: column past N / K -> the zero page)
+  int srow[2];
+  long aoff[2][2], boff[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = (i * NW + wave) * 4 + (lane >> 4);
@@ -982,30 +1015,40 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnP p) {
     srow[i] = row;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      acol[u][i] = (n0 + u * 128 + c * 8 < p.N) ? n0 + u * 128 + c * 8 : -1;
-      bcol[u][i] = (k0 + u * 128 + c * 8 < p.K) ? k0 + u * 128 + c * 8 : -1;
+      aoff[u][i] = (n0 + u * 128 + c * 8 < p.N) ? (long)row * p.lda + n0 + u * 128 + c * 8 : -1;
+      boff[u][i] = (k0 + u * 128 + c * 8 < p.K) ? (long)row * p.ldb + k0 + u * 128 + c * 8 : -1;
     }
   }
-  using gptr = const __attribute__((address_space(1))) void*;
-  using lptr = __attribute__((address_space(3))) void*;
+  // the segment a tile lies in changes a handful of times per block: its descriptors stay in scalar registers and are re-read
+  // from the kernel arguments only on a change (reading them every step put ~1 k cycles of scalar-load latency between the
+  // barrier and the first MFMA)
   int seg = 0;
+  while (mt0 >= p.mt_start[seg + 1] && seg + 1 < p.nseg) ++seg;
+  const __bf16* curA = p.A[seg];
+  const __bf16* curB = p.B[seg];
+  int curM = p.segM[seg], seg_lo = p.mt_start[seg], seg_hi = p.mt_start[seg + 1];
+  const char* zp = (const char*)g_zero_page;            // pinned in scalar registers: otherwise re-loaded (GOT) inside the loop
+  asm volatile("" : "+s"(zp));
+  const unsigned lds0 = lds_u32(dsmem);
   auto issue = [&](int t, int stage) {
     const int mt = mt0 + t;
-    while (mt >= p.mt_start[seg + 1]) ++seg;
-    const int segM = p.segM[seg], r0 = (mt - p.mt_start[seg]) * BR;
-    const __bf16* A = p.A[seg];
-    const __bf16* B = p.B[seg];
-    char* sa = dsmem + stage * STAGE + wave * 1024;
+    if (mt >= seg_hi) {                                      // tiles are issued in increasing order
+      do { ++seg; } while (mt >= p.mt_start[seg + 1]);
+      curA = p.A[seg]; curB = p.B[seg]; curM = p.segM[seg]; seg_lo = p.mt_start[seg]; seg_hi = p.mt_start[seg + 1];
+    }
+    const int r0 = (mt - seg_lo) * BR;
+    const __bf16* At = curA + (long)r0 * p.lda;
+    const __bf16* Bt = curB + (long)r0 * p.ldb;
+    const unsigned sa = lds0 + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int row = r0 + srow[i];
-      const bool rok = row < segM;
+      const bool rok = r0 + srow[i] < curM;
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const void* pa = (rok && acol[u][i] >= 0) ? (const void*)(A + (long)row * p.lda + acol[u][i]) : (const void*)g_zero_page;
-        const void* pb = (rok && bcol[u][i] >= 0) ? (const void*)(B + (long)row * p.ldb + bcol[u][i]) : (const void*)g_zero_page;
-        __builtin_amdgcn_global_load_lds((gptr)pa, (lptr)(sa + u * SUB + i * NW * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(sa + (2 + u) * SUB + i * NW * 1024), 16, 0, 0);
+        const void* pa = (rok && aoff[u][i] >= 0) ? (const void*)(At + aoff[u][i]) : (const void*)zp;
+        const void* pb = (rok && boff[u][i] >= 0) ? (const void*)(Bt + boff[u][i]) : (const void*)zp;
+        lds_dma16(pa, sa + u * SUB + i * NW * 1024);
+        lds_dma16(pb, sa + (2 + u) * SUB + i * NW * 1024);
       }
     }
   };
@@ -1013,21 +1056,37 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnP p) {
   const int frow = 8 * h + qq, half8 = 8 * (pp & 1);
   const int cha = (16 * cb) / 8 + (pp >> 1);                         // + 4 * i: 32-column block i of A sub-tile wr
   const int chb = ((wc & 1) * 64 + 16 * cb) / 8 + (pp >> 1);         // + 4 * j inside B sub-tile wc >> 1
-
-  f32x16 acc[4][2], acs[4];
+  f32x16 acc[4][2], acs;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int x = 0; x < 16; ++x) acs[x] = 0.f;
 #pragma unroll
-    for (int x = 0; x < 16; ++x) acs[i][x] = 0.f;
+  for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
-  }
-  const bool do_cs = p.colsum != nullptr && k0 == 0 && wc == 0;
+  const bool do_cs = p.colsum != nullptr && k0 == 0;                 // block-uniform; wave (wr, wc) sums A block wc of half wr
   bf16x8 ones;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+  // fragments of k-step kk of the stage at `st`: A blocks 0..3 of sub-tile wr, B blocks 0..1 of sub-tile 2 + (wc >> 1)
+  auto frags = [&](const char* st, int kk, bf16x8 (&a)[4], bf16x8 (&b)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = tr_frag(st + (2 + (wc >> 1)) * SUB, 16 * kk + frow, chb + 4 * j, half8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = tr_frag(st + wr * SUB, 16 * kk + frow, cha + 4 * i, half8);
+  };
+  auto mma = [&](const bf16x8 (&a)[4], const bf16x8 (&b)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    if (do_cs) {
+      const bf16x8 mine = wc == 0 ? a[0] : wc == 1 ? a[1] : wc == 2 ? a[2] : a[3];
+      acs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mine, ones, acs, 0, 0, 0);
+    }
+  };
 
   if (nk > 0) {
     issue(0, 0);
@@ -1036,24 +1095,16 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnP p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (t + 1 < nk) issue(t + 1, stage ^ 1);
-      const char* As = dsmem + stage * STAGE + wr * SUB;
-      const char* Bs = dsmem + stage * STAGE + (2 + (wc >> 1)) * SUB;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 a[4], b[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = tr_frag(Bs, 16 * kk + frow, chb + 4 * j, half8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = tr_frag(As, 16 * kk + frow, cha + 4 * i, half8);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        if (do_cs) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acs[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], ones, acs[i], 0, 0, 0);
-        }
-      }
+      const char* st = dsmem + stage * STAGE;
+      bf16x8 a0[4], b0[2], a1[4], b1[2];
+      frags(st, 0, a0, b0);
+      frags(st, 1, a1, b1);
+      mma(a0, b0);
+      frags(st, 2, a0, b0);
+      mma(a1, b1);
+      frags(st, 3, a1, b1);
+      mma(a0, b0);
+      mma(a1, b1);
       stage ^= 1;
     }
   }
@@ -1069,14 +1120,179 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnP p) {
         if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
       }
   }
-  if (do_cs && r == 0) {
+  if (do_cs && r == 0) {                                   // column 0 of the ones-product holds the column sums of A
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int row = n0 + wr * 128 + wc * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+      if (row < p.N) atomicAdd(p.colsum + row, acs[x]);
+    }
+  }
+}
+
+// The same 256 x 256 tile as a 4-slot ring of 32-row half-steps (4 x 32 KiB): a half-step's rows are requested three barriers
+// before they are read (two half-steps = 64 KiB in flight under the MFMAs of a third), and the barrier at the top of half-step s
+// certifies half-step s + 1, so the first fragments of s + 1 are already being read from LDS while the last MFMAs of s issue -
+// no LDS latency and no global latency is exposed after a barrier. 64-row reduction tiles of the host (mt_start, mt_per_split)
+// are walked as two half-steps each.
+__global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnP p) {
+  constexpr int BR = 32, SUB = BR * 256, STAGE = 4 * SUB, NSLOT = 4;
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int xcd = bid & 7, q8 = nwg >> 3, rr = nwg & 7;
+  const int wgid = (xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8) + (bid >> 3);
+  const int ntk = (p.K + 255) / 256;
+  const int n0 = (wgid / ntk) * 256, k0 = (wgid % ntk) * 256;
+  const int nmt = p.mt_start[p.nseg];
+  const int mt0 = blockIdx.z * p.mt_per_split;
+  const int S = 2 * (min(nmt, mt0 + p.mt_per_split) - mt0);          // half-steps of this block
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3, r = lane & 31, h = lane >> 5;
+
+  // a 32-row sub-tile is 8 LDS-DMA instructions (4 rows x 256 B each): one per wave and sub-tile.
+  // Per lane: four running source pointers (A left/right, B left/right) that advance by 32 rows per half-step; a lane whose 16-byte
+  // chunk lies past N / K points at the zero page with stride 0. Only a segment change or a segment's ragged last rows recompute
+  // anything (address arithmetic every half-step cost ~480 cycles of the ~1 k-cycle MFMA budget).
+  const int srow = wave * 4 + (lane >> 4);
+  const int c16 = (lane & 15) ^ (((srow & 3) << 2) | ((srow >> 2) & 3));
+  bool cok[4];
+  long coff[4];                                               // element offset of the lane's chunk inside a 32-row slab
+  unsigned step[4];                                           // bytes per half-step (0 for zero-page lanes)
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    cok[u] = n0 + u * 128 + c16 * 8 < p.N;
+    cok[2 + u] = k0 + u * 128 + c16 * 8 < p.K;
+    coff[u] = (long)srow * p.lda + n0 + u * 128 + c16 * 8;
+    coff[2 + u] = (long)srow * p.ldb + k0 + u * 128 + c16 * 8;
+    step[u] = cok[u] ? (unsigned)(BR * p.lda * 2) : 0u;
+    step[2 + u] = cok[2 + u] ? (unsigned)(BR * p.ldb * 2) : 0u;
+  }
+  int seg = 0;
+  while (mt0 >= p.mt_start[seg + 1] && seg + 1 < p.nseg) ++seg;
+  int curM = p.segM[seg], seg_lo = p.mt_start[seg], seg_hi = p.mt_start[seg + 1];
+  const char* zp = (const char*)g_zero_page;
+  asm volatile("" : "+s"(zp));
+  const unsigned lds0 = lds_u32(dsmem);
+  const char* ptr[4];
+  auto point_at = [&](int r0) {                               // pointers of the half-step that starts at row r0 of segment `seg`
+    const __bf16* A = p.A[seg] + (long)r0 * p.lda;
+    const __bf16* B = p.B[seg] + (long)r0 * p.ldb;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      ptr[u] = cok[u] ? (const char*)(A + coff[u]) : zp;
+      ptr[2 + u] = cok[2 + u] ? (const char*)(B + coff[2 + u]) : zp;
+    }
+  };
+  point_at((mt0 - seg_lo) * 64);
+  auto issue = [&](int q) {                                   // half-step q -> slot q % 4; half-steps are issued in increasing order
+    const int mt = mt0 + (q >> 1);
+    if (mt >= seg_hi) {
+      do { ++seg; } while (mt >= p.mt_start[seg + 1]);
+      curM = p.segM[seg]; seg_lo = p.mt_start[seg]; seg_hi = p.mt_start[seg + 1];
+      point_at(0);
+    }
+    const int r0 = (mt - seg_lo) * 64 + (q & 1) * BR;
+    const unsigned sa = lds0 + (q & (NSLOT - 1)) * STAGE + wave * 1024;
+    if (r0 + BR <= curM) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) lds_dma16(ptr[u], sa + u * SUB);
+    } else {                                                  // ragged end of a segment: rows past it read zeros
+      const bool rok = r0 + srow < curM;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) lds_dma16(rok ? ptr[u] : zp, sa + u * SUB);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ptr[u] += step[u];
+  };
+  const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
+  const int frow = 8 * h + qq, half8 = 8 * (pp & 1);
+  const int cha = (16 * cb) / 8 + (pp >> 1);
+  const int chb = ((wc & 1) * 64 + 16 * cb) / 8 + (pp >> 1);
+  f32x16 acc[4][2], acs;
+#pragma unroll
+  for (int x = 0; x < 16; ++x) acs[x] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int x = 0; x < 16; ++x) acc[i][j][x] = 0.f;
+  const bool do_cs = p.colsum != nullptr && k0 == 0;
+  bf16x8 ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+  // fragments of k-step kk of the stage at `st`: A blocks 0..3 of sub-tile wr, B blocks 0..1 of sub-tile 2 + (wc >> 1)
+  auto frags = [&](const char* st, int kk, bf16x8 (&a)[4], bf16x8 (&b)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b[j] = tr_frag(st + (2 + (wc >> 1)) * SUB, 16 * kk + frow, chb + 4 * j, half8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = tr_frag(st + wr * SUB, 16 * kk + frow, cha + 4 * i, half8);
+  };
+  // one half-step = two groups of [8 (+1) MFMAs of one fragment set | the 12 reads (24 ds_read_tr) of the other set]; the
+  // sched_group_barrier sequence makes the compiler issue 3 reads after every MFMA instead of 24 reads up front (right after a
+  // barrier both waves of a SIMD are in the same phase, so reads-first leaves the matrix pipe idle)
+  auto half = [&](auto CS, const char* rd, int rd_kk, bf16x8 (&an)[4], bf16x8 (&bn)[2], const bf16x8 (&a)[4], const bf16x8 (&b)[2]) {
+    frags(rd, rd_kk, an, bn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    if constexpr (decltype(CS)::value) {
+      const bf16x8 mine = wc == 0 ? a[0] : wc == 1 ? a[1] : wc == 2 ? a[2] : a[3];
+      acs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mine, ones, acs, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // 3 LDS reads
+    }
+  };
+  auto run = [&](auto CS) {
+    bf16x8 a0[4], b0[2], a1[4], b1[2];
+    frags(dsmem, 0, a0, b0);
+    for (int s = 0; s < S; ++s) {
+      // own share of half-step s + 1 landed (s + 2 may still be in flight), then everybody's; every wave is also done reading s - 1
+      if (s + 2 < S) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (s + 3 < S) issue(s + 3);
+      half(CS, dsmem + (s & (NSLOT - 1)) * STAGE, 1, a1, b1, a0, b0);
+      // after the last half-step this reads a slot nobody needs (unused values) - keeps the loop body free of branches
+      half(CS, dsmem + ((s + 1) & (NSLOT - 1)) * STAGE, 0, a0, b0, a1, b1);
+    }
+  };
+
+  if (S > 0) {
+    issue(0);
+    if (S > 1) issue(1);
+    if (S > 2) issue(2);
+    // half-step 0 has to be there before its first fragments are read
+    if (S > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (S > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (do_cs) run(std::true_type{});
+    else run(std::false_type{});
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = k0 + wc * 64 + j * 32 + r;
+    if (col >= p.K) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
         const int row = n0 + wr * 128 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-        if (row < p.N) atomicAdd(p.colsum + row, acs[i][x]);
+        if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
       }
+  }
+  if (do_cs && r == 0) {
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+      const int row = n0 + wr * 128 + wc * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
+      if (row < p.N) atomicAdd(p.colsum + row, acs[x]);
+    }
   }
 }
 
@@ -1302,7 +1518,15 @@ extern "C" int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const
   p.mt_per_split = cdiv(nmt, split);
   dim3 grid(cdiv(N, BM) * cdiv(K, BN), 1, cdiv(nmt, p.mt_per_split));
   hipStream_t st = (hipStream_t)stream;
-  if (variant == 6) {                       // 256 x 256 tiles, 2 x 64 KiB stages
+  if (variant == 7) {                       // 256 x 256 tiles, ring of four 32-row half-steps
+    constexpr int LDS = 4 * 4 * 32 * 256;
+    static bool attr7 = false;
+    if (!attr7) {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      attr7 = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_ring_kernel, dim3(cdiv(N, 256) * cdiv(K, 256), 1, grid.z), dim3(512), LDS, st, p);
+  } else if (variant == 6) {                // 256 x 256 tiles, 2 x 64 KiB stages
     constexpr int LDS = 2 * 4 * 64 * 256;
     static bool attr6 = false;
     if (!attr6) {

@@ -573,7 +573,7 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev):
     if TN_BIG and N >= 256 and K >= 256 and nmt >= 32:
         t256 = ((N + 255) // 256) * ((K + 255) // 256)
         s6 = max(1, min(nmt // 4, round(252 / t256)))
-        cands |= {(6, s6), (6, max(1, s6 // 2)), (6, max(1, (3 * s6) // 4))}
+        cands |= {(v, sp) for v in (6, 7) for sp in (s6, max(1, s6 // 2), max(1, (3 * s6) // 4))}
     scratch = torch.zeros((N, K), dtype=torch.float32, device=dev)
     cs = torch.zeros((N,), dtype=torch.float32, device=dev)
     timed = []
