@@ -263,7 +263,7 @@ def main():
             e0.record()
             r = orig(a, b, *p, **k)
             e1.record()
-            n_ = b.t.shape[1] if isinstance(b, ops.KN) else b.shape[0]          # KN: dgrad operand W[K, N] (no transposed copy)
+            n_ = b.n if isinstance(b, ops.WT) else b.t.shape[1] if isinstance(b, ops.KN) else b.shape[0]      # WT / KN: dgrad operand handles
             rec.append((2.0 * a.shape[0] * n_ * a.shape[1], e0, e1, (a.shape[0], n_, a.shape[1])))
             return r
 
@@ -275,7 +275,7 @@ def main():
             r = orig2(a, b, *p, **k)
             e1.record()
             rows = a[0].shape[0] + a[1].shape[0]
-            n_ = b[0].t.shape[1] if isinstance(b[0], ops.KN) else b[0].shape[0]
+            n_ = b[0].n if isinstance(b[0], ops.WT) else b[0].t.shape[1] if isinstance(b[0], ops.KN) else b[0].shape[0]
             rec.append((2.0 * rows * n_ * a[0].shape[1], e0, e1, (rows, n_, a[0].shape[1])))
             return r
 

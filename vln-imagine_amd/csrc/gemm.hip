@@ -922,17 +922,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_nn_glds_kernel(GemmP p) {
     bok[i] = n0 + c * 8 < p.N;                                             // N is a multiple of 8: a chunk is all-in or all-out
     gb[i] = p.B + ((long)krow * p.ldb + n0 + c * 8) * ES;
   }
-  using gptr = const __attribute__((address_space(1))) void*;
-  using lptr = __attribute__((address_space(3))) void*;
   const char* zp = (const char*)g_zero_page;            // pinned in scalar registers: otherwise re-loaded (GOT) inside the loop
   asm volatile("" : "+s"(zp));
+  const unsigned lds0 = lds_u32(dsmem);
   auto issue = [&](int t, int stage) {
-    char* sa = dsmem + stage * STAGE + wave * 1024;
+    const unsigned sa = lds0 + stage * STAGE + wave * 1024;
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
-      __builtin_amdgcn_global_load_lds((gptr)(ga[i] + (long)t * ROWB), (lptr)(sa + i * NW * 1024), 16, 0, 0);
+      lds_dma16(ga[i] + (long)t * ROWB, sa + i * NW * 1024);
       const void* pb = bok[i] ? (const void*)(gb[i] + (long)t * BK * p.ldb * ES) : (const void*)zp;
-      __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(sa + BM * ROWB + i * NW * 1024), 16, 0, 0);
+      lds_dma16(pb, sa + BM * ROWB + i * NW * 1024);
     }
   };
   const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;

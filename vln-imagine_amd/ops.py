@@ -9,6 +9,7 @@ bidirectional cross-attention block) so that the backward pass is an explicit ke
 sequence with fused epilogues (bias, GELU / GELU', residual) instead of ~40 tiny nodes.
 """
 import ctypes
+import os
 import weakref
 import math
 
@@ -75,10 +76,31 @@ class KN:
         self.t = t
 
 
-NN_DGRAD = False         # True: bf16 dgrad straight from W[out, in] (no W^T shadows, half the shadow memory). Measured on the
-                         # bench step: the transposing-read kernels are ~6 % slower per dgrad launch (+1.3 ms) than the NT kernels on
-                         # W^T, which is more than the 88 transposes per step they remove (0.9 ms) - so off by default.
+NN_DGRAD = os.environ.get("VLNI_NN_DGRAD", "1") == "1"    # bf16 dgrad straight from W[out, in] through the transposing-read kernel: no W^T
+                         # shadows to rebuild after every optimizer step and half the shadow memory. Same-box A/B on the bench step
+                         # (3 pairs): 37.5-37.8 ms vs 38.1 ms with NT kernels on W^T copies. (Before the LDS-DMA of that kernel was
+                         # issued as asm it was the slower choice: the compiler serialised its copies with the reads.)
 NN_VARIANTS = (2, 3, 4, 5)
+NN_MIN_ROWS = int(os.environ.get("VLNI_NN_MIN_ROWS", "4096"))   # below this the small-tile NT pipelines on a W^T copy win (DUET's map / viewpoint
+                                                                # streams: 25.0 vs 26.0 ms per step with every dgrad on the NN kernel)
+
+
+class WT:
+    """The dgrad operand of a (possibly row-packed) weight, resolved by gemm_nt / gemm_nt2 once the row count of the launch is known:
+    the weight itself as [K, N] (KN, transposing-read kernel) for long launches, the maintained W^T copy for short ones."""
+    __slots__ = ("params", "dtype")
+
+    def __init__(self, params, dtype):
+        self.params, self.dtype = params, dtype
+
+    @property
+    def n(self):                      # output width of the dgrad launch = in_features
+        return self.params[0].shape[1]
+
+    def resolve(self, rows):
+        if rows >= NN_MIN_ROWS:
+            return KN(SHADOWS.get(self.params, self.dtype, False))
+        return SHADOWS.get(self.params, self.dtype, True)
 
 
 def _gemm_call(variant, a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K, drop=None):
@@ -93,6 +115,8 @@ def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_s
             alpha=1.0, split_k=1, atomic=False, out_dtype=None, drop=None):
     """out[M,N] = epi(a[M,K] @ b[N,K]^T); a, b same dtype, K-contiguous. drop = (p, seed): dropout after act, before residual."""
     M, K = a.shape
+    if isinstance(b, WT):
+        b = b.resolve(M)
     kn = isinstance(b, KN)
     if kn:
         b = b.t
@@ -138,6 +162,9 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
     (a0, a1), (b0, b1) = a, b
     M0, K = a0.shape
     M1 = a1.shape[0]
+    if isinstance(b0, WT):
+        b0, b1 = b0.resolve(M0 + M1), b1.resolve(M0 + M1)
+        b = (b0, b1)
     kn = isinstance(b0, KN)
     if kn:
         b0, b1 = b0.t, b1.t
@@ -475,11 +502,12 @@ SHADOWS = ShadowCache()
 
 def _w(params, dtype, transposed=False):
     """Operand form of a (possibly row-packed) parameter. transposed=True is the dgrad operand: W^T [in, out] for the NT kernels,
-    or - bf16 with NN_DGRAD - the untransposed weight wrapped in KN for the transposing-read kernels (no copy to rebuild)."""
+    or - bf16 with NN_DGRAD - a WT handle that the GEMM front-ends turn into the untransposed weight (KN, transposing-read kernels,
+    no copy to rebuild) or the W^T copy depending on the launch's row count."""
     if transposed and NN_DGRAD and dtype == torch.bfloat16 and params[0].dim() == 2:
         out_f = sum(p.shape[0] for p in params)
         if out_f % 64 == 0 and out_f >= 192 and params[0].shape[1] % 8 == 0:
-            return KN(SHADOWS.get(params, dtype, False))
+            return WT(params, dtype)
     return SHADOWS.get(params, dtype, transposed)
 
 
