@@ -396,6 +396,57 @@ def test_wgrad_tn_lds_dma_variants_exact(ops, variant, split):
     assert torch.equal(cs.cpu(), sum(d.sum(0) for d in dys))
 
 
+@pytest.mark.parametrize("split", [2, 4])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
+def test_wgrad_partials_then_batched_reduction_exact(ops, variant, split):
+    """Partials mode: every row split stores its share (no atomics), vlni_reduce_parts adds all of them into gradients that already
+    hold something - two tensors (weight + bias gradient) x two parameters in ONE reduction launch. Exact on small integers."""
+    import ctypes
+    import numpy as np
+    from vln_imagine_amd import _lib
+    g = torch.Generator().manual_seed(13 + variant)
+    st = torch.cuda.current_stream().cuda_stream
+    entries, refs, keep = [], [], []
+    for (N, K, Ms) in ((768, 256, [700, 64, 333]), (256, 776, [512, 130])):
+        dys = [torch.randint(-2, 3, (m, N), generator=g).float() for m in Ms]
+        xs = [torch.randint(-2, 3, (m, K), generator=g).float() for m in Ms]
+        dd, xx = [d.bfloat16().cuda() for d in dys], [x.bfloat16().cuda() for x in xs]
+        n = len(Ms)
+        nmt = sum((m + 63) // 64 for m in Ms)
+        eff, per = ops._eff_split(nmt, split)
+        assert per >= 3
+        part = torch.full((eff * (N * K + N),), 7.0, device="cuda")                   # stale values must all be overwritten
+        w0, b0 = torch.randint(-3, 4, (N, K), generator=g).float(), torch.randint(-3, 4, (N,), generator=g).float()
+        gw, gb = w0.cuda(), b0.cuda()
+        pa = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dd]); pb = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xx])
+        pm = (ctypes.c_int * n)(*Ms)
+        cpart = part.data_ptr() + 4 * eff * N * K
+        _lib.call("vlni_gemm_tn_bf16_grouped_part", n, pa, pb, pm, N, K, part.data_ptr(), N * K, N, K, cpart, split, variant, st)
+        entries += [(gw.data_ptr(), part.data_ptr(), N * K // 4, N * K // 4, eff), (gb.data_ptr(), cpart, N // 4, N // 4, eff)]
+        refs.append((gw, w0 + sum(d.t() @ x for d, x in zip(dys, xs)), gb, b0 + sum(d.sum(0) for d in dys)))
+        keep += [dd, xx, part]
+    arr = np.zeros((len(entries),), ops._PART_DT)
+    blk = 0
+    for i, (dst, part_ptr, n4, s4, eff) in enumerate(entries):
+        arr[i] = (dst, part_ptr, n4, s4, eff, blk)
+        blk += -(-n4 // 1024)
+    tab = torch.from_numpy(arr.view(np.uint8)).cuda()
+    _lib.call("vlni_reduce_parts", tab.data_ptr(), len(entries), blk, st)
+    for gw, rw, gb, rb in refs:
+        assert torch.equal(gw.cpu(), rw) and torch.equal(gb.cpu(), rb)
+
+
+def test_wgrad_partials_reject_register_staged_kernel(ops):
+    import ctypes
+    from vln_imagine_amd import _lib
+    d, x = torch.zeros(128, 64, dtype=torch.bfloat16, device="cuda"), torch.zeros(128, 64, dtype=torch.bfloat16, device="cuda")
+    part = torch.zeros(2 * (64 * 64 + 64), device="cuda")
+    pa, pb, pm = (ctypes.c_void_p * 1)(d.data_ptr()), (ctypes.c_void_p * 1)(x.data_ptr()), (ctypes.c_int * 1)(128)
+    with pytest.raises(_lib.VlniError):                                              # 1 row tile per split: no LDS-DMA pipeline
+        _lib.call("vlni_gemm_tn_bf16_grouped_part", 1, pa, pb, pm, 64, 64, part.data_ptr(), 64 * 64, 64, 64, part.data_ptr() + 4 * 2 * 4096,
+                  2, 5, torch.cuda.current_stream().cuda_stream)
+
+
 @pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
 def test_gemm_variants_identical(ops, variant):
     """All GEMM pipelines (register-staged, LDS-DMA 2/3-stage with 4 or 8 waves, large tiles 256x128 / 256x256 / 128x256) give

@@ -22,7 +22,7 @@ for (N, K, M, nseg) in [(768, 768, 2752, 6), (2304, 768, 2752, 6), (3072, 768, 2
     pm = (ctypes.c_int * nseg)(*[M] * nseg)
     fl = 2.0 * N * K * M * nseg
     res = []
-    for variant, splits in ((5, (4, 8, 12)), (6, (2, 4, 7, 9, 14)), (7, (2, 4, 7, 9, 14))):
+    for variant, splits in ((7, (2, 4, 7, 9, 14)), (77, (2, 4, 7, 9, 14))):
         for split in splits:
             us = t(lambda: _lib.call("vlni_gemm_tn_bf16_grouped_v", nseg, pa, pb, pm, N, K, out.data_ptr(), K, N, K, cs.data_ptr(), split, variant, st))
             res.append(f"v{variant}s{split}:{us:4.0f}us/{fl/us/1e6:3.0f}TF")

@@ -6,7 +6,7 @@ rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Nam
 idx = [i for i, r in enumerate(rows) if "adamw" in r[2]]
 a, b = idx[-nsteps - 1], idx[-1]
 seg = rows[a + 1:b + 1]
-FAM = ("gemm_nt", "gemm_nn", "gemm_tn", "attn_bwd", "attn_fwd", "ln_bwd", "ln_fwd", "adamw", "transpose", "cast_kernel", "scatter_add",
+FAM = ("gemm_nt", "gemm_nn", "gemm_tn", "reduce_parts", "attn_bwd", "attn_fwd", "ln_bwd", "ln_fwd", "adamw", "transpose", "cast_kernel", "scatter_add",
        "smallk", "FillFunctor", "CatArray", "CUDAFunctor_add", "direct_copy", "MulFunctor", "reduce_kernel", "copyBuffer")
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, k in seg:

@@ -23,6 +23,8 @@ SIGNATURES = {
     "vlni_gemm_tn_bf16": [P, L, P, L, P, L, I, I, I, P, I, P],
     "vlni_gemm_tn_bf16_grouped": [I, P, P, P, L, L, P, L, I, I, P, I, P],
     "vlni_gemm_tn_bf16_grouped_v": [I, P, P, P, L, L, P, L, I, I, P, I, I, P],
+    "vlni_gemm_tn_bf16_grouped_part": [I, P, P, P, L, L, P, L, I, I, P, I, I, P],
+    "vlni_reduce_parts": [P, I, I, P],
     "vlni_attn_fwd": [I, P, L, P, L, P, L, P, P, P, L, P, I, I, I, I, F, F, U, P],
     "vlni_attn_bwd": [I, P, L, P, L, P, L, P, P, P, L, P, L, P, P, L, P, L, P, L, P, I, I, I, I, F, F, U, P],
     "vlni_layernorm_fwd": [I, P, L, P, P, F, P, L, P, P, I, I, P],

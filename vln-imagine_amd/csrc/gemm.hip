@@ -600,7 +600,19 @@ struct TnP {
   int N, K;
   int mt_per_split;
   float* colsum;
+  // "partials" mode (part != null): split z writes its share of C with plain stores to part + z * part_stride (dense [N][K]) and its
+  // column sums to colsum + z * N; vlni_reduce_parts adds them into the gradient afterwards. Float atomics run at ~1.3 TB/s on this
+  // chip against ~5 TB/s for stores, and were 30-50 % of a weight-gradient launch (tools/tn_probe.py).
+  float* part; long part_stride;
 };
+__device__ __forceinline__ void tn_out(const TnP& p, int row, int col, float v) {
+  if (p.part) p.part[(long)blockIdx.z * p.part_stride + (long)row * p.K + col] = v;
+  else atomicAdd(&p.C[(long)row * p.ldc + col], v);
+}
+__device__ __forceinline__ void tn_cs(const TnP& p, int row, float v) {
+  if (p.part) p.colsum[(long)blockIdx.z * p.N + row] = v;
+  else atomicAdd(p.colsum + row, v);
+}
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ int tr_off(int row, int ch) { return row * 256 + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
@@ -725,7 +737,7 @@ __global__ __launch_bounds__(NT) void gemm_tn_bf16_kernel(TnP p) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
         const int row = n0 + wr * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-        if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
+        if (row < p.N) tn_out(p, row, col, acc[i][j][x]);
       }
   }
   if (do_cs) {
@@ -871,7 +883,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_glds_kernel(TnP p) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
         const int row = n0 + wr * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-        if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
+        if (row < p.N) tn_out(p, row, col, acc[i][j][x]);
       }
   }
   if (do_cs && r == 0) {                                   // column 0 of the ones-product holds the column sums of A
@@ -880,7 +892,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_glds_kernel(TnP p) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
         const int row = n0 + wr * 64 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-        if (row < p.N) atomicAdd(p.colsum + row, acs[i][x]);
+        if (row < p.N) tn_cs(p, row, acs[i][x]);
       }
   }
 }
@@ -1116,14 +1128,14 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(TnP p) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
         const int row = n0 + wr * 128 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-        if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
+        if (row < p.N) tn_out(p, row, col, acc[i][j][x]);
       }
   }
   if (do_cs && r == 0) {                                   // column 0 of the ones-product holds the column sums of A
 #pragma unroll
     for (int x = 0; x < 16; ++x) {
       const int row = n0 + wr * 128 + wc * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-      if (row < p.N) atomicAdd(p.colsum + row, acs[x]);
+      if (row < p.N) tn_cs(p, row, acs[x]);
     }
   }
 }
@@ -1284,14 +1296,14 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnP p) {
 #pragma unroll
       for (int x = 0; x < 16; ++x) {
         const int row = n0 + wr * 128 + i * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-        if (row < p.N) atomicAdd(&p.C[(long)row * p.ldc + col], acc[i][j][x]);
+        if (row < p.N) tn_out(p, row, col, acc[i][j][x]);
       }
   }
   if (do_cs && r == 0) {
 #pragma unroll
     for (int x = 0; x < 16; ++x) {
       const int row = n0 + wr * 128 + wc * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;
-      if (row < p.N) atomicAdd(p.colsum + row, acs[x]);
+      if (row < p.N) tn_cs(p, row, acs[x]);
     }
   }
 }
@@ -1499,13 +1511,14 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
 // Replaces autograd's weight-gradient matmuls (one launch per parameter per episode when the segments are the T steps).
 // variant: 0/1 = register-staged kernel, 2 = LDS-DMA 2-stage, 3 = 3-stage, 4 / 5 = 3- / 2-stage with 8 waves, 6 = 256 x 256 tiles (identical sums up
 // to float atomics order).
-extern "C" int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
-                                           float* C, long ldc, int N, int K, float* colsum, int split, int variant, void* stream) {
+static int tn_grouped_go(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb, float* C, long ldc,
+                         int N, int K, float* colsum, float* part, long part_stride, int split, int variant, void* stream) {
   VLNI_CHECK(nseg >= 1 && nseg <= TN_MAXSEG, VLNI_EINVAL, "gemm_tn: nseg=%d not in 1..%d", nseg, TN_MAXSEG);
   VLNI_CHECK(N > 0 && K > 0 && split >= 1, VLNI_EINVAL, "gemm_tn: bad problem N=%d K=%d split=%d", N, K, split);
   VLNI_CHECK(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, VLNI_EINVAL, "gemm_tn: N/K/lda/ldb multiples of 8");
   TnP p;
   p.nseg = nseg; p.lda = lda; p.ldb = ldb; p.C = C; p.ldc = ldc; p.N = N; p.K = K; p.colsum = colsum;
+  p.part = part; p.part_stride = part_stride;
   p.mt_start[0] = 0;
   for (int s = 0; s < nseg; ++s) {
     VLNI_CHECK(M[s] > 0, VLNI_EINVAL, "gemm_tn: empty segment %d", s);
@@ -1549,8 +1562,54 @@ extern "C" int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const
     else if (variant == 4) hipLaunchKernelGGL((gemm_tn_glds_kernel<3, 8>), grid, dim3(512), 3 * ST, st, p);
     else hipLaunchKernelGGL((gemm_tn_glds_kernel<2, 8>), grid, dim3(512), 2 * ST, st, p);
   } else {
+    VLNI_CHECK(part == nullptr, VLNI_EUNSUP, "gemm_tn partials: needs an LDS-DMA variant (2..7) and >= 3 row tiles per split (variant=%d, %d)",
+               variant, p.mt_per_split);
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(NT), 0, st, p);
   }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
+                                           float* C, long ldc, int N, int K, float* colsum, int split, int variant, void* stream) {
+  return tn_grouped_go(nseg, A, B, M, lda, ldb, C, ldc, N, K, colsum, nullptr, 0, split, variant, stream);
+}
+
+extern "C" int vlni_gemm_tn_bf16_grouped_part(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
+                                              float* part, long part_stride, int N, int K, float* colsum_part, int split, int variant,
+                                              void* stream) {
+  VLNI_CHECK(part && part_stride >= (long)N * K && part_stride % 4 == 0, VLNI_EINVAL, "gemm_tn partials: part_stride=%ld < N*K", part_stride);
+  return tn_grouped_go(nseg, A, B, M, lda, ldb, nullptr, 0, N, K, colsum_part, part, part_stride, split, variant, stream);
+}
+
+namespace {
+struct PartEntry { float* dst; const float* part; long n4, stride4; int split, blk0; };
+// dst[i] += sum_z part[z][i], many (dst, part) pairs per launch; block -> entry by binary search over the entries' first blocks;
+// a block covers 1024 float4 of one entry
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const PartEntry* __restrict__ tab, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].blk0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PartEntry e = tab[lo];
+  const long base = (long)(blockIdx.x - e.blk0) * 1024 + threadIdx.x;
+  f32x4* dst = (f32x4*)e.dst;
+  const f32x4* part = (const f32x4*)e.part;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long i = base + u * 256;
+    if (i >= e.n4) break;
+    f32x4 a = dst[i];
+    for (int z = 0; z < e.split; ++z) a += part[(long)z * e.stride4 + i];
+    dst[i] = a;
+  }
+}
+}  // namespace
+
+extern "C" int vlni_reduce_parts(const void* table, int n_entries, int n_blocks, void* stream) {
+  VLNI_CHECK(table && n_entries > 0 && n_blocks > 0, VLNI_EINVAL, "reduce_parts: n_entries=%d n_blocks=%d", n_entries, n_blocks);
+  hipLaunchKernelGGL(reduce_parts_kernel, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, (const PartEntry*)table, n_entries);
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

@@ -13,6 +13,8 @@ import os
 import weakref
 import math
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -584,11 +586,30 @@ _WQ = {}
 _TN_BEST = {}
 
 
+WGRAD_PARTS = os.environ.get("VLNI_WGRAD_PARTS", "1") == "1"   # row splits write partial gradients with plain stores + ONE batched reduction per
+                                                              # step instead of float atomics (~1.3 TB/s on this chip, 30-50 % of a launch)
+_PART_BUFS = {}       # (gradient address, chunk, splits, N, K) -> workspace: [splits][N][K] slabs, then [splits][N] column sums
+_PART_TABLES = {}     # signature of a flush -> (device table, entries, blocks)
+_PART_DT = np.dtype([("dst", "<u8"), ("part", "<u8"), ("n4", "<i8"), ("stride4", "<i8"), ("split", "<i4"), ("blk0", "<i4")])
+
+
+def _eff_split(nmt, split):
+    """Row splits a grouped launch really produces (include/vlni.h)."""
+    per = -(-nmt // split)
+    return -(-nmt // per), per
+
+
+def _parts_ok(variant, nmt, split):
+    eff, per = _eff_split(nmt, split)
+    return WGRAD_PARTS and eff > 1 and variant >= 2 and per >= 3
+
+
 def _tn_choice(n, pa, pb, pm, N, K, nmt, dev):
     """(kernel variant, row split) of a grouped weight-gradient launch. Which of the 128x128 LDS-DMA kernel (more, smaller blocks)
-    and the 256x256 tile (half the operand traffic, one block per CU) wins, and at which split, depends on the output size and on
+    and the 256x256 tiles (half the operand traffic, one block per CU) wins, and at which split, depends on the output size and on
     the length of the reduction (tools/tn_probe.py): the first launch of a (N, K, rows) class times the candidates on a scratch
-    output and the winner is cached."""
+    output and the winner is cached. Split candidates are timed in the mode they will run in (partials + their share of the
+    batched reduction, priced at 4 TB/s; atomics otherwise)."""
     default = (TN_VARIANT, max(1, min(8, nmt // 8)))
     if not AUTOTUNE:
         return default
@@ -597,23 +618,31 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev):
     if best is not None or torch.cuda.is_current_stream_capturing():
         return best or default
     t128 = ((N + 127) // 128) * ((K + 127) // 128)
-    cands = {(TN_VARIANT, max(1, min(s, nmt // 3))) for s in (2, 3, 4, 6, 8, 12, max(1, round(512 / t128)))}
+    cands = {(TN_VARIANT, max(1, min(s, nmt // 3))) for s in (2, 3, 4, 6, 8, 12, 16, max(1, round(512 / t128)))}
     if TN_BIG and N >= 256 and K >= 256 and nmt >= 32:
         t256 = ((N + 255) // 256) * ((K + 255) // 256)
         s6 = max(1, min(nmt // 4, round(252 / t256)))
-        cands |= {(v, sp) for v in (6, 7) for sp in (s6, max(1, s6 // 2), max(1, (3 * s6) // 4))}
-    scratch = torch.zeros((N, K), dtype=torch.float32, device=dev)
-    cs = torch.zeros((N,), dtype=torch.float32, device=dev)
+        cands |= {(v, sp) for v in (6, 7) for sp in (s6, max(1, s6 // 2), max(1, (3 * s6) // 4), min(nmt // 4, 2 * s6))}
+    smax = max(_eff_split(nmt, sp)[0] for _, sp in cands)
+    scratch = torch.zeros((smax * (N * K + N),), dtype=torch.float32, device=dev)
     timed = []
     for v, sp in sorted(cands):
-        args = ("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, scratch.data_ptr(), K, N, K, cs.data_ptr(), sp, v, _st())
+        if _parts_ok(v, nmt, sp):
+            eff = _eff_split(nmt, sp)[0]
+            args = ("vlni_gemm_tn_bf16_grouped_part", n, pa, pb, pm, N, K, scratch.data_ptr(), N * K, N, K,
+                    scratch.data_ptr() + 4 * smax * N * K, sp, v, _st())
+            extra = (eff + 2) * (N * K + N) * 4 / 4e9            # ms: its share of the batched reduction
+        else:
+            args = ("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, scratch.data_ptr(), K, N, K, scratch.data_ptr() + 4 * N * K,
+                    sp, v, _st())
+            extra = 0.0
         _lib.call(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         _lib.call(*args); _lib.call(*args)
         e1.record()
         e1.synchronize()
-        timed.append((e0.elapsed_time(e1), v, sp))
+        timed.append((e0.elapsed_time(e1) / 2 + extra, v, sp))
     _, v, sp = min(timed)
     _TN_BEST[key] = (v, sp)
     return v, sp
@@ -621,7 +650,9 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev):
 
 def flush_wgrads():
     """Runs the queued weight/bias gradient reductions (must precede any read of the .grad arena)."""
+    entries, dev = [], None
     for wv, bv, segs in _WQ.values():
+        dev = wv.device
         for c in range(0, len(segs), 16):
             chunk = segs[c:c + 16]
             n = len(chunk)
@@ -631,9 +662,31 @@ def flush_wgrads():
             pm = (ctypes.c_int * n)(*[d.shape[0] for d, _ in chunk])
             nmt = sum((d.shape[0] + 63) // 64 for d, _ in chunk)
             variant, split = _tn_choice(n, pa, pb, pm, N, K, nmt, wv.device)
-            _lib.call("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
-                      split, variant, _st())
+            if _parts_ok(variant, nmt, split) and wv.is_contiguous() and bv.is_contiguous() and N % 4 == 0:
+                eff = _eff_split(nmt, split)[0]
+                key = (wv.data_ptr(), c, eff, N, K)
+                buf = _PART_BUFS.get(key)
+                if buf is None:
+                    buf = _PART_BUFS[key] = torch.empty((eff * (N * K + N),), dtype=torch.float32, device=wv.device)
+                cpart = buf.data_ptr() + 4 * eff * N * K                 # [eff][N] column-sum partials behind the [eff][N][K] slabs
+                _lib.call("vlni_gemm_tn_bf16_grouped_part", n, pa, pb, pm, N, K, buf.data_ptr(), N * K, N, K, cpart, split, variant, _st())
+                entries.append((wv.data_ptr(), buf.data_ptr(), N * K // 4, N * K // 4, eff))
+                entries.append((bv.data_ptr(), cpart, N // 4, N // 4, eff))
+            else:
+                _lib.call("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
+                          split, variant, _st())
     _WQ.clear()
+    if entries:
+        sig = tuple(entries)
+        tab = _PART_TABLES.get(sig)
+        if tab is None:
+            arr = np.zeros((len(entries),), _PART_DT)
+            blk = 0
+            for i, (dst, part, n4, stride4, eff) in enumerate(entries):
+                arr[i] = (dst, part, n4, stride4, eff, blk)
+                blk += -(-n4 // 1024)
+            tab = _PART_TABLES[sig] = (torch.from_numpy(arr.view(np.uint8)).to(dev), len(entries), blk)
+        _lib.call("vlni_reduce_parts", tab[0].data_ptr(), tab[1], tab[2], _st())
 
 
 def _wb_grad_to(ws, bs, dy, x):
