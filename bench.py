@@ -307,7 +307,7 @@ def main():
                 traffic = round(json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["bytes_per_launch"])
         except Exception:
             traffic = None
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel<%s>" % ("__bf16" if args.dtype == "bf16" else "float"),
+        roof = {"bound": "mfma", "kernel": "gemm_nt_* / gemm_nn_glds_kernel <%s>" % ("__bf16" if args.dtype == "bf16" else "float"),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec) / len(rec)),
                 "launches_per_step": len(rec), "avg_launch_us": round(tot_ms * 1e3 / len(rec), 2),

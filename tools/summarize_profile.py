@@ -7,7 +7,7 @@ rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 line = json.loads(open(prof_json).read())
 steps = sum(int(r["Calls"]) for r in rows if "adamw" in r["Name"]) or (line["steps"] + line["warmup"] + 1)   # one AdamW launch per step
-nt = [r for r in rows if "gemm_nt" in r["Name"]]
+nt = [r for r in rows if "gemm_nt" in r["Name"] or "gemm_nn" in r["Name"]]
 nt_calls = sum(int(r["Calls"]) for r in nt); nt_ns = sum(float(r["TotalDurationNs"]) for r in nt)
 out = [f"# rocprofv3 --kernel-trace --stats ({tag})", "",
        "command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --no-cpu-baseline --no-time-batched-extra` "
@@ -15,7 +15,7 @@ out = [f"# rocprofv3 --kernel-trace --stats ({tag})", "",
        "launches; the first warm-up step also holds the per-shape GEMM autotune trials, ~8 variants x 3 launches per shape)", "",
        f"bench line under the profiler: {line['value']} episodes/s, {line['ms_per_step']} ms/step",
        f"kernel time total {tot/1e6:.1f} ms over {steps} steps = {tot/1e6/steps:.2f} ms/step",
-       f"dominant kernel family gemm_nt* (one contraction, thirteen pipelines): {nt_calls/steps:.0f} launches/step, average "
+       f"dominant kernel family gemm_nt* / gemm_nn* (one contraction: thirteen NT pipelines + the transposing-read dgrad form): {nt_calls/steps:.0f} launches/step, average "
        f"{nt_ns/nt_calls/1e3:.1f} us per launch (rocprof, all launches incl. autotune trials) vs roofline.avg_launch_us "
        f"{line['roofline']['avg_launch_us']} us (HIP events around each launch of one eager step inside bench.py, behind a 50-ms spin "
        "kernel so that the pairs bracket the kernels only; each pair still adds ~2 us)", "",

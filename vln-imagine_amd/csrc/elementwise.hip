@@ -102,7 +102,18 @@ __global__ __launch_bounds__(256) void smallk_bwd_kernel(const T* __restrict__ d
   if (n >= N) return;
   float a[16], s = 0.f;
   for (int k = 0; k < 16; ++k) a[k] = 0.f;
-  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+  int r = blockIdx.y;
+  for (; r + 3 * (int)gridDim.y < rows; r += 4 * gridDim.y) {          // four rows' loads in flight (the loop is latency-bound)
+    float d[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) d[u] = DT<T>::ld(dy + (long)(r + u * gridDim.y) * lddy + n);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s += d[u];
+      for (int k = 0; k < K; ++k) a[k] += d[u] * x[(long)(r + u * gridDim.y) * ldx + k];
+    }
+  }
+  for (; r < rows; r += gridDim.y) {
     const float d = DT<T>::ld(dy + (long)r * lddy + n);
     s += d;
     for (int k = 0; k < K; ++k) a[k] += d * x[(long)r * ldx + k];
@@ -321,6 +332,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   float a = 0.f;
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 * stride < n; i += 4 * stride) {              // four independent 16-byte loads in flight per lane
+    const f32x4 v0 = *(const f32x4*)(g + i), v1 = *(const f32x4*)(g + i + stride), v2 = *(const f32x4*)(g + i + 2 * stride),
+                v3 = *(const f32x4*)(g + i + 3 * stride);
+    a += (v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2] + v0[3] * v0[3]) + (v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2] + v1[3] * v1[3]) +
+         (v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2] + v2[3] * v2[3]) + (v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2] + v3[3] * v3[3]);
+  }
   for (; i < n; i += stride) {
     const f32x4 v = *(const f32x4*)(g + i);
     a += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];

@@ -623,7 +623,7 @@ __device__ __forceinline__ int tr_off(int row, int ch) { return row * 256 + 16 *
 // awaited by the explicit s_waitcnt vmcnt(N) + s_barrier these kernels carry anyway) while the reads stay builtins, so the compiler
 // still counts lgkmcnt for them. lds_addr must be wave-uniform: lane l's 16 bytes land at lds_addr + 16 * l.
 __device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
 }
 __device__ __forceinline__ unsigned lds_u32(const char* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
