@@ -1,4 +1,5 @@
-"""Micro-benchmark of the grouped transposing-read wgrad kernel: TF/s vs split for the episode-level shapes."""
+"""Micro-benchmark of the grouped transposing-read wgrad kernels in partials mode (plain-store row splits, the mode the product
+runs them in; the batched reduction is not included): TF/s vs variant x split for the episode-level shapes."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +15,7 @@ def t(fn, reps=10):
     return e0.elapsed_time(e1) / reps * 1e3
 
 st = torch.cuda.current_stream().cuda_stream
-for (N, K, M, nseg) in [(768, 768, 2752, 6), (2304, 768, 2752, 6), (3072, 768, 2752, 6), (768, 3072, 2752, 6), (2304, 768, 5120, 1), (3072, 768, 5120, 1), (768, 3072, 5120, 1), (2304, 768, 2304, 6), (3072, 768, 2304, 6)]:
+for (N, K, M, nseg) in [(3072, 768, 2752, 6), (768, 3072, 2752, 6), (2304, 768, 2752, 6)]:
     dys = [(torch.randn(M, N, device="cuda") * 0.1).bfloat16() for _ in range(nseg)]
     xs = [(torch.randn(M, K, device="cuda") * 0.5).bfloat16() for _ in range(nseg)]
     out = torch.zeros(N, K, device="cuda"); cs = torch.zeros(N, device="cuda")
@@ -22,8 +23,9 @@ for (N, K, M, nseg) in [(768, 768, 2752, 6), (2304, 768, 2752, 6), (3072, 768, 2
     pm = (ctypes.c_int * nseg)(*[M] * nseg)
     fl = 2.0 * N * K * M * nseg
     res = []
-    for variant, splits in ((7, (2, 4, 7, 9, 14)), (77, (2, 4, 7, 9, 14))):
+    for variant, splits in ((5, (4, 8, 12)), (6, (7, 9)), (7, (2, 4, 7, 9, 14))):
         for split in splits:
-            us = t(lambda: _lib.call("vlni_gemm_tn_bf16_grouped_v", nseg, pa, pb, pm, N, K, out.data_ptr(), K, N, K, cs.data_ptr(), split, variant, st))
+            part = torch.empty(16 * (N * K + N), device="cuda")
+            us = t(lambda: _lib.call("vlni_gemm_tn_bf16_grouped_part", nseg, pa, pb, pm, N, K, part.data_ptr(), N * K, N, K, part.data_ptr() + 4 * 16 * N * K, split, variant, st))
             res.append(f"v{variant}s{split}:{us:4.0f}us/{fl/us/1e6:3.0f}TF")
     print(f"N={N:5d} K={K:5d} M={M}x{nseg}: " + "  ".join(res), flush=True)

@@ -1241,9 +1241,10 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnP p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = tr_frag(st + wr * SUB, 16 * kk + frow, cha + 4 * i, half8);
   };
-  // one half-step = two groups of [8 (+1) MFMAs of one fragment set | the 12 reads (24 ds_read_tr) of the other set]; the
-  // sched_group_barrier sequence makes the compiler issue 3 reads after every MFMA instead of 24 reads up front (right after a
-  // barrier both waves of a SIMD are in the same phase, so reads-first leaves the matrix pipe idle)
+  // one half-step = two groups of [8 (+1) MFMAs of one fragment set | the 12 reads (24 ds_read_tr) of the other set], interleaved
+  // instead of 24 reads up front (right after a barrier both waves of a SIMD are in the same phase, so reads-first leaves the matrix
+  // pipe idle). Same probe, split 2: no hint 247 us, sched_group_barrier (1 MFMA, 3 reads) x 8: 249 us, iglp_opt(0): 233 us;
+  // iglp_opt(1) sends hipcc out of memory on this file. On the 2-stage kernels above the hint changes nothing.
   auto half = [&](auto CS, const char* rd, int rd_kk, bf16x8 (&an)[4], bf16x8 (&bn)[2], const bf16x8 (&a)[4], const bf16x8 (&b)[2]) {
     frags(rd, rd_kk, an, bn);
 #pragma unroll
@@ -1254,11 +1255,7 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnP p) {
       const bf16x8 mine = wc == 0 ? a[0] : wc == 1 ? a[1] : wc == 2 ? a[2] : a[3];
       acs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(mine, ones, acs, 0, 0, 0);
     }
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);      // 3 LDS reads
-    }
+    __builtin_amdgcn_iglp_opt(0);                             // the compiler's MFMA / DS-read interleave for small GEMM loops
   };
   auto run = [&](auto CS) {
     bf16x8 a0[4], b0[2], a1[4], b1[2];
