@@ -621,9 +621,10 @@ __device__ __forceinline__ int tr_off(int row, int ch) { return row * 256 + 16 *
 // first one - which serialises every stage's global -> LDS copy with the MFMAs it was meant to overlap (measured on the 256 x 256
 // weight-gradient tile: 4.3 k cycles per 64-row step instead of 3.3 k). As asm the copy is invisible to that pass (its completion is
 // awaited by the explicit s_waitcnt vmcnt(N) + s_barrier these kernels carry anyway) while the reads stay builtins, so the compiler
-// still counts lgkmcnt for them. lds_addr must be wave-uniform: lane l's 16 bytes land at lds_addr + 16 * l.
+// still counts lgkmcnt for them. lds_addr must be wave-uniform: lane l's 16 bytes land at lds_addr + 16 * l. M0 is a reserved register
+// (hipcc rejects it on the clobber list); nothing else in these kernels uses it.
 __device__ __forceinline__ void lds_dma16(const void* src, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory", "m0");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_addr) : "memory");
 }
 __device__ __forceinline__ unsigned lds_u32(const char* p) {
   return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
