@@ -268,3 +268,60 @@ class OracleNavBuilders:
 
     def targets(self, a):
         return self.torch.from_numpy(a)
+
+
+class OracleObsBuilders:
+    """The host-side half of Seq2SeqCMTAgent.rollout as the reference does it (VLN-HAMT/finetune_src/r2r/agent_cmt.py): numpy loops
+    over observations whose 'feature' rows are [image 768 | angle 4] (env.py:290-335), behind the interface
+    vln_imagine_amd/hamt/rollout.py drives (CPU torch tensors out)."""
+
+    def __init__(self, feats, keys, imag_feats, imag_flags):
+        import torch
+        self.torch, self.feats = torch, {k: np.asarray(f, np.float32) for k, f in zip(keys, feats)}
+        self.imag_feats, self.imag_flags = imag_feats, imag_flags
+
+    def _full(self, ob):
+        """ob['feature'] and the candidates' features as the environment would hand them over."""
+        f = np.concatenate([self.feats[ob["key"]], _view_angles(ob["viewIndex"])], 1)
+        cands = [np.concatenate([self.feats[ob["key"]][c["pointId"]],
+                                 np.array([math.sin(c["heading"]), math.cos(c["heading"]), math.sin(c["elevation"]), math.cos(c["elevation"])], np.float32)])
+                 for c in ob["candidate"]]
+        return f, cands
+
+    def observation(self, obs, views=36, D=768):
+        """_cand_pano_feature_variable, agent_cmt.py:130-176."""
+        torch = self.torch
+        img, ang, nav, lens, cand_lens = [], [], [], [], []
+        for ob in obs:
+            f, cands = self._full(ob)
+            ci, ca, nt, used = [], [], [], set()
+            for c, cf in zip(ob["candidate"], cands):
+                ci.append(cf[:D]); ca.append(cf[D:]); nt.append(1); used.add(c["pointId"])
+            ci.append(np.zeros((D,), np.float32)); ca.append(np.zeros((4,), np.float32)); nt.append(2)          # [STOP]
+            rest = [k for k in range(views) if k not in used]
+            ci += [f[k, :D] for k in rest]; ca += [f[k, D:] for k in rest]; nt += [0] * len(rest)
+            img.append(np.stack(ci)); ang.append(np.stack(ca)); nav.append(nt)
+            lens.append(len(nt)); cand_lens.append(len(ob["candidate"]) + 1)
+        V = max(lens)
+        pad = lambda a: np.concatenate([a, np.zeros((V - a.shape[0],) + a.shape[1:], a.dtype)], 0)
+        return (torch.from_numpy(np.stack([pad(a) for a in img])), torch.from_numpy(np.stack([pad(a) for a in ang])),
+                torch.from_numpy(np.stack([pad(np.array(n, np.int64)) for n in nav])), lens, cand_lens)
+
+    def history(self, obs, next_ids, D=768):
+        """_history_variable + prev_act_angle, agent_cmt.py:198-215,589-594."""
+        torch = self.torch
+        B = len(obs)
+        hi, hp, ha, pa = np.zeros((B, D), np.float32), np.zeros((B, 36, D), np.float32), np.zeros((B, 36, 4), np.float32), np.zeros((B, 4), np.float32)
+        for b, ob in enumerate(obs):
+            f, cands = self._full(ob)
+            hi[b], hp[b], ha[b] = f[ob["viewIndex"], :D], f[:, :D], f[:, D:]
+            if next_ids[b] != -1:
+                pa[b] = cands[next_ids[b]][-4:]
+        return tuple(torch.from_numpy(a) for a in (hi, hp, ha, pa))
+
+    def imaginations(self, instr_ids):
+        f, m = imaginations_v2(instr_ids, self.imag_flags, self.imag_feats)
+        return self.torch.from_numpy(f), self.torch.from_numpy(m)
+
+    def targets(self, a):
+        return self.torch.from_numpy(a)

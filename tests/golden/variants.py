@@ -67,3 +67,21 @@ def rollout_setup():
     feats = synth.det_uniform("roll0/views", (n, 36, 768), -0.5, 0.5)
     keys = [f"scan_vp{v:03d}" for v in range(n)]
     return w, feats, keys, synth.DuetEpisode(**ROLLOUT["text"])
+
+# end-to-end HAMT rollout (make_golden_hamt_rollout.py)
+HAMT_ROLLOUT = dict(walk=dict(tag="hroll0", B=4, T=5, n=40, k=4, revisit=False), stop_early={2: 3}, text=dict(tag="hroll0", B=4, L=80, V=37, I=4, T=1))
+
+
+def hamt_rollout_setup():
+    """(walk, view features, keys, text episode, imagination features dict, flags dict) - closed form."""
+    from vln_imagine_amd import synth
+    w = synth.GraphWalk(**HAMT_ROLLOUT["walk"])
+    for b, n in HAMT_ROLLOUT["stop_early"].items():
+        w.length[b] = min(w.length[b], n)
+    n = HAMT_ROLLOUT["walk"]["n"]
+    feats = synth.det_uniform("hroll0/views", (n, 36, 768), -0.5, 0.5)
+    keys = [f"scan_vp{v:03d}" for v in range(n)]
+    ep = synth.HamtEpisode(**HAMT_ROLLOUT["text"])
+    flags = {f"hroll0_{b}": ep.sub_instr_imag_flag[b] for b in range(ep.B)}
+    imag = {f"hroll0_{b}": ep.imagine_feats[b][ep.imagine_masks[b]] for b in range(ep.B) if ep.imagine_masks[b].any()}
+    return w, feats, keys, ep, imag, flags

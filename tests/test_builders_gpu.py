@@ -120,3 +120,35 @@ def test_hamt_candidate_and_history_builders_match_reference_loops():
     assert np.array_equal(g_hi.cpu().numpy(), hi) and np.array_equal(g_hp.cpu().numpy(), hp)
     assert np.abs(g_ha.cpu().numpy() - ha).max() < 2e-6 and np.abs(g_pa.cpu().numpy() - pa).max() < 2e-6
     assert not g_pa[0].any()
+
+
+def test_hamt_rollout_with_device_builders_matches_reference_golden(golden_dir):
+    """End to end on the GPU: HIP NavCMT (fp32) + resident view features + resident imagination table through hamt/rollout.py against
+    the reference NavCMT driven by the reference-style host loops (tests/golden/hamt_rollout.npz): logits, losses, gradient norms."""
+    import os
+    from tests.golden.variants import HAMT_C1, hamt_rollout_setup
+    from tests.test_hamt_gpu import _close, build_product
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.builders import ResidentFeatures
+    from vln_imagine_amd.hamt.config import HamtConfig
+    from vln_imagine_amd.hamt.rollout import DeviceObsBuilders, rollout
+    g = np.load(os.path.join(golden_dir, "hamt_rollout.npz"))
+    walk, feats, keys, ep, imag, flags = hamt_rollout_setup()
+    model = build_product(HamtConfig(**HAMT_C1))
+    t = lambda a: torch.from_numpy(a).cuda()
+    out = rollout(model, walk, DeviceObsBuilders(ResidentFeatures(feats, keys), imag, flags), t(ep.txt_ids), t(ep.txt_masks),
+                  annotations=(ep.sub_instr_segs, ep.sub_instr_imag_flag, ep.noun_phrase_segs), criterion=ops.cross_entropy_sum)
+    out["loss"].backward()
+    assert len(out["logits"]) == int(g["steps"]) and np.array_equal(out["hist_lens"], g["hist_lens"])
+    _close(out["loss"].item(), g["loss"], 1e-4, "loss")
+    _close(out["aux"].item(), g["aux"], 1e-4, "aux")
+    for i, f in enumerate(out["logits"]):
+        assert np.array_equal(out["targets"][i], g[f"target{i}"])
+        _close(f.detach().float().cpu().numpy(), g[f"logits{i}"], 1e-4, f"logits{i}")
+    params = dict(model.named_parameters())
+    for n, ref in zip(g["grad_names"].tolist(), g["grad_norms"]):
+        if ref < 0:
+            assert params[n].grad is None or float(params[n].grad.abs().max()) == 0.0, n
+        else:
+            nrm = float(params[n].grad.double().norm())
+            assert abs(nrm - ref) <= max(2e-4 * ref, 2e-5), (n, nrm, ref)

@@ -99,3 +99,30 @@ def test_rollout_oracle_matches_reference_golden(golden_dir):
         assert ["|".join("" if k is None else k for k in row) for row in out["gmap_vpids"][i]] == g[f"vpids{i}"].tolist()
         _close(f.detach(), g[f"fused{i}"], what=f"fused{i}")
     assert (g["target1"] >= 0).all() and (g[f"target{int(g['steps']) - 1}"] == -100).any()      # an agent that stopped early is ignored later
+
+
+def test_hamt_rollout_oracle_matches_reference_golden(golden_dir):
+    """Whole HAMT chain on CPU: oracle model + oracle builders through hamt/rollout.py == reference NavCMT (tests/golden/hamt_rollout.npz)."""
+    import torch
+    from oracle.hamt_oracle import HamtOracle
+    from tests.golden.variants import HAMT_C1, hamt_rollout_setup
+    from tests.test_oracle_hamt import _close
+    from vln_imagine_amd.hamt.config import HamtConfig
+    from vln_imagine_amd.hamt.rollout import rollout
+    from vln_imagine_amd.hamt.spec import param_shapes
+    g = np.load(os.path.join(golden_dir, "hamt_rollout.npz"))
+    walk, feats, keys, ep, imag, flags = hamt_rollout_setup()
+    cfg = HamtConfig(**HAMT_C1)
+    sd = {k: torch.from_numpy(v).requires_grad_() for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()}
+    torch.set_num_threads(8)
+    t = torch.from_numpy
+    out = rollout(HamtOracle(cfg, sd), walk, GO.OracleObsBuilders(feats, keys, imag, flags), t(ep.txt_ids), t(ep.txt_masks),
+                  annotations=(ep.sub_instr_segs, ep.sub_instr_imag_flag, ep.noun_phrase_segs))
+    assert len(out["logits"]) == int(g["steps"]) and np.array_equal(out["hist_lens"], g["hist_lens"])
+    _close(out["loss"].item(), g["loss"], what="loss")
+    _close(out["aux"].item(), g["aux"], what="aux")
+    for i, f in enumerate(out["logits"]):
+        assert np.array_equal(out["targets"][i], g[f"target{i}"])
+        _close(f.detach(), g[f"logits{i}"], what=f"logits{i}")
+    last = g[f"target{int(g['steps']) - 1}"]
+    assert (last == -100).any() and (g["target1"] == 0).any()                     # ended agents ignored; first candidates taken
