@@ -297,7 +297,7 @@ def main():
             for f, e0, e1, shp in rec:
                 a_ = agg.setdefault(shp, [0, 0.0, 0.0])
                 a_[0] += 1; a_[1] += e0.elapsed_time(e1); a_[2] += f
-            for shp, (n, ms_, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:24]:
+            for shp, (n, ms_, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
                 log(f"gemm M={shp[0]:6d} N={shp[1]:5d} K={shp[2]:5d}: {n:4d} calls {ms_:7.2f} ms {f / ms_ / 1e9:7.1f} TF/s")
         ach = tot_f / (tot_ms * 1e-3) / 1e12
         traffic = None
