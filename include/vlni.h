@@ -91,6 +91,10 @@ int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, long ldk, c
                   const float* kmask, const float* bias, const void* out, long ldo, const void* dout, long lddo,
                   const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* dbias, int B,
                   int nh, int Sq, int Sk, float scale, float drop_p, unsigned drop_seed, void* stream);
+/* softmax(q k^T * scale + kmask + bias) MATERIALISED as float32 [B][nh][Sq][Sk] (Sk <= 512) - only for the visualisation outputs of
+   NavCMT.forward(..., return_cross_attention_probs=True) (reference vilmodel_cmt.py:391,393,438,439); same q / k layout as above */
+int vlni_attn_probs(int dtype, const void* q, long ldq, const void* k, long ldk, const float* kmask, const float* bias, float* probs,
+                    int B, int nh, int Sq, int Sk, float scale, void* stream);
 
 /* LayerNorm over the last dim H in {256,512,768} (BertLayerNorm R:22; eps 1e-12, T:170-182 eps 1e-5).
  * bwd accumulates (+=) into dgamma/dbeta (float32; both NULL to skip). */

@@ -46,6 +46,15 @@ def mha(sd, p, q_in, kv_in, add_mask, nh=12):       # R:100-134 / R:326-353
     return (pr @ v).transpose(1, 2).reshape(B, Sq, H)
 
 
+def att_probs(sd, p, q_in, kv_in, add_mask, nh=12):  # softmax of the raw scores an attention returns (R:118-124 with output_attentions)
+    B, Sq, H = q_in.shape
+    Sk = kv_in.shape[1]
+    dh = H // nh
+    q = _lin(sd, p + ".query", q_in).view(B, Sq, nh, dh).transpose(1, 2)
+    k = _lin(sd, p + ".key", kv_in).view(B, Sk, nh, dh).transpose(1, 2)
+    return torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(dh) + add_mask, -1)
+
+
 def self_output(sd, p, h, resid):                   # R:144-148 / R:186-190
     return _ln(sd, p + ".LayerNorm", _lin(sd, p + ".dense", h) + resid)
 
@@ -76,6 +85,16 @@ def lxrt_layer(sd, p, lang, lang_mask, visn, visn_mask):   # R:423-445
     l3 = ffn(sd, p + ".lang_inter", p + ".lang_output", l2)            # R:409-421
     v3 = ffn(sd, p + ".visn_inter", p + ".visn_output", v2)
     return l3, v3
+
+
+def lxrt_layer_probs(sd, p, lang, lang_mask, visn, visn_mask):
+    """The four visualisation maps of a layer (R:391,393,438,439): cross-attention pair on its inputs, self-attention pair on the
+    cross-attention outputs."""
+    xa = p + ".visual_attention"
+    l1 = x_attention(sd, xa, lang, visn, visn_mask)
+    v1 = x_attention(sd, xa, visn, lang, lang_mask)
+    return (att_probs(sd, xa + ".att", lang, visn, visn_mask), att_probs(sd, xa + ".att", visn, lang, lang_mask),
+            att_probs(sd, p + ".lang_self_att.self", l1, l1, lang_mask), att_probs(sd, p + ".visn_self_att.self", v1, v1, visn_mask))
 
 
 class HamtOracle:
@@ -228,7 +247,11 @@ class HamtOracle:
                 visn, vm = torch.cat([visn, img], 1), torch.cat([vm, im], -1)
             else:                                    # R:1109-1112
                 lang, lm = torch.cat([lang, img], 1), torch.cat([lm, im], -1)
+        cross_probs, self_probs = [], []
         for i in range(cfg.num_x_layers):
+            if kw.get("return_cross_attention_probs"):   # R:1128-1153
+                lq, vq, ls, vs = lxrt_layer_probs(sd, f"encoder.x_layers.{i}", lang, lm, visn, vm)
+                cross_probs.append((lq, vq)); self_probs.append((ls, vs))
             lang, visn = lxrt_layer(sd, f"encoder.x_layers.{i}", lang, lm, visn, vm)
         hist_o, ob_o, txt_o = visn[:, :nh], visn[:, nh:nh + no], lang[:, :nt]
         if cfg.imagine_enc_pano:
@@ -247,4 +270,6 @@ class HamtOracle:
         h = _ln(sd, "next_action.net.2", F.relu(_lin(sd, "next_action.net.0", f)))   # R:956-960
         logits = _lin(sd, "next_action.net.4", h).squeeze(-1)
         logits = logits.masked_fill(kw["ob_nav_types"] == 0, -float("inf"))           # R:1200
+        if kw.get("return_cross_attention_probs"):
+            return logits, txt_o, hist_o, ob_o, cross_probs, self_probs
         return logits, txt_o, hist_o, ob_o

@@ -85,3 +85,22 @@ def hamt_rollout_setup():
     flags = {f"hroll0_{b}": ep.sub_instr_imag_flag[b] for b in range(ep.B)}
     imag = {f"hroll0_{b}": ep.imagine_feats[b][ep.imagine_masks[b]] for b in range(ep.B) if ep.imagine_masks[b].any()}
     return w, feats, keys, ep, imag, flags
+
+
+# ---- visualisation outputs (make_golden_hamt_probs.py) ----
+def visual_step0(model, et):
+    """The calls of an episode up to the first `visual`, with the probabilities switched on."""
+    txt = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
+    img = model("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None)
+    hist = model("history").expand(et.B, -1).unsqueeze(1)
+    s = et.steps[0]
+    return model("visual", txt_embeds=txt, txt_masks=et.txt_masks, hist_embeds=hist, hist_masks=et.hist_masks[0],
+                 ob_img_feats=s["ob_img_feats"], ob_ang_feats=s["ob_ang_feats"], ob_nav_types=s["ob_nav_types"], ob_masks=s["ob_masks"],
+                 imagine_embeds=img, imagine_masks=et.imagine_masks, return_cross_attention_probs=True)
+
+
+def probs_sample(p):
+    p = p.detach().float().cpu().numpy()
+    return p[::2, ::5, ::7, ::3].copy()
+
+

@@ -241,3 +241,24 @@ def test_graphed_step_replays_the_eager_step(family):
         ops.set_seed_base(None)
         ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
         ops._WQ.clear()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_probabilities_for_visualisation(dtype, golden_dir):
+    """`return_cross_attention_probs=True` (NavCMT and the VLNBertCMT tuple layout): per layer the cross-attention pair and the
+    self-attention pair as probabilities, against the reference's own maps (1e-4 in fp32)."""
+    from tests.golden.variants import probs_sample as sample, visual_step0
+    g = np.load(os.path.join(golden_dir, "hamt_attention_probs.npz"))
+    cfg, ep = hamt_variant_setup("c1_shipped")
+    model = build_product(cfg, dtype)
+    with torch.no_grad():
+        out = visual_step0(model, EpisodeTensors(ep, "cuda"))
+        plain = visual_step0(lambda mode, **kw: model(mode, **{k: v for k, v in kw.items() if k != "return_cross_attention_probs"}),
+                             EpisodeTensors(ep, "cuda"))
+    assert len(out) == 6 and len(plain) == 4 and torch.equal(out[0], plain[0])            # asking for the maps changes nothing else
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    for l, ((lq, vq), (ls, vs)) in enumerate(zip(out[4], out[5])):
+        for name, p in (("lq", lq), ("vq", vq), ("ls", ls), ("vs", vs)):
+            assert list(p.shape) == g[f"{name}{l}.shape"].tolist() and p.dtype == torch.float32
+            assert (p.sum(-1) - 1).abs().max().item() < 1e-5
+            assert np.abs(sample(p) - g[f"{name}{l}.sample"]).max() <= tol, (name, l)

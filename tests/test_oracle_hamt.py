@@ -58,3 +58,19 @@ def test_oracle_matches_reference_golden(name, golden_dir):
         assert abs(float(gr.double().norm()) - ref_norm) <= 1e-4 * max(ref_norm, 1e-3), (n, float(gr.double().norm()), ref_norm)
         head = gr.reshape(-1)[:8].numpy()
         _close(head, g["grad_heads"][i][:head.size], tol=1e-4, what=f"grad {n}")
+
+
+def test_oracle_attention_probabilities_match_reference(golden_dir):
+    """`return_cross_attention_probs=True`: the four per-layer maps of the reference (tests/golden/hamt_attention_probs.npz)."""
+    from tests.golden.variants import probs_sample as sample, visual_step0
+    g = np.load(os.path.join(golden_dir, "hamt_attention_probs.npz"))
+    cfg, ep = hamt_variant_setup("c1_shipped")
+    sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()}
+    with torch.no_grad():
+        out = visual_step0(HamtOracle(cfg, sd), EpisodeTensors(ep))
+    assert len(out) == 6 and len(out[4]) == len(out[5]) == int(g["layers"])
+    _close(out[0], g["logits"], what="logits")
+    for l, ((lq, vq), (ls, vs)) in enumerate(zip(out[4], out[5])):
+        for name, p in (("lq", lq), ("vq", vq), ("ls", ls), ("vs", vs)):
+            assert list(p.shape) == g[f"{name}{l}.shape"].tolist()
+            _close(sample(p), g[f"{name}{l}.sample"], what=f"{name}{l}")

@@ -68,6 +68,12 @@ def test_hamt_wrapper_dispatch_masks_states_and_dropout():
     w.args.no_lang_ca = True
     assert torch.equal(w("visual", hist_embeds=hist, hist_lens=hist_lens, return_states=True, **kw)[1], hist_o[:, 0])
     w.args.no_lang_ca = False
+    # visualisation variant of the tuple (model_HAMT.py:80-95): (logits, [states,] cross_attn_probs, self_attn_probs)
+    viz = w("visual", hist_embeds=hist, hist_lens=hist_lens, return_cross_attention_probs=True, **kw)
+    assert len(viz) == 3 and torch.equal(viz[0], logits) and len(viz[1]) == len(viz[2]) == 1
+    assert viz[1][0][0].shape == (B, 12, L + I, 2 + V) and viz[2][0][1].shape == (B, 12, 2 + V, 2 + V)
+    viz = w("visual", hist_embeds=hist, hist_lens=hist_lens, return_states=True, return_cross_attention_probs=True, **kw)
+    assert len(viz) == 4 and torch.equal(viz[1], states)
     with pytest.raises(NotImplementedError):
         w("panorama")
     # train mode: the wrapper's feature dropout (p = feat_dropout) hits the caller's FEATURES, nothing else

@@ -26,6 +26,7 @@ SIGNATURES = {
     "vlni_gemm_tn_bf16_grouped_part": [I, P, P, P, L, L, P, L, I, I, P, I, I, P],
     "vlni_reduce_parts": [P, I, I, P],
     "vlni_attn_fwd": [I, P, L, P, L, P, L, P, P, P, L, P, I, I, I, I, F, F, U, P],
+    "vlni_attn_probs": [I, P, L, P, L, P, P, P, I, I, I, I, F, P],
     "vlni_attn_bwd": [I, P, L, P, L, P, L, P, P, P, L, P, L, P, P, L, P, L, P, L, P, I, I, I, I, F, F, U, P],
     "vlni_layernorm_fwd": [I, P, L, P, P, F, P, L, P, P, I, I, P],
     "vlni_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, P, I, I, P, L, P, L, F, U, P],

@@ -739,3 +739,65 @@ extern "C" int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, 
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Attention PROBABILITIES materialised for visualisation (NavCMT.forward(..., return_cross_attention_probs=True): the reference's
+// LXRTXLayer returns softmax(raw scores) of its four attentions, vilmodel_cmt.py:391,393,438,439). Never on the training path (the
+// fused kernels above keep the scores on chip); one wave per (batch, head, query row), keys strided over the lanes.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(64) void attn_probs_kernel(const T* __restrict__ q, long ldq, const T* __restrict__ k, long ldk,
+                                                        const float* __restrict__ kmask, const float* __restrict__ bias,
+                                                        float* __restrict__ P, int nh, int Sq, int Sk, float scale) {
+  __shared__ float qs[64];
+  const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z, lane = threadIdx.x;
+  qs[lane] = DT<T>::ld(q + ((long)b * Sq + i) * ldq + h * 64 + lane);
+  __syncthreads();
+  float sc[8];                                              // Sk <= 512
+  float mx = -INFINITY;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int j = lane + 64 * u;
+    sc[u] = -INFINITY;
+    if (j < Sk) {
+      const T* kr = k + ((long)b * Sk + j) * ldk + h * 64;
+      float a = 0.f;
+      for (int d = 0; d < 64; d += 4) {
+        const f32x4 kv = DT<T>::ld4(kr + d);
+        a += qs[d] * kv[0] + qs[d + 1] * kv[1] + qs[d + 2] * kv[2] + qs[d + 3] * kv[3];
+      }
+      a = a * scale + (kmask ? kmask[(long)b * Sk + j] : 0.f) + (bias ? bias[((long)b * Sq + i) * Sk + j] : 0.f);
+      sc[u] = a;
+      mx = fmaxf(mx, a);
+    }
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    if (lane + 64 * u < Sk) { sc[u] = expf(sc[u] - mx); sum += sc[u]; }
+  }
+  sum = wave_sum(sum);
+  float* o = P + (((long)b * nh + h) * Sq + i) * Sk;
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    if (lane + 64 * u < Sk) o[lane + 64 * u] = sc[u] / sum;
+}
+}  // namespace
+
+extern "C" int vlni_attn_probs(int dtype, const void* q, long ldq, const void* k, long ldk, const float* kmask, const float* bias,
+                               float* probs, int B, int nh, int Sq, int Sk, float scale, void* stream) {
+  VLNI_CHECK(q && k && probs && B > 0 && nh > 0 && Sq > 0 && Sk > 0 && Sk <= 512, VLNI_EINVAL, "attn_probs: B=%d nh=%d Sq=%d Sk=%d (Sk <= 512)",
+             B, nh, Sq, Sk);
+  VLNI_CHECK(ldq >= nh * 64 && ldk >= nh * 64 && ldk % 4 == 0 && ((uintptr_t)k & 15) == 0, VLNI_EINVAL, "attn_probs: strides / alignment");
+  VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "attn_probs: dtype %d", dtype);
+  dim3 grid(Sq, nh, B);
+  if (dtype == VLNI_F32)
+    hipLaunchKernelGGL((attn_probs_kernel<float>), grid, dim3(64), 0, (hipStream_t)stream, (const float*)q, ldq, (const float*)k, ldk, kmask,
+                       bias, probs, nh, Sq, Sk, scale);
+  else
+    hipLaunchKernelGGL((attn_probs_kernel<__bf16>), grid, dim3(64), 0, (hipStream_t)stream, (const __bf16*)q, ldq, (const __bf16*)k, ldk,
+                       kmask, bias, probs, nh, Sq, Sk, scale);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}

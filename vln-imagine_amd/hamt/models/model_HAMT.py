@@ -49,15 +49,17 @@ class VLNBertCMT(nn.Module):
         if mode == "visual":
             hist = torch.stack(hist_embeds, 1)
             hist_masks = length2mask(hist_lens, size=hist.size(1), device=hist.device).logical_not()
-            act_logits, txt_o, hist_o, ob_o = m(
+            outs = m(
                 mode, txt_embeds=txt_embeds, txt_masks=txt_masks, hist_embeds=hist, hist_masks=hist_masks,
                 ob_img_feats=self.drop_env(ob_img_feats), ob_ang_feats=ob_ang_feats, ob_nav_types=ob_nav_types,
                 ob_masks=ob_masks, imagine_embeds=imagine_embeds, imagine_masks=imagine_masks,
                 return_cross_attention_probs=return_cross_attention_probs)
+            act_logits, txt_o, hist_o, ob_o = outs[:4]
+            extra = tuple(outs[4:])                      # (cross_attn_probs, self_attn_probs) per layer when asked for (:80-95)
             if return_states:
                 states = hist_o[:, 0] if self.args.no_lang_ca else txt_o[:, 0] * hist_o[:, 0]
-                return act_logits, states
-            return (act_logits,)
+                return (act_logits, states) + extra
+            return (act_logits,) + extra
         raise NotImplementedError("wrong mode: %s" % mode)
 
 

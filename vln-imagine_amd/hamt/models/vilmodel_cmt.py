@@ -128,7 +128,7 @@ class BertEncoder(nn.Module):
 class LXRTXLayer(nn.Module):
     """Cross-modal layer (reference vilmodel_cmt.py:366-445): bidirectional cross-attention with shared
     weights on pre-update inputs, then per-stream self-attention and FFN: 5 fused nodes instead of ~45 kernels.
-    The four visualisation softmaxes of the reference (:391,393,438,439) are not computed."""
+    The four visualisation softmaxes of the reference (:391,393,438,439) are only computed on request (`attention_probs`)."""
 
     def __init__(self, c):
         super().__init__()
@@ -140,6 +140,28 @@ class LXRTXLayer(nn.Module):
         self.visn_inter = BertIntermediate(c)
         self.visn_output = BertOutput(c)
         self.visual_attention = BertXAttention(c)
+
+    @staticmethod
+    def _probs(att, xq, xk, kmask):
+        """softmax(Q K^T / 8 + mask) of one attention, [B, heads, Sq, Sk] float32 (the reference's `nn.Softmax(dim=-1)(raw scores)`)."""
+        wq, bq, wk, bk = _att(att)[:4]
+        B, Sq, H = xq.shape
+        Sk = xk.shape[1]
+        q = ops.linear(xq.reshape(B * Sq, H), wq, bq)
+        k = ops.linear(xk.reshape(B * Sk, H), wk, bk)
+        return ops.attn_probs(q, k, B, Sq, Sk, kmask=kmask, nh=H // 64)
+
+    @torch.no_grad()
+    def attention_probs(self, lang, lang_mask, visn, visn_mask):
+        """(lang_query_probs, visual_query_probs, lang_self_attn_probs, visual_self_attn_probs) of this layer for its INPUTS
+        (reference LXRTXLayer.forward, vilmodel_cmt.py:423-445): the cross-attention pair on the pre-update streams with the shared
+        weights, the self-attention pair on the cross-attention outputs. Visualisation only: separate Q / K projections + one small
+        kernel per map, outside the fused training path."""
+        xa = self.visual_attention
+        lq = self._probs(xa, lang, visn, visn_mask)
+        vq = self._probs(xa, visn, lang, lang_mask)
+        lang2, visn2 = ops.xatt_pair_block(lang, visn, lang_mask, visn_mask, _att(xa), drop=_drop(xa))
+        return lq, vq, self._probs(self.lang_self_att, lang2, lang2, lang_mask), self._probs(self.visn_self_att, visn2, visn2, visn_mask)
 
     def forward(self, lang, lang_mask, visn, visn_mask):
         xa = self.visual_attention
@@ -517,8 +539,9 @@ class NavCMT(nn.Module):
 
         if mode != "visual":
             raise NotImplementedError("wrong mode: %s" % mode)
-        if return_cross_attention_probs:
-            raise NotImplementedError("attention maps never leave the fused kernels; visualisation is out of scope")
+        if return_cross_attention_probs and c.no_lang_ca:
+            raise NotImplementedError("return_cross_attention_probs with no_lang_ca (the reference's own comment: 'this might break')")
+        cross_probs, self_probs = [], []
         hm, om, tm = ops.additive_mask(hist_masks), ops.additive_mask(ob_masks), ops.additive_mask(txt_masks)
         hist = hist_embeds.to(dt)
         if self.encoder.h_layers is not None:
@@ -549,6 +572,10 @@ class NavCMT(nn.Module):
         for i, xl in enumerate(self.encoder.x_layers):
             if txt_list is not None:       # no_lang_ca: per-layer precomputed text states (:1138-1145)
                 lang = txt_list[i].to(dt) if img_side != "language" else lang
+            if return_cross_attention_probs:            # visualisation outputs (:1128-1153): probabilities of the layer's four attentions
+                lq, vq, ls, vs = xl.attention_probs(lang, lm, visn, vm)
+                cross_probs.append((lq, vq))
+                self_probs.append((ls, vs))
             lang, visn = xl(lang, lm, visn, vm)
         hist_o, ob_o = visn[:, :nh], visn[:, nh:nh + no]
         txt_o = lang[:, :nt]
@@ -571,4 +598,6 @@ class NavCMT(nn.Module):
         else:
             raise ValueError(f"act_pred_token {tok!r}")
         act_logits = self.next_action(f.contiguous(), ob_nav_types == 0)
+        if return_cross_attention_probs:
+            return act_logits, txt_o, hist_o, ob_o, cross_probs, self_probs
         return act_logits, txt_o, hist_o, ob_o

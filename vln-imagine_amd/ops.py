@@ -290,6 +290,14 @@ def attn_fwd(q, k, v, B, Sq, Sk, kmask=None, bias=None, nh=12, drop=None):
     return out, lse
 
 
+def attn_probs(q, k, B, Sq, Sk, kmask=None, bias=None, nh=12):
+    """softmax(q k^T / 8 + kmask (+ bias)) as float32 [B, nh, Sq, Sk] - visualisation only (vlni_attn_probs)."""
+    P = torch.empty((B, nh, Sq, Sk), dtype=torch.float32, device=q.device)
+    _lib.call("vlni_attn_probs", _dt(q), q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), _p(kmask), _p(bias), P.data_ptr(),
+              B, nh, Sq, Sk, 1.0 / 8.0, _st())
+    return P
+
+
 def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, Sq, Sk, kmask=None, bias=None, dbias=None, nh=12, drop=None):
     _lib.call("vlni_attn_bwd", _dt(q), q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
               _p(kmask), _p(bias), out.data_ptr(), out.stride(0), dout.data_ptr(), dout.stride(0), lse.data_ptr(),
