@@ -126,3 +126,21 @@ def test_hamt_rollout_oracle_matches_reference_golden(golden_dir):
         _close(f.detach(), g[f"logits{i}"], what=f"logits{i}")
     last = g[f"target{int(g['steps']) - 1}"]
     assert (last == -100).any() and (g["target1"] == 0).any()                     # ended agents ignored; first candidates taken
+
+
+def test_host_graphmap_module_matches_reference_golden():
+    """`models.graph_utils.GraphMap` as shipped in the DUET package (host-side drop-in): same numbers as the reference's."""
+    from vln_imagine_amd.duet.models.graph_utils import GraphMap
+    g = np.load(GOLD)
+    w = synth.GraphWalk(**WALK)
+    maps = [GraphMap(ob["viewpoint"]) for ob in w.steps[0]]
+    for t, obs in enumerate(w.steps):
+        for b, (ob, m) in enumerate(zip(obs, maps)):
+            m.update_graph(ob)
+            names = list(m.node_positions.keys())
+            assert names == [str(x) for x in g[f"names_{t}_{b}"]]
+            assert np.array_equal(np.array([[m.graph.distance(x, y) for y in names] for x in names]), g[f"dist_{t}_{b}"])
+            assert [len(m.graph.path(ob["viewpoint"], y)) for y in names] == g[f"hops_{t}_{b}"].tolist()
+            assert [m.graph.visited(k) for k in names] == g[f"visited_{t}_{b}"].tolist()
+            f = m.get_pos_fts(ob["viewpoint"], [None] + names, ob["heading"], ob["elevation"])
+            assert np.abs(f - g[f"pos_fts_{t}_{b}"]).max() <= 1e-6 and np.array_equal(f[:, 4:], g[f"pos_fts_{t}_{b}"][:, 4:])

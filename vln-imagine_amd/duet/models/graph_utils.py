@@ -19,8 +19,9 @@ def calc_position_distance(a, b):
 def calculate_vp_rel_pos_fts(a, b, base_heading=0, base_elevation=0):
     """heading / elevation / distance of b seen from a (the simulator's x-y axes are transposed)."""
     dx, dy, dz = b[0] - a[0], b[1] - a[1], b[2] - a[2]
-    xy = max(math.hypot(dx, dy), 1e-8)
-    xyz = max(math.sqrt(dx * dx + dy * dy + dz * dz), 1e-8)
+    # `**` on python floats is libm pow (1 ulp off x * x now and then): kept so that the features equal the reference's bit for bit
+    xy = max(math.sqrt(dx ** 2 + dy ** 2), 1e-8)
+    xyz = max(math.sqrt(dx ** 2 + dy ** 2 + dz ** 2), 1e-8)
     heading = math.asin(dx / xy)
     if b[1] < a[1]:
         heading = math.pi - heading
