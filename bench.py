@@ -255,8 +255,17 @@ def main():
     if not args.no_roofline:           # EVERY rank runs the instrumented step (it contains the gradient all-reduce)
         # instrumented pass: HIP events (torch.cuda.Event on the launch stream = torch's current stream) around
         # every vlni_gemm_nt launch of ONE more step; not part of the timed region above.
-        rec = []
+        rec, epi = [], [0.0]
         orig = ops.gemm_nt
+
+        def _epi_bytes(k):              # tensors the fused epilogue reads / writes besides C: residual, GELU' source, pre-activation
+            n = 0
+            for key in ("residual", "dact_src", "preact"):
+                v = k.get(key)
+                for t_ in (v if isinstance(v, (tuple, list)) else (v,)):
+                    if torch.is_tensor(t_):
+                        n += t_.numel() * t_.element_size()
+            return n
 
         def timed(a, b, *p, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -265,6 +274,7 @@ def main():
             e1.record()
             n_ = b.n if isinstance(b, ops.WT) else b.t.shape[1] if isinstance(b, ops.KN) else b.shape[0]      # WT / KN: dgrad operand handles
             rec.append((2.0 * a.shape[0] * n_ * a.shape[1], e0, e1, (a.shape[0], n_, a.shape[1])))
+            epi[0] += _epi_bytes(k)
             return r
 
         orig2 = ops.gemm_nt2
@@ -277,6 +287,7 @@ def main():
             rows = a[0].shape[0] + a[1].shape[0]
             n_ = b[0].n if isinstance(b[0], ops.WT) else b[0].t.shape[1] if isinstance(b[0], ops.KN) else b[0].shape[0]
             rec.append((2.0 * rows * n_ * a[0].shape[1], e0, e1, (rows, n_, a[0].shape[1])))
+            epi[0] += _epi_bytes(k)
             return r
 
         step = eager_step
@@ -310,6 +321,7 @@ def main():
         roof = {"bound": "mfma", "kernel": "gemm_nt_* / gemm_nn_glds_kernel <%s>" % ("__bf16" if args.dtype == "bf16" else "float"),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": round(sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec) / len(rec)),
+                "algorithmic_bytes_per_launch_with_epilogue": round((sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec) + epi[0]) / len(rec)),
                 "launches_per_step": len(rec), "avg_launch_us": round(tot_ms * 1e3 / len(rec), 2),
                 "avg_gflop_per_launch": round(tot_f / len(rec) / 1e9, 3),
                 "gemm_share_of_step": round(tot_ms / ms, 3),
