@@ -152,3 +152,28 @@ def test_hamt_rollout_with_device_builders_matches_reference_golden(golden_dir):
         else:
             nrm = float(params[n].grad.double().norm())
             assert abs(nrm - ref) <= max(2e-4 * ref, 2e-5), (n, nrm, ref)
+
+
+def test_feature_stores_from_disk_feed_the_resident_tables(tmp_path):
+    """formats.load_view_features / load_imagination_table (.npz stand-ins for the reference's HDF5 stores, same keys) -> the device
+    builders give what the in-memory construction gives."""
+    from oracle import graph_oracle as GO
+    from vln_imagine_amd import formats
+    from vln_imagine_amd.builders import ViewBuilder
+    feats, keys, obs = _fake_env(seed=11)
+    wide = np.concatenate([feats, np.zeros(feats.shape[:2] + (4,), np.float32)], 2)          # stores carry >= D columns
+    np.savez(tmp_path / "views.npz", **{k: wide[i] for i, k in enumerate(keys)})
+    table = formats.load_view_features(str(tmp_path / "views.npz"))
+    assert sorted(table.index) == sorted(keys)
+    img, ang, nav, lens, cl = ViewBuilder(table, A).hamt_observation(obs)
+    from vln_imagine_amd.builders import ResidentFeatures
+    img2, ang2, nav2, lens2, cl2 = ViewBuilder(ResidentFeatures(feats, keys), A).hamt_observation(obs)
+    assert torch.equal(img, img2) and torch.equal(ang, ang2) and torch.equal(nav, nav2) and lens == lens2 and cl == cl2
+    flags = {"7_0": ["True", "False", "True"], "7_1": ["False", "False"], "9_2": ["False", "True"]}
+    rng = np.random.default_rng(3)
+    imag = {"7_0": rng.standard_normal((2, 770)).astype(np.float32), "9_2": rng.standard_normal((1, 770)).astype(np.float32)}
+    np.savez(tmp_path / "imag.npz", **imag)
+    t = formats.load_imagination_table(str(tmp_path / "imag.npz"), flags)
+    f, m = t.batch(["9_2", "7_1", "7_0"])
+    rf, rm = GO.imaginations_v2(["9_2", "7_1", "7_0"], flags, imag)
+    assert np.array_equal(f.cpu().numpy(), rf) and np.array_equal(m.cpu().numpy(), rm)

@@ -219,3 +219,41 @@ def test_graph_map_shortest_paths_and_features():
     e = torch.ones(4, requires_grad=True)
     g.update_node_embed("n7", e * 2); g.update_node_embed("n7", e * 4)
     assert torch.allclose(g.get_node_embed("n7"), torch.full((4,), 3.0)) and g.get_node_embed("n7").requires_grad
+
+
+def test_annotation_and_flag_formats(tmp_path):
+    """The run-time JSON formats of the imagination pipeline (parser.py:155-176, env.py:125-127, agent_cmt.py:436-459)."""
+    import json
+    from vln_imagine_amd import formats
+    flags = [{"path_id": 12, "instruction": 0, "generated_imaginations": ["True", "False", "True"]},
+             {"path_id": 12, "instruction": 1, "generated_imaginations": ["False"]}]
+    annos = [{"instruction_id": "12_0", "instr_segmentation_indices": [[1, 3], [4, 6], [7, 9]], "noun_phrase_indices": [[[1, 2]], [], [[8, 8], [9, 9]]],
+              "instruction": "ignored"},
+             {"instruction_id": "12_1", "instr_segmentation_indices": [[1, 5]], "noun_phrase_indices": [[]]}]
+    fp, ap = tmp_path / "flags.json", tmp_path / "annos.json"
+    fp.write_text(json.dumps(flags)); ap.write_text(json.dumps(annos))
+    assert formats.load_generated_flags(str(fp)) == {"12_0": ["True", "False", "True"], "12_1": ["False"]}
+    idx = formats.AnnotationIndex(str(ap), str(fp))
+    segs, fl, nps = idx.batch(["12_1", "12_0"])
+    assert segs == [[[1, 5]], [[1, 3], [4, 6], [7, 9]]] and fl == [["False"], ["True", "False", "True"]]
+    assert nps == [[[]], [[[1, 2]], [], [[8, 8], [9, 9]]]]
+    bad = [dict(annos[0], instr_segmentation_indices=[[1, 3]]), annos[1]]
+    ap.write_text(json.dumps(bad))
+    with pytest.raises(ValueError):
+        formats.AnnotationIndex(str(ap), str(fp))
+    # feature stores: .npz and directory forms, first feat_size columns, float32
+    rng = np.random.default_rng(0)
+    store = {"scanA_vp1": rng.standard_normal((36, 772)), "scanA_vp2": rng.standard_normal((36, 772))}
+    np.savez(tmp_path / "views.npz", **store)
+    got = dict(formats._iter_store(str(tmp_path / "views.npz"), 768))
+    assert set(got) == set(store) and got["scanA_vp1"].dtype == np.float32 and got["scanA_vp1"].shape == (36, 768)
+    assert np.array_equal(got["scanA_vp2"], store["scanA_vp2"][:, :768].astype(np.float32))
+    d = tmp_path / "dir"
+    d.mkdir()
+    np.save(d / "12_0.npy", rng.standard_normal((2, 768)))
+    assert [k for k, _ in formats._iter_store(str(d), 768)] == ["12_0"]
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="h5py"):
+            list(formats._iter_store(str(tmp_path / "x.hdf5"), 768))
