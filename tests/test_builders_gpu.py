@@ -177,3 +177,37 @@ def test_feature_stores_from_disk_feed_the_resident_tables(tmp_path):
     f, m = t.batch(["9_2", "7_1", "7_0"])
     rf, rm = GO.imaginations_v2(["9_2", "7_1", "7_0"], flags, imag)
     assert np.array_equal(f.cpu().numpy(), rf) and np.array_equal(m.cpu().numpy(), rm)
+
+
+def test_reverie_panorama_builder_matches_reference_loop():
+    """Views + objects (reverie/agent_obj.py:52-107 restated): loc_fts / nav_types interleave each sample's views and objects."""
+    from vln_imagine_amd.builders import ResidentFeatures, ResidentObjects, ViewBuilder, reverie_panorama
+    feats, keys, obs = _fake_env(seed=5, B=5)
+    rng = np.random.RandomState(9)
+    objects = {}
+    for i, k in enumerate(keys):
+        n = [3, 0, 5, 1, 2][i % 5]
+        objects[k] = {"obj_img_fts": rng.uniform(-1, 1, (n, D + 2)).astype(np.float32), "obj_ang_fts": rng.uniform(-1, 1, (n, 4)).astype(np.float32),
+                      "obj_box_fts": rng.uniform(0, 1, (n, 3)).astype(np.float32), "obj_ids": [f"o{i}_{j}" for j in range(n)]}
+    for ob in obs:                                               # what ObjectFeatureDB adds to an observation
+        ob.update({k2: objects[ob["key"]][k2] for k2 in ("obj_img_fts", "obj_ang_fts", "obj_box_fts", "obj_ids")})
+    vi_l, oi_l, loc_l, nav_l = [], [], [], []
+    for ob in obs:
+        vi, va, nt, used = [], [], [], set()
+        for cc in ob["candidate"]:
+            vi.append(cc["feature"][:D]); va.append(cc["feature"][D:]); nt.append(1); used.add(cc["pointId"])
+        vi.extend([x[:D] for k, x in enumerate(ob["feature"]) if k not in used])
+        va.extend([x[D:] for k, x in enumerate(ob["feature"]) if k not in used])
+        nt.extend([0] * (36 - len(used)))
+        vloc = np.concatenate([np.stack(va), np.ones((len(vi), 3), np.float32)], 1)
+        oloc = np.concatenate([ob["obj_ang_fts"], ob["obj_box_fts"]], 1).reshape(-1, 7)
+        nt.extend([2] * len(oloc))
+        vi_l.append(np.stack(vi)); oi_l.append(ob["obj_img_fts"][:, :D].reshape(-1, D)); loc_l.append(np.concatenate([vloc, oloc], 0)); nav_l.append(nt)
+    pad = lambda arrs: np.stack([np.concatenate([a, np.zeros((max(len(x) for x in arrs) - len(a),) + a.shape[1:], np.float32)], 0) for a in arrs])
+    out = reverie_panorama(ViewBuilder(ResidentFeatures(feats, keys), A), ResidentObjects(objects), obs)
+    assert np.array_equal(out["view_img_fts"].cpu().numpy(), pad(vi_l)) and np.array_equal(out["obj_img_fts"].cpu().numpy(), pad(oi_l))
+    assert np.abs(out["loc_fts"].cpu().numpy() - pad(loc_l)).max() < 2e-6
+    L = max(len(n) for n in nav_l)
+    assert np.array_equal(out["nav_types"].cpu().numpy(), np.stack([np.array(n + [0] * (L - len(n))) for n in nav_l]))
+    assert out["view_lens"].tolist() == [len(v) for v in vi_l] and out["obj_lens"].tolist() == [len(o) for o in oi_l]
+    assert out["obj_ids"] == [ob["obj_ids"] for ob in obs]

@@ -185,3 +185,62 @@ class ImaginationTable:
         _lib.call("vlni_gather_rows_or_zero", ops._dt(self.table), self.table.data_ptr(), self.D, rows_t.data_ptr(), out.data_ptr(), B * I,
                   self.D, ops._st())
         return out, rows_t >= 0
+
+
+class ResidentObjects:
+    """REVERIE / SOON object annotations of every viewpoint, resident on the device (the reference's ObjectFeatureDB reads an HDF5
+    file keyed 'scan_viewpoint' per observation, reverie/data_utils.py): per key `n` objects with image features [n, D], angle
+    features [n, 4], box features [n, 3] and ids. Rows of all viewpoints are concatenated; loc = [angle | box | 0] in 8 columns."""
+
+    def __init__(self, objects, feat_size=768, device="cuda", dtype=torch.float32):
+        """objects: {key: {'obj_img_fts': [n, >= D], 'obj_ang_fts': [n, 4], 'obj_box_fts': [n, 3], 'obj_ids': [n]}} (n may be 0)."""
+        self.first, self.count, self.ids, self.D = {}, {}, {}, feat_size
+        img, loc, n = [], [], 0
+        for k, o in objects.items():
+            c = len(o["obj_ids"])
+            self.first[k], self.count[k], self.ids[k] = n, c, list(o["obj_ids"])
+            if c:
+                img.append(np.asarray(o["obj_img_fts"])[:, :feat_size].astype(np.float32))
+                loc.append(np.concatenate([np.asarray(o["obj_ang_fts"], np.float32), np.asarray(o["obj_box_fts"], np.float32),
+                                           np.zeros((c, 1), np.float32)], 1))
+            n += c
+        self.img = torch.from_numpy(np.concatenate(img, 0) if img else np.zeros((1, feat_size), np.float32)).to(device=device, dtype=dtype)
+        self.loc = torch.from_numpy(np.concatenate(loc, 0) if loc else np.zeros((1, 8), np.float32)).to(device)
+
+
+def reverie_panorama(view_builder, objects, obs, views=36):
+    """REVERIE `_panorama_feature_variable` (VLN-DUET/map_nav_src/reverie/agent_obj.py:52-107): the R2R panorama slots + the
+    viewpoint's objects. loc_fts / nav_types hold each sample's views IMMEDIATELY followed by its objects (nav type 2), padded to the
+    longest sum; view_img_fts and obj_img_fts are padded separately."""
+    out = view_builder.duet_panorama(obs, views)
+    dev = out["view_img_fts"].device
+    B = len(obs)
+    vl = out["view_lens"].tolist()
+    ol = [objects.count[ob["key"]] for ob in obs]
+    O = max(max(ol), 1)
+    rows = np.full((B, O), -1, np.int64)
+    for b, ob in enumerate(obs):
+        rows[b, :ol[b]] = objects.first[ob["key"]] + np.arange(ol[b])
+    rows_t = torch.from_numpy(rows).to(dev)
+    obj_img = torch.empty((B, O, objects.D), dtype=torch.float32, device=dev)
+    obj_loc = torch.empty((B, O, 8), dtype=torch.float32, device=dev)
+    st = ops._st()
+    _lib.call("vlni_gather_rows_or_zero", ops._dt(objects.img), objects.img.data_ptr(), objects.D, rows_t.data_ptr(), obj_img.data_ptr(),
+              B * O, objects.D, st)
+    _lib.call("vlni_gather_rows_or_zero", 0, objects.loc.data_ptr(), 8, rows_t.data_ptr(), obj_loc.data_ptr(), B * O, 8, st)
+    # interleave per sample: [views of b | objects of b | padding]
+    V = out["loc_fts"].shape[1]
+    L = max(v + o for v, o in zip(vl, ol))
+    src = np.full((B, L), B * (V + O), np.int64)                  # last row of the pool = zeros
+    nav = np.zeros((B, L), np.int64)
+    nav_v = out["nav_types"].cpu().numpy()
+    for b in range(B):
+        src[b, :vl[b]] = b * (V + O) + np.arange(vl[b])
+        src[b, vl[b]:vl[b] + ol[b]] = b * (V + O) + V + np.arange(ol[b])
+        nav[b, :vl[b]] = nav_v[b, :vl[b]]
+        nav[b, vl[b]:vl[b] + ol[b]] = 2
+    pool = torch.cat([torch.cat([out["loc_fts"], obj_loc[:, :, :7]], 1).reshape(B * (V + O), 7), torch.zeros((1, 7), device=dev)], 0)
+    loc = pool.index_select(0, torch.from_numpy(src.reshape(-1)).to(dev)).view(B, L, 7)
+    out.update(obj_img_fts=obj_img[:, :max(ol)] if max(ol) else obj_img[:, :0], loc_fts=loc, nav_types=torch.from_numpy(nav).to(dev),
+               obj_lens=torch.tensor(ol, device=dev), obj_ids=[objects.ids[ob["key"]] for ob in obs])
+    return out
