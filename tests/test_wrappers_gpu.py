@@ -2,9 +2,7 @@
 masks from lengths, state vector, Critic, checkpoint key remapping (VLN-HAMT/finetune_src/models/model_HAMT.py:13-96,289-300,
 vlnbert_init.py:4-83; VLN-DUET/map_nav_src/models/model.py:12-62)."""
 import argparse
-import sys
 
-import numpy as np
 import pytest
 import torch
 

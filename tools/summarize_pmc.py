@@ -2,7 +2,7 @@
 profiles/<tag>_pmc_traffic.json (HBM bytes per launch of the NT GEMM family, gfx950 FETCH_SIZE correction applied) and
 profiles/<tag>_pmc_sq.md (MFMA utilisation, LDS bank conflicts per kernel family).
 usage: summarize_pmc.py <fetch_dir> <write_dir> <sq_dir> <tag>"""
-import collections, csv, glob, json, os, re, sys
+import collections, csv, glob, json, os, sys
 fetch_dir, write_dir, sq_dir, tag = sys.argv[1:5]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

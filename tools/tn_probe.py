@@ -3,7 +3,7 @@ runs them in; the batched reduction is not included): TF/s vs variant x split fo
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vln_imagine_amd import ops, _lib
+from vln_imagine_amd import _lib
 
 def t(fn, reps=10):
     for _ in range(2): fn()

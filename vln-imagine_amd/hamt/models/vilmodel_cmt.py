@@ -12,7 +12,6 @@ Dropout (train mode): attention-probability and hidden dropout run INSIDE the fu
 mask (regenerated in backward from (seed, element index), never stored); the few dropouts on small tensors
 (embeddings, heads, features) use torch's. eval() / p = 0 is bit-identical to the no-dropout path.
 """
-import copy
 import os
 
 import torch

@@ -11,7 +11,6 @@ sequence with fused epilogues (bias, GELU / GELU', residual) instead of ~40 tiny
 import ctypes
 import os
 import weakref
-import math
 
 import numpy as np
 
