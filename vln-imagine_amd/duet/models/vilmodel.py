@@ -281,7 +281,7 @@ class GlocalTextPathNavCMT(nn.Module):
         c, dt = self.config, self.compute_dtype
         ge, le = self.global_encoder, self.local_encoder
         B, G = gmap_masks.shape
-        gmap = gmap_img_embeds.to(dt) + ge.gmap_step_embeddings.weight[gmap_step_ids].to(dt) \
+        gmap = gmap_img_embeds.to(dt) + ge.gmap_step_embeddings.weight.index_select(0, gmap_step_ids.reshape(-1)).view(*gmap_step_ids.shape, -1).to(dt) \
             + ge.gmap_pos_embeddings.embed(gmap_pos_fts, dt)
         sprels = None
         if ge.sprel_linear is not None:                                                     # reference :1145-1147
