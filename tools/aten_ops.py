@@ -4,14 +4,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 from vln_imagine_amd import ops, synth
-from vln_imagine_amd.hamt.config import HamtConfig
-from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
 from vln_imagine_amd.train import FlatTrainer
-import bench
-cfg = HamtConfig()
-model = bench.make_model(cfg, torch.bfloat16, torch.device("cuda"))
+if "--duet" in sys.argv:
+    from vln_imagine_amd.duet.config import DuetConfig
+    from vln_imagine_amd.duet.episode import DuetEpisodeTensors as EpisodeTensors, run_episode
+    from vln_imagine_amd.duet.models.vilmodel import GlocalTextPathNavCMT
+    from vln_imagine_amd.duet.spec import param_shapes
+    cfg = DuetConfig()
+    model = GlocalTextPathNavCMT(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()})
+    model = model.cuda().train().set_compute_dtype(torch.bfloat16)
+    et = EpisodeTensors(synth.DuetEpisode(tag="hp", B=8, L=80, V=36, I=6, T=6, ragged=False), "cuda")
+else:
+    from vln_imagine_amd.hamt.config import HamtConfig
+    from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+    import bench
+    cfg = HamtConfig()
+    model = bench.make_model(cfg, torch.bfloat16, torch.device("cuda"))
+    et = EpisodeTensors(synth.HamtEpisode(tag="hp", B=8, L=80, V=37, I=6, T=6, ragged=False), "cuda")
 tr = FlatTrainer(model)
-et = EpisodeTensors(synth.HamtEpisode(tag="hp", B=8, L=80, V=37, I=6, T=6, ragged=False), "cuda")
 def step():
     tr.zero_grad()
     out = run_episode(model, et, criterion=ops.cross_entropy_sum, keep=False)
