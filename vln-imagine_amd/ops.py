@@ -595,7 +595,7 @@ _TN_BEST = {}
 
 WGRAD_PARTS = os.environ.get("VLNI_WGRAD_PARTS", "1") == "1"   # row splits write partial gradients with plain stores + ONE batched reduction per
                                                               # step instead of float atomics (~1.3 TB/s on this chip, 30-50 % of a launch)
-_PART_BUFS = {}       # (gradient address, chunk, splits, N, K) -> workspace: [splits][N][K] slabs, then [splits][N] column sums
+_PART_BUFS = {}       # (gradient address, chunk, N, K) -> workspace: [splits][N][K] slabs, then [splits][N] column sums
 _PART_TABLES = {}     # signature of a flush -> (device table, entries, blocks)
 _PART_DT = np.dtype([("dst", "<u8"), ("part", "<u8"), ("n4", "<i8"), ("stride4", "<i8"), ("split", "<i4"), ("blk0", "<i4")])
 
@@ -671,9 +671,9 @@ def flush_wgrads():
             variant, split = _tn_choice(n, pa, pb, pm, N, K, nmt, wv.device)
             if _parts_ok(variant, nmt, split) and wv.is_contiguous() and bv.is_contiguous() and N % 4 == 0:
                 eff = _eff_split(nmt, split)[0]
-                key = (wv.data_ptr(), c, eff, N, K)
+                key = (wv.data_ptr(), c, N, K)                   # one workspace per gradient, grown to the largest split seen
                 buf = _PART_BUFS.get(key)
-                if buf is None:
+                if buf is None or buf.numel() < eff * (N * K + N):
                     buf = _PART_BUFS[key] = torch.empty((eff * (N * K + N),), dtype=torch.float32, device=wv.device)
                 cpart = buf.data_ptr() + 4 * eff * N * K                 # [eff][N] column-sum partials behind the [eff][N][K] slabs
                 _lib.call("vlni_gemm_tn_bf16_grouped_part", n, pa, pb, pm, N, K, buf.data_ptr(), N * K, N, K, cpart, split, variant, _st())
