@@ -104,6 +104,8 @@ class FlatTrainer:
         """Undoes the process-wide switches the constructor flipped (direct gradient accumulation, deferred weight gradients,
         the registered parameter arena, a registered dropout seed base). The parameters keep pointing into the arenas."""
         ops._WQ.clear()
+        ops._PART_BUFS.clear()                 # row-split workspaces and reduction tables of this arena's gradients
+        ops._PART_TABLES.clear()
         ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
         if ops.SHADOWS.arena is not None and ops.SHADOWS.arena[0] is self.flat_p:
             ops.SHADOWS.set_arena(None, None)
