@@ -136,12 +136,17 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const T* __restri
 // out[b][:] = mean_s x[b][s][:]   and its backward dx[b][s][:] = dout[b][:] / S
 template <typename T>
 __global__ __launch_bounds__(256) void seqmean_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int S, int H) {
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < H; c += 256) {
-    float a = 0.f;
-    for (int s = 0; s < S; ++s) a += DT<T>::ld(x + ((long)b * S + s) * H + c);
-    DT<T>::st(out + (long)b * H + c, a / S);
+  const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;      // grid (B, ceil(H / 256)): 3x the blocks of one-per-sample
+  if (c >= H) return;
+  const T* xp = x + (long)b * S * H + c;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int s = 0;
+  for (; s + 3 < S; s += 4) {                                         // four rows in flight (the loop is latency-bound)
+    a0 += DT<T>::ld(xp + (long)s * H); a1 += DT<T>::ld(xp + (long)(s + 1) * H);
+    a2 += DT<T>::ld(xp + (long)(s + 2) * H); a3 += DT<T>::ld(xp + (long)(s + 3) * H);
   }
+  for (; s < S; ++s) a0 += DT<T>::ld(xp + (long)s * H);
+  DT<T>::st(out + (long)b * H + c, ((a0 + a1) + (a2 + a3)) / S);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void seqmean_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int B, int S, int H) {
@@ -552,8 +557,8 @@ extern "C" int vlni_scatter_add_rows(int dtype, const void* src, long lds_, cons
 
 extern "C" int vlni_seqmean_fwd(int dtype, const void* x, void* out, int B, int S, int H, void* stream) {
   VLNI_CHECK(B > 0 && S > 0 && H > 0, VLNI_EINVAL, "seqmean_fwd: %d %d %d", B, S, H);
-  BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_fwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, B, S, H),
-           hipLaunchKernelGGL((seqmean_fwd_kernel<__bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)out, B, S, H));
+  BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_fwd_kernel<float>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, B, S, H),
+           hipLaunchKernelGGL((seqmean_fwd_kernel<__bf16>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)out, B, S, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
