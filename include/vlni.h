@@ -130,6 +130,10 @@ int vlni_smallk_linear_bwd(int dtype, const void* dy, long lddy, const float* x,
 /* table_grad[idx[r]] += src[r] (nn.Embedding backward); idx NULL: all rows into row 0 */
 int vlni_scatter_add_rows(int dtype, const void* src, long lds, const long* idx, float* table_grad, int rows, int H,
                           void* stream);
+/* the same for a table of <= 8 rows whose indices lie in [0, table_rows) (navigation-type / token-type embeddings): register
+   accumulators per table row, block totals as atomics - thousands of rows on 2-3 table rows serialise the per-element atomics */
+int vlni_scatter_add_rows_small(int dtype, const void* src, long lds_, const long* idx, float* table_grad, int rows, int H,
+                                int table_rows, void* stream);
 /* out[b] = mean_s x[b][s] (torch.mean(pano_embeddings, 1) R:612) */
 int vlni_seqmean_fwd(int dtype, const void* x, void* out, int B, int S, int H, void* stream);
 int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, int B, int S, int H, void* stream);

@@ -75,3 +75,18 @@ def test_longest_history_the_agent_can_build():
     for t in range(T):
         nav = torch.from_numpy(ep.steps[t]["ob_nav_types"]).cuda() != 0
         assert torch.isfinite(out["logits"][t][nav]).all() and torch.isinf(out["logits"][t][~nav]).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("table_rows,rows,H", [(3, 2368, 768), (2, 100, 768), (8, 37, 520), (1, 33, 256)])
+def test_small_table_scatter_equals_index_add(dtype, table_rows, rows, H):
+    """Embedding gradient of a table with a handful of rows (navigation types): block-level accumulators instead of per-element atomics."""
+    from vln_imagine_amd import _lib, ops
+    g = torch.Generator().manual_seed(table_rows * 100 + rows)
+    src = torch.randint(-3, 4, (rows, H), generator=g).float().to(dtype).cuda()        # integers: exact in any summation order
+    idx = torch.randint(0, table_rows, (rows,), generator=g).cuda()
+    tab = torch.randint(-2, 3, (table_rows, H), generator=g).float().cuda()
+    ref = tab.clone().index_add_(0, idx, src.float())
+    _lib.call("vlni_scatter_add_rows_small", ops._dt(src), src.data_ptr(), src.stride(0), idx.data_ptr(), tab.data_ptr(), rows, H, table_rows,
+              torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(tab, ref)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "vlni_smallk_linear_fwd": [I, P, L, P, P, P, L, I, I, I, P],
     "vlni_smallk_linear_bwd": [I, P, L, P, L, P, P, I, I, I, P],
     "vlni_scatter_add_rows": [I, P, L, P, P, I, I, P],
+    "vlni_scatter_add_rows_small": [I, P, L, P, P, I, I, I, P],
     "vlni_seqmean_fwd": [I, P, P, I, I, I, P],
     "vlni_seqmean_bwd": [I, P, P, I, I, I, P],
     "vlni_rowdot_fwd": [I, P, L, P, P, P, P, I, I, P],

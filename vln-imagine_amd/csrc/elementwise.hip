@@ -133,6 +133,30 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const T* __restri
   }
 }
 
+// The same for a table of at most 8 rows (navigation-type / token-type embeddings: thousands of source rows land on 2-3 table rows, so
+// per-element global atomics serialise ~800-deep on every address: 68 us per call). A block takes 32 source rows x 256 columns,
+// every thread keeps one register accumulator per table row for its column and only the block totals go out as atomics.
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_add_rows_small_kernel(const T* __restrict__ src, long lds_, const long* __restrict__ idx,
+                                                                     float* __restrict__ tab, int rows, int H, int TR) {
+  constexpr int RPB = 32;
+  const int c = blockIdx.y * 256 + threadIdx.x, r0 = blockIdx.x * RPB;
+  if (c >= H) return;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  const int r1 = min(rows, r0 + RPB);
+  for (int r = r0; r < r1; ++r) {
+    const int t = (int)idx[r];                                // uniform over the block
+    const float v = DT<T>::ld(src + (long)r * lds_ + c);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (t == k) ? v : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (k < TR && acc[k] != 0.f) atomicAdd(tab + (long)k * H + c, acc[k]);
+}
+
 // out[b][:] = mean_s x[b][s][:]   and its backward dx[b][s][:] = dout[b][:] / S
 template <typename T>
 __global__ __launch_bounds__(256) void seqmean_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int S, int H) {
@@ -551,6 +575,19 @@ extern "C" int vlni_scatter_add_rows(int dtype, const void* src, long lds_, cons
   dim3 grid(std::min(rows, 2048)), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((scatter_add_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, lds_, idx, table_grad, rows, H),
            hipLaunchKernelGGL((scatter_add_rows_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_scatter_add_rows_small(int dtype, const void* src, long lds_, const long* idx, float* table_grad, int rows,
+                                           int H, int table_rows, void* stream) {
+  VLNI_CHECK(rows > 0 && H > 0 && table_rows >= 1 && table_rows <= 8, VLNI_EINVAL, "scatter_add_rows_small: rows=%d H=%d table_rows=%d (1..8)",
+             rows, H, table_rows);
+  VLNI_CHECK(src && idx && table_grad, VLNI_EINVAL, "scatter_add_rows_small: null pointer");
+  dim3 grid(cdiv(rows, 32), cdiv(H, 256)), block(256);
+  BY_DTYPE(dtype,
+           hipLaunchKernelGGL((scatter_add_rows_small_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, lds_, idx, table_grad, rows, H, table_rows),
+           hipLaunchKernelGGL((scatter_add_rows_small_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H, table_rows));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

@@ -593,6 +593,7 @@ _WQ = {}
 _TN_BEST = {}
 
 
+SMALL_TABLE_SCATTER = os.environ.get("VLNI_SMALL_SCATTER", "1") == "1"
 WGRAD_PARTS = os.environ.get("VLNI_WGRAD_PARTS", "1") == "1"   # row splits write partial gradients with plain stores + ONE batched reduction per
                                                               # step instead of float atomics (~1.3 TB/s on this chip, 30-50 % of a launch)
 _PART_BUFS = {}       # (gradient address, chunk, N, K) -> workspace: [splits][N][K] slabs, then [splits][N] column sums
@@ -1377,8 +1378,12 @@ class _SumLayerNorm(torch.autograd.Function):
                 tab = ctx.tables[k]
                 direct = _direct(tab) and tab.grad.is_contiguous()
                 tg = tab.grad if direct else torch.zeros(shape, dtype=torch.float32, device=dsum.device)
-                _lib.call("vlni_scatter_add_rows", _dt(dsum), dsum.data_ptr(), dsum.stride(0), idxs[k].data_ptr(),
-                          tg.data_ptr(), rows, H, _st())
+                if SMALL_TABLE_SCATTER and shape[0] <= 8:      # a few table rows, thousands of adders each: block-level accumulators
+                    _lib.call("vlni_scatter_add_rows_small", _dt(dsum), dsum.data_ptr(), dsum.stride(0), idxs[k].data_ptr(),
+                              tg.data_ptr(), rows, H, shape[0], _st())
+                else:
+                    _lib.call("vlni_scatter_add_rows", _dt(dsum), dsum.data_ptr(), dsum.stride(0), idxs[k].data_ptr(),
+                              tg.data_ptr(), rows, H, _st())
                 grads.append(None if direct else tg)
         return (None, None, None, None, None, dg, db) + tuple(grads)
 
