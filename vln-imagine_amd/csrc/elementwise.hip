@@ -93,30 +93,37 @@ __global__ __launch_bounds__(256) void smallk_fwd_kernel(const float* __restrict
     DT<T>::st(y + (long)r * ldy + n, a);
   }
 }
-// dW[n][k] += sum_r dy[r][n] x[r][k];  db[n] += sum_r dy[r][n]
+// dW[n][k] += sum_r dy[r][n] x[r][k];  db[n] += sum_r dy[r][n].  grid (ceil(N / 256), row slabs): a block owns rows
+// [slab * rpb, (slab + 1) * rpb); their x rows (<= 64 x 16 floats) go to LDS first so that the row loop holds nothing but independent
+// dy loads, eight in flight (the loop is latency-bound: 24 us -> see tools/kernel_calls.py).
 template <typename T>
 __global__ __launch_bounds__(256) void smallk_bwd_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                          long ldx, float* __restrict__ dW, float* __restrict__ db, int rows,
-                                                         int N, int K) {
+                                                         int N, int K, int rpb) {
+  __shared__ float xs[64 * 16];
+  const int r0 = blockIdx.y * rpb, nr = min(rpb, rows - r0);
+  for (int i = threadIdx.x; i < nr * K; i += 256) xs[i] = x[(long)(r0 + i / K) * ldx + i % K];
+  __syncthreads();
   const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  if (n >= N || nr <= 0) return;
   float a[16], s = 0.f;
   for (int k = 0; k < 16; ++k) a[k] = 0.f;
-  int r = blockIdx.y;
-  for (; r + 3 * (int)gridDim.y < rows; r += 4 * gridDim.y) {          // four rows' loads in flight (the loop is latency-bound)
-    float d[4];
+  const T* dp = dy + (long)r0 * lddy + n;
+  int r = 0;
+  for (; r + 7 < nr; r += 8) {
+    float d[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) d[u] = DT<T>::ld(dy + (long)(r + u * gridDim.y) * lddy + n);
+    for (int u = 0; u < 8; ++u) d[u] = DT<T>::ld(dp + (long)(r + u) * lddy);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       s += d[u];
-      for (int k = 0; k < K; ++k) a[k] += d[u] * x[(long)(r + u * gridDim.y) * ldx + k];
+      for (int k = 0; k < K; ++k) a[k] += d[u] * xs[(r + u) * K + k];
     }
   }
-  for (; r < rows; r += gridDim.y) {
-    const float d = DT<T>::ld(dy + (long)r * lddy + n);
+  for (; r < nr; ++r) {
+    const float d = DT<T>::ld(dp + (long)r * lddy);
     s += d;
-    for (int k = 0; k < K; ++k) a[k] += d * x[(long)r * ldx + k];
+    for (int k = 0; k < K; ++k) a[k] += d * xs[r * K + k];
   }
   for (int k = 0; k < K; ++k) atomicAdd(dW + (long)n * K + k, a[k]);
   if (db) atomicAdd(db + n, s);
@@ -562,9 +569,11 @@ extern "C" int vlni_smallk_linear_fwd(int dtype, const float* x, long ldx, const
 extern "C" int vlni_smallk_linear_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, float* dW, float* db,
                                       int rows, int N, int K, void* stream) {
   VLNI_CHECK(K >= 1 && K <= 16 && rows > 0 && N > 0, VLNI_EINVAL, "smallk_bwd: rows=%d N=%d K=%d", rows, N, K);
-  dim3 grid(cdiv(N, 256), std::max(1, std::min(rows / 16, 128))), block(256);
-  BY_DTYPE(dtype, hipLaunchKernelGGL((smallk_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dy, lddy, x, ldx, dW, db, rows, N, K),
-           hipLaunchKernelGGL((smallk_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)dy, lddy, x, ldx, dW, db, rows, N, K));
+  static const int rpb_env = getenv("VLNI_SMALLK_RPB") ? atoi(getenv("VLNI_SMALLK_RPB")) : 0;
+  const int rpb = std::min(64, std::max(8, rpb_env > 0 ? rpb_env : cdiv(rows, 128)));      // <= 64 rows of x in LDS; ~128 slabs
+  dim3 grid(cdiv(N, 256), cdiv(rows, rpb)), block(256);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((smallk_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dy, lddy, x, ldx, dW, db, rows, N, K, rpb),
+           hipLaunchKernelGGL((smallk_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)dy, lddy, x, ldx, dW, db, rows, N, K, rpb));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
