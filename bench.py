@@ -7,59 +7,158 @@ One "step" = one batch of synthetic R2R episodes through the HIP path (SURVEY.md
   -> backward -> [RCCL gradient all-reduce if N > 1] -> clip_grad_norm(40) -> AdamW.
 Default workload = BASELINE.json configs[1]: 9 L + 4 X + 2 hist-pano layers, batch 64 per GPU,
 80 text tokens, 37 observation tokens, 6 imaginations, T = 6, bf16 compute, all layers trainable.
-Inputs are resident in HBM before the timed region. N > 1: one process per GPU (torchrun), weak scaling
-(64 episodes per GPU), value = all ranks' episodes / max-over-ranks time.
+Inputs are resident in HBM before the timed region. Weak scaling (64 episodes per GPU), value = all ranks' episodes /
+max-over-ranks time.
 
-Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the MFMA GEMM, timed with HIP events
-in an instrumented pass after the timed region) and `cpu_baseline` (the CPU oracle on a bounded sample).
+N > 1: one process per GPU over RCCL. Under torchrun the ranks come from the environment; `python bench.py --gpus N` alone
+starts the N rank processes itself - from a parent that never touches the GPU - and relays rank 0's line
+(reference launch: VLN-HAMT/finetune_src/utils/distributed.py:13-71, DDP wrap r2r/agent_cmt.py:61-63).
+
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the MFMA GEMM family, timed with HIP events on the
+launch stream in an instrumented pass after the timed region), `cpu_baseline` (the CPU oracle on a bounded sample, N = 1),
+`bf16_vs_fp32` (error of the timed bf16 path against the fp32 parity path of the same model on a B = 8 slice) and, at N = 1,
+`extras`: the same episodes time-batched, in train mode (in-kernel dropout p = 0.1), with the shipped freeze, at T = 1 and in fp32.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+import torch  # noqa: E402   (importing torch does not initialise the GPU)
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+# =====================================================================================================================
+#  N ranks from one command line
+# =====================================================================================================================
+def launch_ranks(n):
+    """Starts n copies of this command line as rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), waits, and returns
+    the worst exit code. This parent makes no GPU call (a process that holds the device must not start others on these boxes);
+    rank 0 inherits stdout, so its JSON line is this command's JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = None if r == 0 else subprocess.DEVNULL
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                c = p.poll()
+                if c is None:
+                    continue
+                procs.remove(p)
+                rc = max(rc, abs(c))
+                if c != 0:                         # one rank died: the others would wait in a collective forever
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
+# =====================================================================================================================
+#  workloads
+# =====================================================================================================================
 def episode_flops(cfg, B, L, V, I, T, shipped_freeze):
-    """Algorithmic FLOPs of one episode batch (SURVEY.md section 8d formulas; multiply-add = 2, bwd = 2x fwd)."""
-    H, FF = 768, 3072
+    """Algorithmic FLOPs of one HAMT episode batch (SURVEY.md section 8d formulas; multiply-add = 2, bwd = 2x fwd)."""
+    H = 768
     bert = lambda S: 24 * S * H * H + 4 * S * S * H
     xl = lambda Lt, Lv: 32 * (Lt + Lv) * H * H + 8 * Lt * Lv * H + 4 * (Lt * Lt + Lv * Lv) * H
     lang = cfg.num_l_layers * bert(L)
     hist_step = 2 * H * H + cfg.num_h_pano_layers * bert(36) + 2 * 36 * H * H
     aux = 2 * I * (768 * 512 + 512 * 512 + 512 * 768)
-    total = 0.0
-    total += lang * (1 if shipped_freeze else 3)
-    total += aux * 3
+    total = lang * (1 if shipped_freeze else 3) + aux * 3
     for t in range(T):
         Lv = (1 + t) + V
         visual = cfg.num_x_layers * xl(L + I, Lv) + 2 * V * H * H * 2   # + obs embed + head
-        total += visual * 3
-        total += hist_step * (1 if shipped_freeze else 3)
+        total += visual * 3 + hist_step * (1 if shipped_freeze else 3)
     return total * B
 
 
-def make_model(cfg, dtype, device):
-    from vln_imagine_amd import synth
-    from vln_imagine_amd.hamt.models.vilmodel_cmt import NavCMT
-    from vln_imagine_amd.hamt.spec import param_shapes
-    m = NavCMT(cfg)
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()})
-    return m.to(device).eval().set_compute_dtype(dtype)      # eval(): dropout p = 0 as in the survey probe
+class Workload:
+    """Model + resident synthetic episode + the episode driver, for the product (device) or the CPU oracle."""
 
+    def __init__(self, family, args, shipped, device, dtype=None, batch=None, T=None, tag="bench", oracle=False, model=None):
+        from vln_imagine_amd import synth
+        self.family, self.shipped = family, shipped
+        B, T = batch or args.batch, T or args.T
+        self.B, self.T = B, T
+        if family == "duet":
+            from vln_imagine_amd.duet.config import DuetConfig
+            from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode
+            from vln_imagine_amd.duet.spec import param_shapes
+            self.cfg = DuetConfig(fix_lang_embedding=shipped, update_lang_bert=not shipped)
+            ep = synth.DuetEpisode(tag=tag, B=B, L=args.L, V=36, I=args.I, T=T, ragged=False)
+            self.et, self.logits_key = DuetEpisodeTensors(ep, device), "fused"
+            self._run = run_episode
+            self.flops = 150e9 * B * T / 6.0                     # SURVEY 8d: DUET episode T=6 all-trainable ~150 GF/sample
+            self.label = "DUET-Imagine 9L+2pano+4global+4local X, map 5+3t nodes"
+        else:
+            from vln_imagine_amd.hamt.config import HamtConfig
+            from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+            from vln_imagine_amd.hamt.spec import param_shapes
+            self.cfg = HamtConfig(fix_lang_embedding=shipped, fix_hist_embedding=shipped, update_lang_bert=not shipped)
+            ep = synth.HamtEpisode(tag=tag, B=B, L=args.L, V=args.V, I=args.I, T=T, ragged=False)
+            self.et, self.logits_key = EpisodeTensors(ep, device), "logits"
+            self._run = run_episode
+            self.flops = episode_flops(self.cfg, B, args.L, args.V, args.I, T, shipped)
+            self.label = "HAMT-Imagine 9L+4X+2pano"
+        self._shapes, self._weights = param_shapes(self.cfg), None
+        if oracle:
+            self.sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in self.weights.items()}
+            if family == "duet":
+                from oracle.duet_oracle import DuetOracle as Oracle
+            else:
+                from oracle.hamt_oracle import HamtOracle as Oracle
+            self.model = Oracle(self.cfg, self.sd)
+        else:
+            self.model = model if model is not None else self.build(device, dtype)      # model: another episode for a resident model
 
-def log(msg):
-    if int(os.environ.get("RANK", "0")) == 0:
-        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+    @property
+    def weights(self):
+        """Closed-form synthetic weights (a hash of parameter name + index, vln_imagine_amd/synth.py): no checkpoint is shipped."""
+        if self._weights is None:
+            from vln_imagine_amd import synth
+            self._weights = synth.fill_state_dict(self._shapes.items())
+        return self._weights
+
+    def build(self, device, dtype):
+        if self.family == "duet":
+            from vln_imagine_amd.duet.models.vilmodel import GlocalTextPathNavCMT as Net
+        else:
+            from vln_imagine_amd.hamt.models.vilmodel_cmt import NavCMT as Net
+        m = Net(self.cfg)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in self.weights.items()})
+        return m.to(device).eval().set_compute_dtype(dtype)      # eval(): dropout p = 0 (the survey's CPU probe); `train_mode` extra: p = 0.1
+
+    def run(self, criterion=None, keep=False, model=None, et=None, time_batched=False):
+        kw = {} if criterion is None else {"criterion": criterion}
+        if time_batched:
+            from vln_imagine_amd.hamt.episode import run_episode_time_batched
+            return run_episode_time_batched(model or self.model, et or self.et, **kw)
+        return self._run(model or self.model, et or self.et, keep=keep, **kw)
 
 
 def host_cores():
@@ -74,39 +173,45 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("VLNI_CPU_THREADS", "64"))))
 
 
-def cpu_baseline(cfg, args):
-    """The CPU oracle (plain PyTorch fp32 restatement pinned to the reference's golden vectors) on the host cores."""
-    from oracle.hamt_oracle import HamtOracle
-    from vln_imagine_amd import synth
-    from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
-    from vln_imagine_amd.hamt.spec import param_shapes
+def cpu_baseline(args, shipped):
+    """The CPU oracle (plain PyTorch fp32 restatement pinned to the reference's golden vectors) on the host cores: one warm-up
+    step at a small batch (thread pools, allocator), then ONE timed step of the GPU workload's batch on all cores, and one at a
+    quarter of the batch on 8 threads (the survey container's core count)."""
     cores = host_cores()
-    log(f"cpu_baseline: oracle on {cores} host threads, batch {args.cpu_batch}")
+
+    def one(B, threads):
+        torch.set_num_threads(threads)
+        w = Workload(args.model, args, shipped, "cpu", batch=B, tag="cpu", oracle=True)
+        params = list(w.sd.values())
+        opt = torch.optim.AdamW(params, lr=1e-5)
+        t0 = time.time()
+        w.run()["loss"].backward()
+        torch.nn.utils.clip_grad_norm_(params, 40.0)
+        opt.step()
+        return time.time() - t0
+
+    log(f"cpu_baseline: oracle on {cores} host threads (warm-up at batch 4, then batch {args.cpu_batch})")
+    one(4, cores)
+    dt = one(args.cpu_batch, cores)
+    res = {"value": args.cpu_batch / dt, "unit": "episodes/s", "cores": cores, "kind": "port",
+           "sample": f"1 step of {args.cpu_batch} episodes after a warm-up step at batch 4 (same model/T/shapes as the GPU workload, fp32, "
+                     f"torch {torch.__version__} CPU, fwd+bwd+clip+AdamW), {dt:.1f} s wall"}
+    if cores > 8 and not args.quick_cpu:
+        b8 = max(4, args.cpu_batch // 4)
+        d8 = one(b8, 8)
+        res["threads8"] = {"value": b8 / d8, "unit": "episodes/s", "cores": 8, "sample": f"1 step of {b8} episodes, {d8:.1f} s wall"}
     torch.set_num_threads(cores)
-    Bc = args.cpu_batch
-    ep = synth.HamtEpisode(tag="cpu", B=Bc, L=args.L, V=args.V, I=args.I, T=args.T, ragged=False)
-    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()}
-    opt = torch.optim.AdamW(list(sd.values()), lr=1e-5)
-    et = EpisodeTensors(ep, "cpu")
-    model = HamtOracle(cfg, sd)
-    t0 = time.time()
-    out = run_episode(model, et, keep=False)
-    out["loss"].backward()
-    torch.nn.utils.clip_grad_norm_(list(sd.values()), 40.0)
-    opt.step()
-    dt = time.time() - t0
-    return {"value": Bc / dt, "unit": "episodes/s", "cores": cores, "kind": "port",
-            "sample": f"1 step of {Bc} episodes (same model/T/shapes as the GPU workload, fp32, torch {torch.__version__} CPU, "
-                      f"fwd+bwd+clip+AdamW), {dt:.1f} s wall"}
+    return res
 
 
+# =====================================================================================================================
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--batch", type=int, default=None, help="episodes per GPU (default: 64 HAMT, 32 DUET = BASELINE.json configs[1] / [3])")
     ap.add_argument("--T", type=int, default=6)
     ap.add_argument("--L", type=int, default=80)
     ap.add_argument("--V", type=int, default=37)
@@ -114,7 +219,7 @@ def main():
     ap.add_argument("--freeze", default="none", choices=["none", "shipped"])
     ap.add_argument("--time-batched", action="store_true",
                     help="HAMT: run the T teacher-forced steps as one [T*B] batch (same results, SURVEY 8f rank 1)")
-    ap.add_argument("--no-time-batched-extra", action="store_true")
+    ap.add_argument("--train-mode", action="store_true", help="model.train(): in-kernel dropout p = 0.1 (the reference's training mode)")
     ap.add_argument("--grad-comm", default="bf16", choices=["bf16", "fp32"],
                     help="dtype of the gradient all-reduce payload for N > 1 (arena stays fp32)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
@@ -122,21 +227,43 @@ def main():
     ap.add_argument("--no-graph", dest="graph", action="store_false", help="launch every kernel from Python")
     ap.add_argument("--model", default="hamt", choices=["hamt", "duet"],
                     help="hamt = BASELINE.json configs[1] (the metric's config); duet = configs[3] (batch 32)")
-    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=None, help="episodes of the CPU baseline step (default: the GPU batch)")
+    ap.add_argument("--quick-cpu", action="store_true", help="skip the 8-thread CPU line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip time-batched / train-mode / shipped-freeze / T=1 / fp32 extra lines")
+    ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-fp32 error report")
     args = ap.parse_args()
+    if args.batch is None:
+        args.batch = 32 if args.model == "duet" else 64
+    if args.cpu_batch is None:
+        args.cpu_batch = args.batch
+    if args.model == "duet":
+        args.time_batched = False                 # DUET's maps grow with the agent's moves: there is no time-batched form
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU (torchrun) or drop WORLD_SIZE")
+    if os.environ.get("VLNI_BENCH_DRY_RUN"):          # CPU test of the launcher: ranks rendezvous over gloo and report, no GPU work
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, local))
+        if rank == 0:
+            print(json.dumps({"n_gpus": world, "ranks": seen}), flush=True)
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if os.environ.get("VLNI_ONE_GPU"):
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -144,47 +271,16 @@ def main():
         backend = os.environ.get("VLNI_DIST_BACKEND", "nccl")
         kw = {"device_id": dev} if backend == "nccl" else {}       # bind the communicator to this rank's GPU up front
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        rccl = {"backend": backend, "world_size": dist.get_world_size()}
 
-    from vln_imagine_amd import ops, synth
-    from vln_imagine_amd.hamt.config import HamtConfig
-    from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.compare import compare_runs
     from vln_imagine_amd.train import FlatTrainer
 
     shipped = args.freeze == "shipped"
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    if args.model == "duet":
-        from vln_imagine_amd.duet.config import DuetConfig
-        from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode as duet_run
-        from vln_imagine_amd.duet.models.vilmodel import GlocalTextPathNavCMT
-        from vln_imagine_amd.duet.spec import param_shapes as duet_shapes
-        if args.batch == 64:
-            args.batch = 32                                  # BASELINE.json configs[3]
-        cfg = DuetConfig(fix_lang_embedding=shipped, update_lang_bert=not shipped)
-        model = GlocalTextPathNavCMT(cfg)
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(duet_shapes(cfg).items()).items()})
-        model = model.to(dev).eval().set_compute_dtype(dtype)
-        ep = synth.DuetEpisode(tag=f"bench{rank}", B=args.batch, L=args.L, V=36, I=args.I, T=args.T, ragged=False)
-        et = DuetEpisodeTensors(ep, dev)
-        run_episode = duet_run
-    else:
-        cfg = HamtConfig(fix_lang_embedding=shipped, fix_hist_embedding=shipped, update_lang_bert=not shipped)
-        model = make_model(cfg, dtype, dev)
-        ep = synth.HamtEpisode(tag=f"bench{rank}", B=args.batch, L=args.L, V=args.V, I=args.I, T=args.T, ragged=False)
-        et = EpisodeTensors(ep, dev)
-        if args.time_batched:
-            from vln_imagine_amd.hamt.episode import run_episode_time_batched
-            run_episode = lambda m, e, criterion=None, keep=False: run_episode_time_batched(m, e, criterion=criterion)
-    trainer = FlatTrainer(model, lr=1e-5, grad_comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
-
-    def step():
-        trainer.zero_grad()
-        out = run_episode(model, et, criterion=ops.cross_entropy_sum, keep=False)
-        out["loss"].backward()
-        trainer.allreduce_grads()
-        trainer.step()
-        return out["loss"]
-
-    eager_step = step
+    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    comm = torch.bfloat16 if args.grad_comm == "bf16" else None
 
     def fence():
         torch.cuda.synchronize()
@@ -192,71 +288,89 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    log(f"model + episode ready on {dev}; warmup {args.warmup}, steps {args.steps}, dtype {args.dtype}")
-    eager_s = float("inf")
-    for i in range(args.warmup):
-        tw = time.perf_counter()
-        loss = step()
-        torch.cuda.synchronize()
-        eager_s = min(eager_s, time.perf_counter() - tw)
-        log(f"warmup {i}: {1e3 * (time.perf_counter() - tw):.1f} ms loss {float(loss.detach()):.5f}")
-    launch = "eager (one kernel launch per op from Python)"
-    if args.graph:
-        # same step, replayed from two captured hipGraphs (fwd+bwd+wgrad flush | clip+AdamW) with the RCCL all-reduce between
-        def fwd_bwd():
-            out = run_episode(model, et, criterion=ops.cross_entropy_sum, keep=False)
-            out["loss"].backward()
-            return out["loss"]
-        loss = None                                 # drop the last eager autograd graph (its AccumulateGrad nodes) before capturing
-        import gc
-        gc.collect()
-        slow, captured = True, None
-        try:
-            captured = trainer.capture(fwd_bwd, warmup=1)
-            loss = captured()
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for _ in range(2):
-                loss = captured()
-            torch.cuda.synchronize()
-            tg = (time.perf_counter() - tg) / 2
-            log(f"step captured into hipGraphs; loss {float(loss.detach()):.5f}; replay {1e3 * tg:.1f} ms vs eager {1e3 * eager_s:.1f} ms")
-            slow = tg > 1.3 * eager_s                 # never seen on a dedicated GPU; two processes SHARING one GPU replay pathologically slowly
-        except Exception as e:                      # keep measuring: fall back to the eager step and say so
-            log(f"graph capture failed ({type(e).__name__}: {e})")
-        if world > 1:                                 # one decision for the whole job (every rank reaches this all-reduce)
-            flag = torch.tensor([1.0 if slow else 0.0], device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            slow = bool(flag.item() > 0)
-        if slow:
-            log("no usable graph replay on this box: timing the eager step")
-            step = eager_step
-        else:
-            step = captured
-            launch = "hipGraph replay (fwd+bwd+wgrad | clip+AdamW), all-reduce eager between"
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms = dt / args.steps * 1e3
-    log(f"timed: {ms:.2f} ms/step")
-    eps = args.batch * world / (dt / args.steps)
-    flops = episode_flops(cfg, args.batch, args.L, args.V, args.I, args.T, shipped) if args.model == "hamt" \
-        else 150e9 * args.batch * args.T / 6.0          # DUET episode T=6 all-trainable ~150 GF/sample
-    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    def agree(flag):
+        """One decision for the whole job (every rank reaches this all-reduce)."""
+        if world > 1:
+            f = torch.tensor([1.0 if flag else 0.0], device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+            return bool(f.item() > 0)
+        return flag
 
+    def measure(w, trainer, steps, warmup, time_batched=False, graph=True, what="step"):
+        """W untimed warm-up steps, capture, then EXACTLY `steps` steps between fences; max over ranks. Returns (seconds per step,
+        launch description, last loss, eager step callable)."""
+        def fwd_bwd():
+            loss = w.run(criterion=ops.cross_entropy_sum, time_batched=time_batched)["loss"]
+            loss.backward()
+            return loss
+
+        def eager():
+            trainer.zero_grad()
+            loss = fwd_bwd()
+            trainer.allreduce_grads()
+            trainer.step()
+            return loss
+
+        eager_s, loss = float("inf"), None
+        for i in range(max(1, warmup)):
+            tw = time.perf_counter()
+            loss = eager()
+            torch.cuda.synchronize()
+            eager_s = min(eager_s, time.perf_counter() - tw)
+            log(f"{what}: warmup {i}: {1e3 * (time.perf_counter() - tw):.1f} ms loss {float(loss.detach()):.5f}")
+        step, launch = eager, "eager (one kernel launch per op from Python)"
+        if graph:
+            import gc
+            loss = None                                 # drop the last eager autograd graph (its AccumulateGrad nodes) before capturing
+            gc.collect()
+            slow, captured = True, None
+            try:
+                captured = trainer.capture(fwd_bwd, warmup=1)
+                captured()
+                torch.cuda.synchronize()
+                tg = time.perf_counter()
+                for _ in range(2):
+                    captured()
+                torch.cuda.synchronize()
+                tg = (time.perf_counter() - tg) / 2
+                log(f"{what}: captured into hipGraphs; replay {1e3 * tg:.1f} ms vs eager {1e3 * eager_s:.1f} ms")
+                slow = tg > 1.3 * eager_s             # never seen on a dedicated GPU; two processes SHARING one GPU replay pathologically slowly
+            except Exception as e:                      # keep measuring: fall back to the eager step and say so
+                log(f"{what}: graph capture failed ({type(e).__name__}: {e})")
+            if agree(slow):
+                log(f"{what}: no usable graph replay on this box: timing the eager step")
+            else:
+                step = captured
+                launch = "hipGraph replay (zero+fwd+bwd | wgrad flush%s | clip+AdamW)" % (
+                    " in %d ranges, RCCL all-reduce of each range on a side stream under the next" % len(trainer.comm_ranges()) if world > 1 else "")
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        log(f"{what}: timed {1e3 * dt / steps:.2f} ms/step")
+        return dt / steps, launch, float(loss.detach()), eager
+
+    # ---- the metric's workload -------------------------------------------------------------------------------------------
+    w = Workload(args.model, args, shipped, dev, dtype, tag=f"bench{rank}")
+    if args.train_mode:
+        w.model.train()
+    trainer = FlatTrainer(w.model, lr=1e-5, grad_comm_dtype=comm)
+    log(f"model + episode ready on {dev}; warmup {args.warmup}, steps {args.steps}, dtype {args.dtype}, world {world}")
+    sec, launch, last_loss, eager_step = measure(w, trainer, args.steps, args.warmup, time_batched=args.time_batched, graph=args.graph)
+    ms = sec * 1e3
+    eps = args.batch * world / sec
+
+    # ---- roofline of the dominant kernel family (instrumented pass, not part of the timed region) -----------------------------
     roof = None
     if not args.no_roofline:           # EVERY rank runs the instrumented step (it contains the gradient all-reduce)
-        # instrumented pass: HIP events (torch.cuda.Event on the launch stream = torch's current stream) around
-        # every vlni_gemm_nt launch of ONE more step; not part of the timed region above.
         rec, epi = [], [0.0]
-        orig = ops.gemm_nt
+        orig, orig2 = ops.gemm_nt, ops.gemm_nt2
 
         def _epi_bytes(k):              # tensors the fused epilogue reads / writes besides C: residual, GELU' source, pre-activation
             n = 0
@@ -267,17 +381,17 @@ def main():
                         n += t_.numel() * t_.element_size()
             return n
 
+        def _n_of(b):
+            return b.n if isinstance(b, ops.WT) else b.t.shape[1] if isinstance(b, ops.KN) else b.shape[0]      # WT / KN: dgrad operand handles
+
         def timed(a, b, *p, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig(a, b, *p, **k)
             e1.record()
-            n_ = b.n if isinstance(b, ops.WT) else b.t.shape[1] if isinstance(b, ops.KN) else b.shape[0]      # WT / KN: dgrad operand handles
-            rec.append((2.0 * a.shape[0] * n_ * a.shape[1], e0, e1, (a.shape[0], n_, a.shape[1])))
+            rec.append((2.0 * a.shape[0] * _n_of(b) * a.shape[1], e0, e1, (a.shape[0], _n_of(b), a.shape[1])))
             epi[0] += _epi_bytes(k)
             return r
-
-        orig2 = ops.gemm_nt2
 
         def timed2(a, b, *p, **k):                     # dual-problem launches (language + vision stream in one launch)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -285,18 +399,16 @@ def main():
             r = orig2(a, b, *p, **k)
             e1.record()
             rows = a[0].shape[0] + a[1].shape[0]
-            n_ = b[0].n if isinstance(b[0], ops.WT) else b[0].t.shape[1] if isinstance(b[0], ops.KN) else b[0].shape[0]
-            rec.append((2.0 * rows * n_ * a[0].shape[1], e0, e1, (rows, n_, a[0].shape[1])))
+            rec.append((2.0 * rows * _n_of(b[0]) * a[0].shape[1], e0, e1, (rows, _n_of(b[0]), a[0].shape[1])))
             epi[0] += _epi_bytes(k)
             return r
 
-        step = eager_step
         ops.gemm_nt, ops.gemm_nt2 = timed, timed2
         try:
             # keep the stream busy while the host enqueues the step, so that each event pair brackets the kernel alone and not
             # the host's gap between recording the event and launching (otherwise the average reads ~35 % above rocprof's)
             torch.cuda._sleep(int(0.05 * getattr(torch.cuda.get_device_properties(dev), "clock_rate", 2.4e6) * 1e3))
-            step()
+            eager_step()
             torch.cuda.synchronize()
         finally:
             ops.gemm_nt, ops.gemm_nt2 = orig, orig2
@@ -311,104 +423,106 @@ def main():
             for shp, (n, ms_, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
                 log(f"gemm M={shp[0]:6d} N={shp[1]:5d} K={shp[2]:5d}: {n:4d} calls {ms_:7.2f} ms {f / ms_ / 1e9:7.1f} TF/s")
         ach = tot_f / (tot_ms * 1e-3) / 1e12
-        traffic = None
-        try:      # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/); never live
+        traffic, traffic_src = None, None
+        try:      # HBM bytes per launch: separate rocprofv3 --pmc passes of this command (never collected inside a timed run)
             pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
             if pmc and args.dtype == "bf16" and args.model == "hamt" and not args.time_batched:      # collected on the default workload only
                 traffic = round(json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["bytes_per_launch"])
+                traffic_src = f"profiles/{pmc[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
         except Exception:
             traffic = None
-        roof = {"bound": "mfma", "kernel": "gemm_nt_* / gemm_nn_glds_kernel <%s>" % ("__bf16" if args.dtype == "bf16" else "float"),
+        alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec)
+        roof = {"bound": "mfma", "kernel": "gemm_nt_* / gemm_nn_* <%s>" % ("__bf16" if args.dtype == "bf16" else "float"),
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": round(sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec) / len(rec)),
-                "algorithmic_bytes_per_launch_with_epilogue": round((sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec) + epi[0]) / len(rec)),
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": round(alg / len(rec)),
+                "algorithmic_bytes_per_launch_with_epilogue": round((alg + epi[0]) / len(rec)),
                 "launches_per_step": len(rec), "avg_launch_us": round(tot_ms * 1e3 / len(rec), 2),
                 "avg_gflop_per_launch": round(tot_f / len(rec) / 1e9, 3),
                 "gemm_share_of_step": round(tot_ms / ms, 3),
-                "step_algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 2),
-                "step_frac_of_peak": round(flops / (ms * 1e-3) / 1e12 / peak, 4)}
+                "step_algorithmic_tflops": round(w.flops / sec / 1e12, 2),
+                "step_frac_of_peak": round(w.flops / sec / 1e12 / peak, 4)}
 
-    tb = None
-    if args.model == "hamt" and not args.time_batched and not args.no_time_batched_extra:
-        # extra, reported beside `value` (never instead of it): the same episodes with the T teacher-forced steps run as one
-        # [T*B] batch (identical logits/loss/gradients, tests/test_hamt_gpu.py)
-        from vln_imagine_amd.hamt.episode import run_episode_time_batched
+    # ---- error of the timed path against the fp32 parity path (same model, same weights, B = 8 slice, fwd + bwd) -------------
+    parity = None
+    if rank == 0 and not args.no_parity and args.dtype == "bf16":
+        ws = Workload(args.model, args, shipped, dev, dtype, batch=8, tag="slice", model=w.model)
+        w32 = ws.build(dev, torch.float32)
+        trainer.zero_grad()
+        o16 = ws.run(criterion=ops.cross_entropy_sum, keep=True)
+        o16["loss"].backward()
+        trainer.flush()
+        o32 = ws.run(criterion=ops.cross_entropy_sum, keep=True, model=w32)
+        o32["loss"].backward()
+        parity = compare_runs(o16, o32, dict(w.model.named_parameters()), dict(w32.named_parameters()), ws.logits_key)
+        parity = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in parity.items()}
+        parity["sample"] = f"B=8, T={args.T}, same weights; fp32 = the exact-fp32 MFMA path held to the reference goldens at 1e-4"
+        log(f"bf16 vs fp32: {parity}")
+        del w32, o16, o32, ws
+    if world > 1:
+        dist.barrier()
 
-        def step_tb():
-            trainer.zero_grad()
-            out = run_episode_time_batched(model, et, criterion=ops.cross_entropy_sum)
-            out["loss"].backward()
-            trainer.allreduce_grads()
-            trainer.step()
-            return out["loss"]
+    # ---- extra lines, reported beside `value` (never instead of it) -------------------------------------------------------
+    extras = {}
+    if world == 1 and not args.no_extras:
+        k_extra = max(3, min(args.steps, 8))
 
-        eager_tb, eager_tb_s = step_tb, float("inf")
-        for _ in range(max(2, args.warmup)):
-            tw = time.perf_counter()
-            step_tb()
-            torch.cuda.synchronize()
-            eager_tb_s = min(eager_tb_s, time.perf_counter() - tw)
-        if args.graph and launch.startswith("hipGraph"):
-            import gc
-            gc.collect()
+        def line(sec_, flops_, note):
+            return {"value": round(args.batch / sec_, 2), "unit": "episodes/s", "ms_per_step": round(sec_ * 1e3, 3),
+                    "step_algorithmic_tflops": round(flops_ / sec_ / 1e12, 2), "note": note}
 
-            def fwd_bwd_tb():
-                out = run_episode_time_batched(model, et, criterion=ops.cross_entropy_sum)
-                out["loss"].backward()
-                return out["loss"]
-            slow, cap_tb = True, None
-            try:
-                cap_tb = trainer.capture(fwd_bwd_tb, warmup=1)
-                cap_tb()
-                torch.cuda.synchronize()
-                tw = time.perf_counter()
-                cap_tb()
-                torch.cuda.synchronize()
-                slow = time.perf_counter() - tw > 1.3 * eager_tb_s
-            except Exception as e:
-                log(f"time-batched graph capture failed ({type(e).__name__}: {e}); eager")
-            if world > 1:
-                flag = torch.tensor([1.0 if slow else 0.0], device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-                slow = bool(flag.item() > 0)
-            step_tb = eager_tb if slow else cap_tb
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step_tb()
-        fence()
-        dtb = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([dtb], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dtb = float(tt.item())
-        tb = {"value": round(args.batch * world / (dtb / args.steps), 2), "unit": "episodes/s",
-              "ms_per_step": round(dtb / args.steps * 1e3, 3),
-              "step_algorithmic_tflops": round(flops / (dtb / args.steps) / 1e12, 2),
-              "note": "T steps as one [T*B] batch under teacher forcing; same results as the step-by-step calls"}
-        log(f"time-batched extra: {tb['ms_per_step']} ms/step")
+        if args.model == "hamt" and not args.time_batched:
+            s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=True, graph=args.graph, what="time-batched")
+            extras["time_batched"] = line(s_, w.flops, "T steps as one [T*B] batch under teacher forcing; same results as the step-by-step calls")
+        if not args.train_mode:
+            w.model.train()
+            s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="train-mode")
+            w.model.eval()
+            extras["train_mode"] = line(s_, w.flops, "model.train(): attention-probability and hidden dropout p = 0.1 inside the fused kernels "
+                                                     "(masks regenerated in backward), the reference's training mode")
+        if args.model == "hamt":
+            w1 = Workload("hamt", args, shipped, dev, dtype, T=1, tag="benchT1", model=w.model)
+            s_, _, _, _ = measure(w1, trainer, k_extra, 2, graph=args.graph, what="T=1")
+            extras["T1"] = line(s_, w1.flops, "one navigation step per episode (SURVEY 8d's second episode length)")
+        if args.dtype == "bf16":
+            w.model.set_compute_dtype(torch.float32)
+            s_, _, _, _ = measure(w, trainer, 3, 1, time_batched=args.time_batched, graph=False, what="fp32")
+            w.model.set_compute_dtype(dtype)
+            e_ = line(s_, w.flops, "the parity path: every contraction on v_mfma_f32_32x32x2_f32 (exact fp32), eager launches")
+            e_["step_frac_of_fp32_mfma_peak"] = round(w.flops / s_ / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
+            extras["fp32"] = e_
+        if not shipped:
+            trainer.close()
+            del trainer
+            ws_ = Workload(args.model, args, True, dev, dtype, tag=f"bench{rank}")
+            tr2 = FlatTrainer(ws_.model, lr=1e-5, grad_comm_dtype=comm)
+            s_, _, _, _ = measure(ws_, tr2, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="freeze=shipped")
+            extras["freeze_shipped"] = line(s_, ws_.flops, "the released run's freeze: language stack (and HAMT history encoder) forward only")
+            tr2.close()
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "hamt":
-        cpu = cpu_baseline(cfg, args)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, shipped)
 
     if rank == 0:
-        line = {
+        line_ = {
             "metric": "episodes/sec (fwd+bwd) HAMT-Imagine 9L, batch 64" if args.model == "hamt"
             else "episodes/sec (fwd+bwd) DUET-Imagine 9L+2pano+4+4X, batch 32", "value": round(eps, 2), "unit": "episodes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{'HAMT-Imagine 9L+4X+2pano' if args.model == 'hamt' else 'DUET-Imagine 9L+2pano+4global+4local X, map 5+3t nodes'}, batch {args.batch}/GPU, {args.L} text, {args.V} obs tokens, "
-                                   f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, dropout p=0"
+            "config": {"workload": f"{w.label}, batch {args.batch}/GPU, {args.L} text, {args.V} obs tokens, "
+                                   f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, "
+                                   + ("train mode: in-kernel dropout p=0.1" if args.train_mode else "dropout p=0 (eval)")
                                    + (", steps time-batched (teacher forcing)" if args.time_batched else ", step-by-step calls"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "launch": launch,
-                       "grad_allreduce": (args.grad_comm + " payload, flat arena, 128-MiB chunks, RCCL") if world > 1 else "none (1 GPU)",
-                       "steps_per_sec": round(args.T * args.batch * world / (dt / args.steps), 1),
-                       "loss": round(float(loss), 5)},
-            "roofline": roof, "cpu_baseline": cpu, "time_batched": tb,
+                       "launch": launch, "rccl": rccl,
+                       "grad_allreduce": (args.grad_comm + " payload, flat arena, flush -> all-reduce pipeline, RCCL") if world > 1 else "none (1 GPU)",
+                       "steps_per_sec": round(args.T * args.batch * world / sec, 1),
+                       "loss": round(last_loss, 5)},
+            "roofline": roof, "cpu_baseline": cpu, "bf16_vs_fp32": parity, "extras": extras or None,
+            "time_batched": extras.get("time_batched"),
         }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line_), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -18,6 +18,7 @@ extern "C" {
 
 #define VLNI_F32 0
 #define VLNI_BF16 1
+#define VLNI_F16 2
 #define VLNI_OK 0
 #define VLNI_EINVAL (-1)
 #define VLNI_ELAUNCH (-2)
@@ -212,6 +213,23 @@ int vlni_clip_coef(const float* sumsq, float max_norm, float* coef, void* stream
 int vlni_optim_prepare(const float* sumsq, float max_norm, float beta1, float beta2, float* state, void* stream);
 int vlni_adamw_step_dev(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, const float* lr_dev,
                         float beta1, float beta2, float eps, float weight_decay, const float* state, void* stream);
+/* Parameter-group form (the optimizer of the shipped "variant4" warm-up: r2r/agent_cmt.py:82-96, r2r/main.py:202-255): the
+   arena is laid out group by group (ngrp <= 8, grp_end[k] = first element past group k, device int64); grp_lr (device,
+   2*ngrp floats) = learning rate per group, then a trainable flag per group (0 = the group is skipped altogether, like
+   torch.optim skips parameters without a gradient); gstate (device, 4*ngrp floats, zeroed once) = per-group step count and
+   bias corrections; state (device, 8 floats, zeroed once): [0] clip factor / loss scale, [3] calls, [4] loss scale S the caller
+   multiplied the loss by (0 = 1), [5] 1 = this step was skipped, [6] good steps since S changed, [7] unscaled gradient norm.
+   growth_interval > 0 = dynamic loss scaling (torch.cuda.amp.GradScaler, VLN-DUET/pretrain_src/train_r2r.py:201-234): a
+   non-finite gradient sum skips the step and halves S, growth_interval good steps double it. shadow_dtype: dtype of the
+   compute-dtype mirror of the parameters kept current by the step (1 bf16, 2 f16), shadow may be null. */
+int vlni_optim_prepare_groups(const float* sumsq, float max_norm, float beta1, float beta2, float* state, float* gstate,
+                              const float* grp_lr, int ngrp, int growth_interval, void* stream);
+int vlni_adamw_step_groups(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long n,
+                           const long* grp_end, const float* grp_lr, const float* gstate, int ngrp, float beta1, float beta2,
+                           float eps, float weight_decay, const float* state, void* stream);
+/* dst[i] = (out dtype)(src[i] * scale), float32 <-> bfloat16: packs / unpacks the gradient all-reduce payload (DDP's gradient
+   averaging with bf16 compression, r2r/agent_cmt.py:61-63); src 16-byte, dst 8-byte aligned */
+int vlni_scale_cast(int dt_in, int dt_out, const void* src, void* dst, long n, float scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -232,5 +232,4 @@ def test_graph_replay_draws_fresh_masks(monkeypatch):
         assert d.max().item() < 2.5e-3 and d.mean().item() < 1e-5, (d.max().item(), d.mean().item())
     finally:
         ops.set_seed_base(None)
-        ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
         ops._WQ.clear()

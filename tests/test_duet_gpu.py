@@ -195,6 +195,5 @@ def test_bf16_trainer_step_with_odd_sized_parameters():
                 wt = ops._w((w2,), torch.bfloat16, True).resolve(64)            # a short launch: the maintained W^T copy
                 assert torch.equal(wt, w2.detach().bfloat16().t())
     finally:
-        ops.DIRECT_GRAD = ops.DEFER_WGRAD = False
         ops._WQ.clear()
         ops.SHADOWS.set_arena(None, None)

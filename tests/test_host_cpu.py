@@ -150,6 +150,9 @@ def test_duet_helper_ops():
     assert length2mask([1, 3], size=3).tolist() == [[False, True, True], [False, False, False]]
 
 
+_UNITS = [(0, 96), (96, 200), (296, 8), (304, 400), (704, 296)]
+
+
 def _dp_worker(rank, world, port, out):
     import torch.distributed as dist
     from vln_imagine_amd.train import allreduce_mean_
@@ -161,6 +164,14 @@ def _dp_worker(rank, world, port, out):
     h = torch.arange(1000, dtype=torch.float32) * (rank + 1)
     allreduce_mean_(h, 300, torch.bfloat16)       # compressed exchange
     out[10 + rank] = h.clone()
+    # the flush -> all-reduce pipeline's stages: ranges cut at unit boundaries, reduced range by range
+    from vln_imagine_amd.train import cut_ranges, reduce_range_
+    ranges = cut_ranges(_UNITS, 1000, 3)
+    for j, cd in enumerate((None, torch.bfloat16)):
+        k = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+        for lo, hi in ranges:
+            reduce_range_(k, lo, hi, world, 128, cd)
+        out[20 + 10 * j + rank] = k.clone()
     dist.destroy_process_group()
 
 
@@ -175,6 +186,14 @@ def test_data_parallel_gradient_mean_gloo_world2(tmp_path):
     assert torch.equal(out[0], want) and torch.equal(out[1], want)
     for r in (10, 11):                            # bf16 exchange: every rank identical, within bf16 rounding of the mean
         assert torch.equal(out[r], out[10]) and ((out[r] - want).abs() <= want.abs() * 2 ** -7 + 1e-6).all()
+    from vln_imagine_amd.train import cut_ranges
+    ranges = cut_ranges(_UNITS, 1000, 3)
+    assert ranges[0][0] == 0 and ranges[-1][1] == 1000 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:])) and len(ranges) == 3
+    starts = {u for u, _ in _UNITS} | {1000}
+    assert all(lo in starts and hi in starts for lo, hi in ranges)           # no unit (packed q/k/v triple) is split
+    assert torch.equal(out[20], want) and torch.equal(out[21], want)
+    for r in (30, 31):
+        assert torch.equal(out[r], out[30]) and ((out[r] - want).abs() <= want.abs() * 2 ** -7 + 1e-6).all()
 
 
 def test_graph_map_shortest_paths_and_features():
@@ -257,3 +276,20 @@ def test_annotation_and_flag_formats(tmp_path):
     except ImportError:
         with pytest.raises(ImportError, match="h5py"):
             list(formats._iter_store(str(tmp_path / "x.hdf5"), 768))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without torchrun starts N rank processes itself (parent makes no GPU call) and relays rank 0's
+    line; a WORLD_SIZE that contradicts --gpus is an error, not a silent 1-GPU run."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, VLNI_BENCH_DRY_RUN="1"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line == {"n_gpus": 2, "ranks": [[0, 0], [1, 1]]}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

@@ -1,0 +1,131 @@
+"""FlatTrainer against torch.optim.AdamW: the three parameter groups and the stage table of the shipped "variant4" warm-up
+(VLN-HAMT/finetune_src/r2r/agent_cmt.py:82-96, r2r/main.py:202-255), optimizer checkpoints (agent_cmt.py:837-870), and the
+scoping of its gradient-accumulation marks to its own parameters."""
+import pytest
+import torch
+
+from tests.golden.variants import hamt_variant_setup
+from tests.test_hamt_gpu import build_product
+from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+
+pytestmark = pytest.mark.gpu
+LR = 1e-3
+# (contrastive + imagine lr, rest lr, rest trainable) per stage: r2r/main.py:209-212 with args.lr = LR
+STAGES = [(LR * 10, None, False), (LR * 5, LR * 0.1, True), (LR * 0.1, LR * 0.1, True)]
+
+
+def _groups(m):
+    a = list(m.contrastive_alignment_model.parameters())
+    b = list(m.imagine_embeddings.parameters())
+    skip = {id(p) for p in a + b}
+    rest = [p for p in m.parameters() if id(p) not in skip]
+    return a, b, rest
+
+
+def test_param_groups_follow_the_variant4_stage_table():
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_language")
+    et = EpisodeTensors(ep, "cuda")
+    ref, m = build_product(cfg), build_product(cfg)
+    ra, rb, rrest = _groups(ref)
+    opt = torch.optim.AdamW([{"params": ra, "lr": LR}, {"params": rb, "lr": LR}, {"params": rrest, "lr": LR}], weight_decay=0.01)
+    a, b, rest = _groups(m)
+    tr = FlatTrainer(m, lr=LR, groups=[{"params": a, "name": "contrastive_alignment_model"},
+                                       {"params": b, "name": "imagine_embeddings"}, {"params": rest, "name": "rest"}])
+    try:
+        for lr_new, lr_rest, rest_on in STAGES:
+            for p in rrest:
+                p.requires_grad_(rest_on)
+            opt.param_groups[0]["lr"] = opt.param_groups[1]["lr"] = lr_new
+            if lr_rest is not None:
+                opt.param_groups[2]["lr"] = lr_rest
+            tr.set_group("contrastive_alignment_model", lr=lr_new)
+            tr.set_group("imagine_embeddings", lr=lr_new)
+            tr.set_group("rest", lr=lr_rest, trainable=rest_on)
+            for _ in range(2):
+                opt.zero_grad(set_to_none=True)
+                run_episode(ref, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+                torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.grad is not None], 40.0)
+                opt.step()
+                tr.zero_grad()
+                run_episode(m, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+                tr.step()
+            worst = 0.0
+            for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+                worst = max(worst, (p - q).abs().max().item())
+                if not rest_on and id(q) in {id(x) for x in rrest}:
+                    assert torch.equal(p, q), n                   # a frozen group is not touched at all (no weight decay either)
+            # Adam turns rounding noise on ~zero gradients into +-lr: the bound is a few learning rates, the typical error far lower
+            assert worst < 4 * 2 * lr_new, (lr_new, worst)
+            mean = torch.cat([(p - q).abs().reshape(-1) for p, q in zip(m.parameters(), ref.parameters())]).mean().item()
+            assert mean < 2e-5, mean
+        # per-group step counts: the rest group sat out stage 1
+        sd, sr = tr.state_dict(), opt.state_dict()
+        assert [len(g["params"]) for g in sd["param_groups"]] == [len(g["params"]) for g in sr["param_groups"]]
+        i_rest = sd["param_groups"][2]["params"][0]
+        assert float(sd["state"][i_rest]["step"]) == float(sr["state"][i_rest]["step"]) == 4.0
+        assert float(sd["state"][0]["step"]) == float(sr["state"][0]["step"]) == 6.0
+    finally:
+        tr.close()
+
+
+def test_optimizer_state_dict_round_trip():
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_language")
+    et = EpisodeTensors(ep, "cuda")
+
+    def steps(tr, m, n):
+        for _ in range(n):
+            tr.zero_grad()
+            run_episode(m, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+            tr.step()
+
+    m1 = build_product(cfg)
+    t1 = FlatTrainer(m1, lr=LR)
+    steps(t1, m1, 2)
+    sd_opt, sd_model = t1.state_dict(), {k: v.clone() for k, v in m1.state_dict().items()}
+    steps(t1, m1, 1)
+    final1 = t1.flat_p.clone()
+    t1.close()
+    m2 = build_product(cfg)
+    m2.load_state_dict(sd_model)
+    t2 = FlatTrainer(m2, lr=LR)
+    try:
+        t2.load_state_dict(sd_opt)
+        assert t2.step_no == 2 and float(t2.gstate[0]) == 2.0
+        steps(t2, m2, 1)
+        d = (t2.flat_p - final1).abs()
+        # moments and bias corrections resumed: a restart from zero moments moves EVERY element by ~lr in step 3; what is left is
+        # Adam's amplification of atomics-order noise on ~zero gradients
+        assert d.max().item() < 5e-4 and d.mean().item() < 1e-6, (d.max().item(), d.mean().item())
+        # and the layout is what torch.optim.AdamW loads
+        plist = [p for p in m2.parameters() if p.requires_grad]
+        opt = torch.optim.AdamW(plist, lr=LR)
+        tmpl = opt.state_dict()
+        tmpl["state"] = sd_opt["state"]
+        opt.load_state_dict(tmpl)
+        assert torch.equal(opt.state[plist[3]]["exp_avg"].cpu(), sd_opt["state"][3]["exp_avg"].cpu())
+    finally:
+        t2.close()
+
+
+def test_marks_are_scoped_to_the_trainers_parameters():
+    """A second model in the process keeps plain autograd accumulation while a FlatTrainer is alive."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_language")
+    et = EpisodeTensors(ep, "cuda")
+    ma, mb, mc = build_product(cfg), build_product(cfg), build_product(cfg)
+    tr = FlatTrainer(ma)
+    try:
+        run_episode(mb, et, criterion=ops.cross_entropy_sum)["loss"].backward()      # trainer alive, model b is not its model
+        assert not ops._WQ
+    finally:
+        tr.close()
+    run_episode(mc, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+    for (n, p), (_, q) in zip(mb.named_parameters(), mc.named_parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if p.grad is not None:
+            assert torch.equal(p.grad, q.grad) or (p.grad - q.grad).abs().max().item() <= 1e-6 * max(1.0, q.grad.abs().max().item()), n

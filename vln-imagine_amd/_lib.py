@@ -64,6 +64,9 @@ SIGNATURES = {
     "vlni_duet_fuse_bwd": [P, P, P, P, I, I, I, P],
     "vlni_optim_prepare": [P, F, F, F, P, P],
     "vlni_adamw_step_dev": [P, P, P, P, P, L, P, F, F, F, F, P, P],
+    "vlni_optim_prepare_groups": [P, F, F, F, P, P, P, I, I, P],
+    "vlni_adamw_step_groups": [P, P, P, P, P, I, L, P, P, P, I, F, F, F, F, P, P],
+    "vlni_scale_cast": [I, I, P, P, L, F, P],
 }
 
 

@@ -5,6 +5,7 @@
 
 #define VLNI_F32 0
 #define VLNI_BF16 1
+#define VLNI_F16 2
 
 // error codes returned by every extern "C" entry point
 #define VLNI_OK 0

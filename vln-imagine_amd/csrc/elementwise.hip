@@ -423,6 +423,89 @@ __global__ __launch_bounds__(256) void adamw_dev_kernel(float* __restrict__ p, c
   }
 }
 
+// ---- parameter groups (the optimizer the shipped "variant4" warm-up builds: VLN-HAMT/finetune_src/r2r/agent_cmt.py:82-96,
+// r2r/main.py:202-255): the arena is laid out group by group, grp_end[k] = first element past group k; per group the learning
+// rate (grp_lr[k]) and a trainable flag (grp_lr[ngrp + k]) live in device memory, so a stage change is a small device write and a
+// captured step replays it. A group that is off is skipped altogether (torch.optim skips parameters without a gradient: no weight
+// decay, no moment update, no step count). gstate[4k..4k+2] = (t, 1 - beta1^t, 1 - beta2^t) of group k.
+// state (8 floats): [0] clip factor x 1/loss-scale, [3] calls so far, [4] loss scale S (1 unless set), [5] 1 = step skipped
+// (non-finite gradients under dynamic loss scaling), [6] good steps since the last change of S, [7] unscaled gradient norm.
+__global__ void optim_prepare_groups_kernel(const float* sumsq, float max_norm, float b1, float b2, float* state, float* gstate,
+                                            const float* grp_lr, int ngrp, int growth_interval) {
+  const int k = threadIdx.x;
+  const float S = state[4] > 0.f ? state[4] : 1.f;
+  const float ss = sumsq[0];
+  const bool finite = ss == ss && ss < 3.0e38f;
+  const bool skip = growth_interval > 0 && !finite;             // GradScaler semantics: drop the step, halve the scale
+  if (k < ngrp && !skip && grp_lr[ngrp + k] != 0.f) {
+    const float t = gstate[4 * k] + 1.f;
+    gstate[4 * k] = t;
+    gstate[4 * k + 1] = 1.f - powf(b1, t);
+    gstate[4 * k + 2] = 1.f - powf(b2, t);
+  }
+  if (k == 0) {
+    const float norm = sqrtf(ss) / S;
+    state[3] += 1.f;
+    state[7] = norm;
+    state[5] = skip ? 1.f : 0.f;
+    state[0] = skip ? 0.f : fminf(1.f, max_norm / (norm + 1e-6f)) / S;
+    if (growth_interval > 0) {
+      if (skip) { state[4] = fmaxf(S * 0.5f, 1.f); state[6] = 0.f; }
+      else if (state[6] + 1.f >= (float)growth_interval) { state[4] = fminf(S * 2.f, 16777216.f); state[6] = 0.f; }
+      else state[6] += 1.f;
+    }
+  }
+}
+
+template <typename SH>        // SH: type of the compute-dtype mirror of the parameters (__bf16 or _Float16)
+__global__ __launch_bounds__(256) void adamw_groups_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, SH* __restrict__ shadow, long n,
+                                                           const long* __restrict__ grp_end, const float* __restrict__ grp_lr,
+                                                           const float* __restrict__ gstate, int ngrp, float b1, float b2,
+                                                           float eps, float wd, const float* __restrict__ state) {
+  if (state[5] != 0.f) return;                                   // skipped step: parameters, moments and mirror stay
+  const float cc = state[0];
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+    int k = 0;
+    while (k + 1 < ngrp && i >= grp_end[k]) ++k;                 // groups start on 8-element boundaries: a float4 never straddles
+    if (grp_lr[ngrp + k] == 0.f) continue;
+    const float lr = grp_lr[k], bc1 = gstate[4 * k + 1], rbc2 = 1.f / sqrtf(gstate[4 * k + 2]);
+    f32x4 pv = *(f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gg = gv[j] * cc;
+      pv[j] *= (1.f - lr * wd);
+      mv[j] = b1 * mv[j] + (1.f - b1) * gg;
+      vv[j] = b2 * vv[j] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(vv[j]) * rbc2 + eps;
+      pv[j] -= (lr / bc1) * mv[j] / denom;
+    }
+    *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
+    if (shadow) {
+      typedef SH sh4 __attribute__((ext_vector_type(4)));
+      sh4 s = {(SH)pv[0], (SH)pv[1], (SH)pv[2], (SH)pv[3]};
+      *(sh4*)(shadow + i) = s;
+    }
+  }
+}
+
+// dst = (OUT)(src * scale): the gradient all-reduce payload (float32 arena -> bf16 with the 1/world pre-division, and back)
+template <typename IN, typename OUT>
+__global__ __launch_bounds__(256) void scale_cast_kernel(const IN* __restrict__ src, OUT* __restrict__ dst, long n, float scale) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const long stride = (long)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    f32x4 x = DT<IN>::ld4(src + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] *= scale;
+    DT<OUT>::st4(dst + i, x);
+  }
+  if (i < n && i + 3 >= n)
+    for (long j = i; j < n; ++j) DT<OUT>::st(dst + j, DT<IN>::ld(src + j) * scale);
+}
+
 // DUET global/local logit fusion (VLN-DUET/map_nav_src/models/vilmodel.py:1198-1217) as one gather / one scatter:
 //   fused[b,0] = gl[b,0] + ll[b,0];  fused[b,g] = gl[b,g] + (src[b,g] >= 0 ? ll[b,src] : src == -2 ? sum_{j: bw[b,j]} ll[b,j] : 0)
 // src / bw come from the host-side plan (which map node is which local candidate; which candidates are visited).
@@ -762,6 +845,48 @@ extern "C" int vlni_adamw_step_dev(float* p, const float* g, float* m, float* v,
   dim3 grid((unsigned)std::min<long>(4096, (n / 4 + 255) / 256)), block(256);
   hipLaunchKernelGGL(adamw_dev_kernel, grid, block, 0, (hipStream_t)stream, p, g, m, v, (__bf16*)bf16_shadow, n, lr_dev, beta1,
                      beta2, eps, weight_decay, state);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+// Parameter-group form of the two calls above (see optim_prepare_groups_kernel): ngrp <= 8 contiguous groups of the arena.
+// growth_interval > 0 switches dynamic loss scaling on (torch.cuda.amp.GradScaler: VLN-DUET/pretrain_src/train_r2r.py:201-234):
+// state[4] holds the scale the caller multiplied the loss by; non-finite gradients skip the step and halve it.
+extern "C" int vlni_optim_prepare_groups(const float* sumsq, float max_norm, float beta1, float beta2, float* state, float* gstate,
+                                         const float* grp_lr, int ngrp, int growth_interval, void* stream) {
+  VLNI_CHECK(sumsq && state && gstate && grp_lr && ngrp >= 1 && ngrp <= 8, VLNI_EINVAL, "optim_prepare_groups: ngrp=%d (1..8)", ngrp);
+  hipLaunchKernelGGL(optim_prepare_groups_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sumsq, max_norm, beta1, beta2, state, gstate,
+                     grp_lr, ngrp, growth_interval);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_adamw_step_groups(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long n,
+                                      const long* grp_end, const float* grp_lr, const float* gstate, int ngrp, float beta1,
+                                      float beta2, float eps, float weight_decay, const float* state, void* stream) {
+  VLNI_CHECK(n > 0 && n % 4 == 0 && grp_end && grp_lr && gstate && state && ngrp >= 1 && ngrp <= 8, VLNI_EINVAL,
+             "adamw_step_groups: n=%ld (multiple of 4), ngrp=%d (1..8), tables non-null", n, ngrp);
+  VLNI_CHECK(shadow == nullptr || shadow_dtype == VLNI_BF16 || shadow_dtype == VLNI_F16, VLNI_EINVAL,
+             "adamw_step_groups: mirror dtype %d (bf16 or f16)", shadow_dtype);
+  dim3 grid((unsigned)std::min<long>(4096, (n / 4 + 255) / 256)), block(256);
+  if (shadow_dtype == VLNI_F16)
+    hipLaunchKernelGGL(adamw_groups_kernel<_Float16>, grid, block, 0, (hipStream_t)stream, p, g, m, v, (_Float16*)shadow, n, grp_end,
+                       grp_lr, gstate, ngrp, beta1, beta2, eps, weight_decay, state);
+  else
+    hipLaunchKernelGGL(adamw_groups_kernel<__bf16>, grid, block, 0, (hipStream_t)stream, p, g, m, v, (__bf16*)shadow, n, grp_end,
+                       grp_lr, gstate, ngrp, beta1, beta2, eps, weight_decay, state);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+// dst[i] = (out dtype)(src[i] * scale); float32 <-> bfloat16 (the bf16 gradient all-reduce payload, pre-divided by the world size)
+extern "C" int vlni_scale_cast(int dt_in, int dt_out, const void* src, void* dst, long n, float scale, void* stream) {
+  VLNI_CHECK(n > 0 && src && dst && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, VLNI_EINVAL, "scale_cast: n=%ld / alignment", n);
+  dim3 grid((unsigned)std::min<long>(4096, (n / 4 + 255) / 256)), block(256);
+  if (dt_in == VLNI_F32 && dt_out == VLNI_BF16)
+    hipLaunchKernelGGL((scale_cast_kernel<float, __bf16>), grid, block, 0, (hipStream_t)stream, (const float*)src, (__bf16*)dst, n, scale);
+  else if (dt_in == VLNI_BF16 && dt_out == VLNI_F32)
+    hipLaunchKernelGGL((scale_cast_kernel<__bf16, float>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, (float*)dst, n, scale);
+  else if (dt_in == VLNI_F32 && dt_out == VLNI_F32)
+    hipLaunchKernelGGL((scale_cast_kernel<float, float>), grid, block, 0, (hipStream_t)stream, (const float*)src, (float*)dst, n, scale);
+  else VLNI_CHECK(false, VLNI_EUNSUP, "scale_cast: dtypes %d -> %d", dt_in, dt_out);
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

@@ -528,14 +528,12 @@ def _split_rows(t, sizes):
     return out
 
 
-# When True (set by train.FlatTrainer) parameter gradients are accumulated by the kernels straight into the
+# Parameters that train.FlatTrainer marked (`_vlni_direct`) get their gradients accumulated by the kernels straight into the
 # pre-allocated `.grad` arena views (wgrad atomics, colsum, LayerNorm dgamma/dbeta, embedding scatter) and the
-# autograd functions return None for them: no zero-filled temporaries, no AccumulateGrad add kernels.
-DIRECT_GRAD = False
-
-
+# autograd functions return None for them: no zero-filled temporaries, no AccumulateGrad add kernels. The mark is per
+# parameter, so a second model in the same process keeps plain autograd accumulation.
 def _direct(*params):
-    return DIRECT_GRAD and all(p is not None and p.grad is not None for p in params)
+    return all(p is not None and p.grad is not None and getattr(p, "_vlni_direct", False) for p in params)
 
 
 def _packed_grad(params):
@@ -581,10 +579,9 @@ def _bgrad_to(params, dy):
     return tuple(_split_rows(colsum(dy), [q.shape[0] for q in params]))
 
 
-# Deferred weight gradients (set by train.FlatTrainer together with DIRECT_GRAD): the (dY, X) pairs of a parameter are
+# Deferred weight gradients (parameters marked `_vlni_defer` by train.FlatTrainer): the (dY, X) pairs of a parameter are
 # queued during backward and reduced by ONE grouped transposing-read GEMM per parameter at flush time, i.e. one launch
 # with a T-times longer reduction instead of T short split-K launches. 288 GB of HBM make keeping dY alive free.
-DEFER_WGRAD = False
 TN_BIG = True            # 256 x 256 tiles for episode-long reductions (+10..26 % there, tools/tn_probe.py)
 TN_VARIANT = 5          # LDS-DMA 2-stage, 8 waves: fastest of the five on every episode-level shape (tools/tn_probe.py)
 _WQ = {}
@@ -656,34 +653,49 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev):
     return v, sp
 
 
-def flush_wgrads():
-    """Runs the queued weight/bias gradient reductions (must precede any read of the .grad arena)."""
+def flush_wgrads(lo=None, hi=None):
+    """Runs the queued weight/bias gradient reductions (must precede any read of the .grad arena). With (lo, hi): only the
+    gradients whose address lies in [lo, hi), in address order (train.FlatTrainer's flush -> all-reduce pipeline)."""
     entries, dev = [], None
-    for wv, bv, segs in _WQ.values():
+    if lo is None:
+        todo = list(_WQ)
+    else:
+        todo = sorted(k for k in _WQ if lo <= k < hi)
+    for key in todo:
+        wv, bv, segs = _WQ.pop(key)
         dev = wv.device
-        for c in range(0, len(segs), 16):
+        N, K = segs[0][0].shape[1], segs[0][1].shape[1]
+        plans, tot = [], 0                 # a gradient with more than 16 segments (an episode of > 8 steps through a shared module)
+        for c in range(0, len(segs), 16):  # takes several grouped launches; their row splits all land in ONE slab workspace
             chunk = segs[c:c + 16]
             n = len(chunk)
-            N, K = chunk[0][0].shape[1], chunk[0][1].shape[1]
             pa = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in chunk])
             pb = (ctypes.c_void_p * n)(*[x.data_ptr() for _, x in chunk])
             pm = (ctypes.c_int * n)(*[d.shape[0] for d, _ in chunk])
             nmt = sum((d.shape[0] + 63) // 64 for d, _ in chunk)
             variant, split = _tn_choice(n, pa, pb, pm, N, K, nmt, wv.device)
-            if _parts_ok(variant, nmt, split) and wv.is_contiguous() and bv.is_contiguous() and N % 4 == 0:
-                eff = _eff_split(nmt, split)[0]
-                key = (wv.data_ptr(), c, N, K)                   # one workspace per gradient, grown to the largest split seen
-                buf = _PART_BUFS.get(key)
-                if buf is None or buf.numel() < eff * (N * K + N):
-                    buf = _PART_BUFS[key] = torch.empty((eff * (N * K + N),), dtype=torch.float32, device=wv.device)
-                cpart = buf.data_ptr() + 4 * eff * N * K                 # [eff][N] column-sum partials behind the [eff][N][K] slabs
-                _lib.call("vlni_gemm_tn_bf16_grouped_part", n, pa, pb, pm, N, K, buf.data_ptr(), N * K, N, K, cpart, split, variant, _st())
-                entries.append((wv.data_ptr(), buf.data_ptr(), N * K // 4, N * K // 4, eff))
-                entries.append((bv.data_ptr(), cpart, N // 4, N // 4, eff))
-            else:
+            parts = _parts_ok(variant, nmt, split) and wv.is_contiguous() and bv.is_contiguous() and N % 4 == 0
+            eff = _eff_split(nmt, split)[0] if parts else 0
+            plans.append((n, pa, pb, pm, variant, split, tot if parts else -1))
+            tot += eff
+        buf = None
+        if tot:
+            key = (wv.data_ptr(), N, K)                      # one workspace per gradient, grown to the largest split count seen
+            buf = _PART_BUFS.get(key)
+            if buf is None or buf.numel() < tot * (N * K + N):
+                buf = _PART_BUFS[key] = torch.empty((tot * (N * K + N),), dtype=torch.float32, device=wv.device)
+            cpart = buf.data_ptr() + 4 * tot * N * K         # [tot][N] column-sum partials behind the [tot][N][K] slabs
+        for n, pa, pb, pm, variant, split, z0 in plans:
+            if z0 >= 0:
+                _lib.call("vlni_gemm_tn_bf16_grouped_part", n, pa, pb, pm, N, K, buf.data_ptr() + 4 * z0 * N * K, N * K, N, K,
+                          cpart + 4 * z0 * N, split, variant, _st())
+            else:                                            # unsplit (or register-staged) launch: float atomics straight into the arena
                 _lib.call("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
                           split, variant, _st())
-    _WQ.clear()
+        if tot:
+            # exactly ONE reduction entry per destination: reduce_parts_kernel's read-modify-write of dst is not atomic
+            entries.append((wv.data_ptr(), buf.data_ptr(), N * K // 4, N * K // 4, tot))
+            entries.append((bv.data_ptr(), cpart, N // 4, N // 4, tot))
     if entries:
         sig = tuple(entries)
         tab = _PART_TABLES.get(sig)
@@ -704,7 +716,7 @@ def _wb_grad_to(ws, bs, dy, x):
         wv = _packed_grad(ws) if len(ws) > 1 else ws[0].grad
         bv = _packed_grad(bs) if len(bs) > 1 else bs[0].grad
         if wv is not None and bv is not None:
-            if DEFER_WGRAD and dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() \
+            if getattr(ws[0], "_vlni_defer", False) and dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() \
                     and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
                 ent = _WQ.get(wv.data_ptr())
                 if ent is None:
