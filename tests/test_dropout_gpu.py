@@ -212,7 +212,7 @@ def test_graph_replay_draws_fresh_masks(monkeypatch):
             return loss
 
         step = tr.capture(fwd_bwd, warmup=1)
-        p0, m0, v0, st0 = tr.flat_p.clone(), tr.m.clone(), tr.v.clone(), tr.state.clone()
+        p0, m0, v0, st0, gs0 = tr.flat_p.clone(), tr.m.clone(), tr.v.clone(), tr.state.clone(), tr.gstate.clone()
         l1 = float(step().detach())
         base1 = int(step.seed_base.item())
         p1 = tr.flat_p.clone()
@@ -221,7 +221,7 @@ def test_graph_replay_draws_fresh_masks(monkeypatch):
         # eager twin: same start, same base value, same host seeds -> same first step
         m2 = build_product(cfg).train()
         tr2 = FlatTrainer(m2, lr=1e-3)
-        tr2.flat_p.copy_(p0); tr2.m.copy_(m0); tr2.v.copy_(v0); tr2.state.copy_(st0)
+        tr2.flat_p.copy_(p0); tr2.m.copy_(m0); tr2.v.copy_(v0); tr2.state.copy_(st0); tr2.gstate.copy_(gs0)
         ops.SHADOWS.invalidate()
         step.seed_base.fill_(base1)
         tr2.zero_grad()

@@ -60,12 +60,12 @@ def test_fp32_full_depth_fwd_bwd_matches_cpu_oracle(family, B):
     r = compare_runs(out, ref, dict(model.named_parameters()), sd, key)
     print(f"\n[{family} fp32 HIP vs CPU oracle, full depth, B={B}] {r}")
     assert r["loss_abs"] <= 1e-4 and r["logit_max_abs"] <= 1e-4, r            # BASELINE.json north_star tolerance
-    assert r["grad_rel_l2"] <= 2e-4 and r["grad_worst_param_rel_l2"] <= 5e-3, r
+    assert r["grad_rel_l2"] <= 2e-5 and r["grad_worst_param_rel_l2"] <= 5e-3, r          # measured 1.0e-6 / 1.5e-6
     assert r["params_compared"] > 100
 
 
 # measured on MI355X (this test's own print), x 2:        loss_abs, logit_max_abs, grad_rel_l2, worst single parameter
-BF16_BOUNDS = {"hamt": (3e-2, 0.15, 0.1, 0.5), "duet": (3e-2, 0.15, 0.1, 0.5)}
+BF16_BOUNDS = {"hamt": (5e-4, 0.07, 0.18, 0.5), "duet": (2e-4, 0.032, 0.17, 0.5)}   # measured: 2.3e-4 / 0.033 / 0.089; 9.4e-5 / 0.0155 / 0.083
 
 
 @pytest.mark.parametrize("family,B", [("hamt", 64), ("duet", 32)])

@@ -447,7 +447,7 @@ def test_wgrad_partials_reject_register_staged_kernel(ops):
                   2, 5, torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32])
 def test_gemm_variants_identical(ops, variant):
     """All GEMM pipelines (register-staged, LDS-DMA 2/3-stage with 4 or 8 waves, large tiles 256x128 / 256x256 / 128x256) give
     bit-identical results, incl. epilogues and ragged tile edges."""
@@ -463,7 +463,7 @@ def test_gemm_variants_identical(ops, variant):
             assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (variant, dtype, M, N, K)
 
 
-@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32])
 def test_gemm_dual_launch_variants(ops, variant):
     """Two problems in one launch (language + vision stream) == two single launches, for every tile geometry."""
     saved = (ops.AUTOTUNE, ops.GEMM_VARIANTS)
@@ -486,7 +486,7 @@ def test_gemm_dual_launch_variants(ops, variant):
         ops._GEMM_BEST.clear()
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 32])
 def test_gemm_nn_weight_layout_matches_transposed_copy(ops, variant):
     """dgrad straight from W[out, in] (transposing LDS reads, variant + 16) == the NT kernel on an explicit W^T copy, bit for bit,
     incl. GELU' / residual epilogues, ragged rows and a partial column tile (zero page)."""
@@ -507,3 +507,46 @@ def test_gemm_nn_weight_layout_matches_transposed_copy(ops, variant):
     w0, w1 = _rand((768, 2304), torch.bfloat16, 57, 0.05), _rand((768, 2304), torch.bfloat16, 58, 0.05)
     o0, o1 = ops.gemm_nt2((a0, a1), (ops.KN(w0), ops.KN(w1)))
     assert torch.equal(o0, ops.gemm_nt(a0, w0.t().contiguous())) and torch.equal(o1, ops.gemm_nt(a1, ops.KN(w1)))
+
+
+@pytest.mark.parametrize("nn,pk", [(False, 14), (True, 6), (False, 15), (True, 7), (False, 32), (True, 32)])
+def test_gemm_persistent_kernel_streams_many_tiles(ops, nn, pk):
+    """The persistent kernel (variant 14; 16 + 6 with the weight as [K, N]) at the bench's row counts: > 512 tiles, so every block walks
+    several tiles through its two LDS stages (next tile's first k-tile prefetched under the epilogue), two problems per launch, every
+    epilogue kind (bias + GELU + stored pre-activation, GELU' + residual, dropout), ragged last row tile. Bit-identical to variant 1 / 5."""
+    base = 16 if nn else 0
+    ref_v, pk_v = (16 + 5, 16 + pk) if nn else (1, pk)
+    K = 768
+    for N in (768, 2304):
+        M0, M1 = 5504, 2752 + 37
+        a0, a1 = _rand((M0, K), torch.bfloat16, 61, 0.5), _rand((M1, K), torch.bfloat16, 62, 0.5)
+        w0, w1 = _rand((N, K), torch.bfloat16, 63, 0.05), _rand((N, K), torch.bfloat16, 64, 0.05)
+        if nn:                                          # operands of the dgrad form: B given as [K, N]
+            w0, w1 = w0.t().contiguous(), w1.t().contiguous()
+        bias = (_rand((N,), torch.float32, 65, 0.1), _rand((N,), torch.float32, 66, 0.1))
+        res = (_rand((M0, N), torch.bfloat16, 67, 0.5), _rand((M1, N), torch.bfloat16, 68, 0.5))
+        zsrc = (_rand((M0, N), torch.bfloat16, 69, 1.0), _rand((M1, N), torch.bfloat16, 70, 1.0))
+        for kind in ("gelu_preact", "dact_res", "drop_res"):
+            outs = []
+            for v in (ref_v, pk_v):
+                saved = (ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.NN_VARIANTS)
+                try:
+                    ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.NN_VARIANTS = True, (v - base,), (v - base,)
+                    ops._GEMM_BEST.clear()
+                    b = (ops.KN(w0), ops.KN(w1)) if nn else (w0, w1)
+                    if kind == "gelu_preact":
+                        z = (torch.empty((M0, N), dtype=torch.bfloat16, device="cuda"), torch.empty((M1, N), dtype=torch.bfloat16, device="cuda"))
+                        o = ops.gemm_nt2((a0, a1), b, bias=bias, act=1, preact=z)
+                        outs.append(o + z)
+                    elif kind == "dact_res":
+                        outs.append(ops.gemm_nt2((a0, a1), b, dact_src=zsrc, dact=1, residual=res))
+                    else:
+                        outs.append(ops.gemm_nt2((a0, a1), b, bias=bias, residual=res, drop=(0.1, (1234, 777))))
+                    # and the single-problem entry point on the longer stream
+                    bs = ops.KN(w0) if nn else w0
+                    outs[-1] = tuple(outs[-1]) + (ops.gemm_nt(a0, bs, bias=bias[0], residual=res[0]),)
+                finally:
+                    ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.NN_VARIANTS = saved
+                    ops._GEMM_BEST.clear()
+            for x, y in zip(outs[0], outs[1]):
+                assert torch.equal(x, y), (nn, N, kind)

@@ -1306,6 +1306,363 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnP p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT form of the 128 x 128 LDS-DMA kernel (variant 14, variant 22 = B as [K,N]): <= 512 blocks (two per CU, 8 waves each)
+// walk the tile list; the k-tiles of consecutive tiles form ONE stream through the two LDS stages, so only a block's first tile has
+// a prologue, and the epilogue never touches LDS: the MFMA operands are swapped (D^T = B A^T), which leaves a lane with one output
+// ROW and 8 x 4 consecutive COLUMNS in its accumulators; four v_permlane32_swap per 16-column group turn that into 8 consecutive
+// columns per lane, so bias / GELU / GELU' / dropout / residual run in registers with 16-byte global accesses while the LDS-DMA of
+// the next tile's first k-tile is already in flight (issued before the last k-tile's MFMAs). In the per-launch kernels above
+// prologue + epilogue are ~35 % of a 128 x 128 x 768 tile (2.8 k + 7.6 k of 29.5 k cycles) and fully exposed.
+// Wave grid 4 (M) x 2 (N), a wave owns 32 rows x 64 columns = 2 accumulators: the four stores of a wave cover whole 128-byte lines.
+// Same k order and the same products as every other variant -> bit-identical results.
+struct PkSide { const char* A; long lda; const char* B; long ldb; int M, m0, n0; };
+
+__device__ __forceinline__ void pk_locate(const GemmP& p, int tile, PkSide& s) {
+  int w = tile;
+  if (w >= p.tiles0) { w -= p.tiles0; s.A = p.A1; s.lda = p.lda1; s.B = p.B1; s.ldb = p.ldb1; s.M = p.M1; }
+  else { s.A = p.A; s.lda = p.lda; s.B = p.B; s.ldb = p.ldb; s.M = p.M; }
+  const int ntn = (p.N + BN - 1) / BN;
+  if (p.group_m <= 1) { s.m0 = (w / ntn) * BM; s.n0 = (w % ntn) * BN; return; }
+  const int ntm = (s.M + BM - 1) / BM;
+  const int per = p.group_m * ntn;
+  const int g = w / per, idx = w - g * per;
+  const int first = g * p.group_m, gsz = min(ntm - first, p.group_m);
+  s.m0 = (first + idx % gsz) * BM;
+  s.n0 = (idx / gsz) * BN;
+}
+
+// Epilogue of one 128 x 128 tile straight from the (transposed) accumulators of the persistent kernels: wave (wr, wc) of the 4 x 2 grid owns
+// rows wr*32.. and columns wc*64.., lane = row, registers = columns; zeroes the accumulators for the next tile.
+__device__ __forceinline__ void pk_epilogue(const GemmP& p, int tile, const PkSide& cur, f32x16 (&acc)[2], int wr, int wc, int r, int h,
+                                            unsigned dseed0, unsigned dseed1) {
+  using T = __bf16;
+  const bool p1 = tile >= p.tiles0;
+  const float* bias = p1 ? p.bias1 : p.bias;
+  const T* res = (const T*)(p1 ? p.residual1 : p.residual); const long ldr = p1 ? p.ldr1 : p.ldr;
+  T* pre = (T*)(p1 ? p.preact1 : p.preact); const long ldp = p1 ? p.ldp1 : p.ldp;
+  const T* dsrc = (const T*)(p1 ? p.dact_src1 : p.dact_src); const long ldd = p1 ? p.ldd1 : p.ldd;
+  T* C = (T*)(p1 ? p.C1 : p.C); const long ldc = p1 ? p.ldc1 : p.ldc;
+  const unsigned dseed = p1 ? dseed1 : dseed0;
+  const int m = cur.m0 + wr * 32 + r;
+  const bool mok = m < cur.M;
+  const int mc = min(m, cur.M - 1);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int col = cur.n0 + wc * 64 + j * 32 + 16 * q + 8 * h;          // this lane's 8 consecutive columns after the swaps
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // scalar copies + __float_as_uint: __builtin_bit_cast applied to an ext_vector ELEMENT makes clang (ROCm 7.2) pass the
+        // same value for both operands of every swap (one v_permlane32_swap for all eight) - checked in the .ll / .s
+        const float lo = acc[j][8 * q + u], hi = acc[j][8 * q + 4 + u];
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+        v[u] = __uint_as_float(sw[0]);
+        v[4 + u] = __uint_as_float(sw[1]);
+      }
+      if (col < p.N) {                                                     // N % 8 == 0: a lane's 8 columns are all-in or all-out
+        if (bias) {
+          const f32x4 b0 = *(const f32x4*)(bias + col), b1 = *(const f32x4*)(bias + col + 4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { v[u] = v[u] * p.alpha + b0[u]; v[4 + u] = v[4 + u] * p.alpha + b1[u]; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] *= p.alpha;
+        }
+        if (pre && mok) {
+          bf16x8 t;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = (T)v[u];
+          *(bf16x8*)(pre + (long)m * ldp + col) = t;
+        }
+        if (p.dact) {
+          const bf16x8 z = *(const bf16x8*)(dsrc + (long)mc * ldd + col);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] *= (p.dact == 1) ? gelu_grad_t<T>((float)z[u]) : ((float)z[u] > 0.f ? 1.f : 0.f);
+        }
+        if (p.act == 1) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = gelu_t<T>(v[u]);
+        } else if (p.act == 2) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = fmaxf(v[u], 0.f);
+        }
+        if (p.drop_thr) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] *= drop_scale((unsigned)m * (unsigned)p.N + col + u, dseed, p.drop_thr, p.drop_inv);
+        }
+        if (res) {
+          const bf16x8 rs = *(const bf16x8*)(res + (long)mc * ldr + col);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] += (float)rs[u];
+        }
+        if (mok) {
+          bf16x8 t;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t[u] = (T)v[u];
+          *(bf16x8*)(C + (long)m * ldc + col) = t;
+        }
+      }
+    }
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[j][x] = 0.f;
+  }
+}
+
+// HACK != 0: timing-only builds that give WRONG results (tools/gemm_step_probe.py, VLNI_PK_HACK): 1 = the B operand's LDS-DMA is issued for a
+// tile's first k-tile only (half the L2 -> LDS bytes), 2 = fragments are read from LDS for the first k16 step of a k-tile only (a quarter
+// of the LDS reads), 3 = both. They price the vector-memory pipe and the LDS read bandwidth against the MFMA time of this loop.
+template <bool NN, int HACK = 0>
+__global__ __launch_bounds__(512, 4) void gemm_pk_kernel(GemmP p, int ntiles) {
+  using T = __bf16;
+  constexpr int BK = 64, NW = 8, STAGE = (BM + BN) * ROWB;
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  // this block's tiles: the XCD's contiguous chunk of the (grouped) tile list, walked with the XCD's block count as stride, so the
+  // tiles an XCD works on at any time are neighbours that share operand panels in its L2
+  const int bid = blockIdx.x, xcd = bid & 7, gx = gridDim.x >> 3;
+  const int q8 = ntiles >> 3, rr = ntiles & 7;
+  const int c0 = xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8;
+  const int c1 = c0 + q8 + (xcd < rr ? 1 : 0);
+  int tile = c0 + (bid >> 3);
+  if (tile >= c1) return;
+  const int nk = p.K / BK;
+
+  // ---- issue side: per-lane source pointers of this wave's 2 + 2 LDS-DMA instructions per k-tile ----
+  const char* zp = (const char*)g_zero_page;
+  asm volatile("" : "+s"(zp));
+  const unsigned lds0 = lds_u32(dsmem);
+  const char* ga[2];
+  const char* gb[2];
+  unsigned bstep[2];                                       // bytes per k-tile of the B pointers (0 for zero-page lanes)
+  auto point_at = [&](const PkSide& s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (i * NW + wave) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      ga[i] = s.A + ((long)min(s.m0 + row, s.M - 1) * s.lda) * 2 + c * 16;
+      if constexpr (NN) {
+        const int krow = (i * NW + wave) * 4 + (lane >> 4);                    // 4 k-rows of 256 B per LDS-DMA instruction
+        const int cc = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
+        const bool ok = s.n0 + cc * 8 < p.N;
+        gb[i] = ok ? s.B + ((long)krow * s.ldb + s.n0 + cc * 8) * 2 : zp;
+        bstep[i] = ok ? (unsigned)(BK * s.ldb * 2) : 0u;
+      } else {
+        gb[i] = s.B + ((long)min(s.n0 + row, p.N - 1) * s.ldb) * 2 + c * 16;
+        bstep[i] = ROWB;
+      }
+    }
+  };
+  // one of the wave's four LDS-DMA instructions of a k-tile (piece 0 / 2: A rows, 1 / 3: B rows); pointers advance with the piece
+  auto issue_piece = [&](int stage, int piece, bool with_b = true) {
+    const unsigned sa = lds0 + stage * STAGE + wave * 1024;
+    const int i = piece >> 1;
+    if (piece & 1) {
+      if (!(HACK & 1) || with_b) lds_dma16(gb[i], sa + BM * ROWB + i * NW * 1024);
+      gb[i] += bstep[i];
+    } else {
+      lds_dma16(ga[i], sa + i * NW * 1024);
+      ga[i] += ROWB;
+    }
+  };
+  auto issue = [&](int stage, bool with_b = true) {
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) issue_piece(stage, pc, with_b);
+  };
+  const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
+  const int frow = 8 * h + qq, half8 = 8 * (pp & 1);
+  const int chb = (wc * 64 + 16 * cb) / 8 + (pp >> 1);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[j][x] = 0.f;
+  const unsigned dseed0 = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
+  const unsigned dseed1 = p.drop_thr ? eff_seed(p.drop_seed1, p.seed_base) : 0u;
+
+  PkSide cur, nxt;
+  pk_locate(p, tile, cur);
+  point_at(cur);
+  issue(0);
+  int stage = 0;
+  while (true) {
+    const int ntile = tile + gx;
+    const bool more = ntile < c1;
+    for (int kt = 0; kt < nk; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of k-tile kt landed (and its last epilogue's stores)
+      __builtin_amdgcn_s_barrier();                        // everybody's share landed; everybody finished reading the other stage
+      // the next k-tile's LDS-DMA (this tile's, or the first of the block's next tile) goes out right behind the barrier. (Issuing it
+      // piece by piece behind the MFMAs of the k16 steps below was slower: 47.6 vs 43.4 us on the N = 2304 dual launch of a step.)
+      const bool in_tile = kt + 1 < nk;
+      if (!in_tile && more) {
+        pk_locate(p, ntile, nxt);
+        point_at(nxt);
+      }
+      if (in_tile || more) issue(stage ^ 1, !in_tile);
+      const char* As = dsmem + stage * STAGE;
+      const char* Bs = As + BM * ROWB;
+      bf16x8 a, b[2];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (!(HACK & 2) || kk == 0) {
+          a = *(const bf16x8*)(As + lds_off(wr * 32 + r, kk * 2 + h));
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            if constexpr (NN) b[j] = tr_frag(Bs, 16 * kk + frow, chb + 4 * j, half8);
+            else b[j] = *(const bf16x8*)(Bs + lds_off(wc * 64 + j * 32 + r, kk * 2 + h));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a, acc[j], 0, 0, 0);   // D^T: lane = row, regs = columns
+      }
+      stage ^= 1;
+    }
+    pk_epilogue(p, tile, cur, acc, wr, wc, r, h, dseed0, dseed1);
+    if (!more) break;
+    tile = ntile;
+    cur = nxt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The persistent kernel with a DEEPER prefetch at the same two blocks per CU (variants 15 / 32, + 16 for [K,N] weights): the k-tile
+// stream is cut into 32-deep half-steps that travel through a ring of NSLOT 16-KiB slots (4 slots = 64 KiB, 5 = 80 KiB per block), and a
+// half-step is requested NSLOT - 1 barriers before it is read (counted vmcnt, never 0 in steady state). The 2-stage kernels request a
+// 64-deep k-tile ONE barrier ahead, so every step lasts at least one L2 / Infinity-Cache round trip: with the B operand's DMA and three
+// quarters of the LDS reads removed (VLNI_PK_HACK) gemm_pk_kernel still runs ~2 k cycles per k-tile where its MFMAs need 1 k - it is
+// latency-bound per block, not LDS- or MFMA-bound. Here up to (NSLOT - 1) x 32 k of both operands are in flight per block.
+// 64-byte LDS rows: 16-byte chunk c of row r sits in slot c ^ ((r >> 2) & 3), which makes the 16 rows of a ds_read_b128 lane group
+// hit 16 different 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int lds_off32(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+}
+
+template <bool NN, int NSLOT>
+__global__ __launch_bounds__(512, 4) void gemm_pkr_kernel(GemmP p, int ntiles) {
+  constexpr int HK = 32, NW = 8, SLOT = (BM + BN) * 64, D = NSLOT - 1;       // D half-steps requested ahead
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+  const int bid = blockIdx.x, xcd = bid & 7, gx = gridDim.x >> 3;
+  const int q8 = ntiles >> 3, rr = ntiles & 7;
+  const int c0 = xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8;
+  const int c1 = c0 + q8 + (xcd < rr ? 1 : 0);
+  int tile = c0 + (bid >> 3);
+  if (tile >= c1) return;
+  const int S = p.K / HK;                                  // half-steps per tile
+  const int total = ((c1 - 1 - tile) / gx + 1) * S;        // half-steps of this block's whole stream
+
+  // ---- issue side: ONE LDS-DMA instruction per operand, wave and half-step (16 rows x 64 B, or 4 k-rows x 256 B of a [K,N] weight) ----
+  const char* zp = (const char*)g_zero_page;
+  asm volatile("" : "+s"(zp));
+  const unsigned lds0 = lds_u32(dsmem);
+  const char* ga;
+  const char* gb;
+  unsigned bstep;
+  auto point_at = [&](const PkSide& s) {
+    const int row = wave * 16 + (lane >> 2);
+    const int c = (lane & 3) ^ ((row >> 2) & 3);
+    ga = s.A + ((long)min(s.m0 + row, s.M - 1) * s.lda) * 2 + c * 16;
+    if constexpr (NN) {
+      const int krow = wave * 4 + (lane >> 4);
+      const int cc = (lane & 15) ^ (((krow & 3) << 2) | ((krow >> 2) & 3));
+      const bool ok = s.n0 + cc * 8 < p.N;
+      gb = ok ? s.B + ((long)krow * s.ldb + s.n0 + cc * 8) * 2 : zp;
+      bstep = ok ? (unsigned)(HK * s.ldb * 2) : 0u;
+    } else {
+      gb = s.B + ((long)min(s.n0 + row, p.N - 1) * s.ldb) * 2 + c * 16;
+      bstep = 64;
+    }
+  };
+  int islot = 0;                                           // slot of the next half-step to request
+  auto issue = [&]() {
+    const unsigned sa = lds0 + islot * SLOT + wave * 1024;
+    lds_dma16(ga, sa);
+    lds_dma16(gb, sa + BM * 64);
+    ga += 64;
+    gb += bstep;
+    islot = islot == NSLOT - 1 ? 0 : islot + 1;
+  };
+  const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1;
+  const int frow = 8 * h + qq, half8 = 8 * (pp & 1);
+  const int chb = (wc * 64 + 16 * cb) / 8 + (pp >> 1);
+
+  f32x16 acc[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int x = 0; x < 16; ++x) acc[j][x] = 0.f;
+  const unsigned dseed0 = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
+  const unsigned dseed1 = p.drop_thr ? eff_seed(p.drop_seed1, p.seed_base) : 0u;
+
+  // the issue side runs D half-steps ahead of the compute side and crosses tile borders on its own
+  PkSide cur, isd;
+  pk_locate(p, tile, cur);
+  isd = cur;
+  point_at(isd);
+  int itile = tile, is = 0, issued = 0;                    // issue-side tile, its next half-step, half-steps requested so far
+  auto issue_next = [&]() {
+    if (is == S) {                                         // next tile of this block (exists: issued < total)
+      itile += gx;
+      pk_locate(p, itile, isd);
+      point_at(isd);
+      is = 0;
+    }
+    issue();
+    ++is;
+    ++issued;
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (issued < total) issue_next();
+
+  int cslot = 0, g = 0;                                    // slot and stream index of the half-step being computed
+  while (true) {
+    for (int s = 0; s < S; ++s, ++g) {
+      // half-step g of the stream has landed when at most min(D - 1, total - 1 - g) younger half-steps (2 DMAs each) are in flight
+      const int younger = total - 1 - g;
+      if (younger >= D - 1) wait_vm<2 * (D - 1)>();
+      else if (younger == 0) wait_vm<0>();
+      else if (younger == 1) wait_vm<2>();
+      else if (younger == 2) wait_vm<4>();
+      else wait_vm<6>();
+      __builtin_amdgcn_s_barrier();                        // everybody's share landed; everybody finished reading the slot requested next
+      if (issued < total) issue_next();
+      const char* As = dsmem + cslot * SLOT;
+      const char* Bs = As + BM * 64;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 b[2];
+        const bf16x8 a = *(const bf16x8*)(As + lds_off32(wr * 32 + r, kk * 2 + h));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if constexpr (NN) b[j] = tr_frag(Bs, 16 * kk + frow, chb + 4 * j, half8);
+          else b[j] = *(const bf16x8*)(Bs + lds_off32(wc * 64 + j * 32 + r, kk * 2 + h));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a, acc[j], 0, 0, 0);
+      }
+      cslot = cslot == NSLOT - 1 ? 0 : cslot + 1;
+    }
+    pk_epilogue(p, tile, cur, acc, wr, wc, r, h, dseed0, dseed1);
+    if (g >= total) break;
+    tile += gx;
+    pk_locate(p, tile, cur);
+  }
+}
+
 }  // namespace
 
 static int gemm_check_one(int es, const void* A, long lda, const void* B, long ldb, long ldc, int M, int N, int K, bool nn = false) {
@@ -1340,9 +1697,16 @@ static void gemm_big_go(GemmP& p, hipStream_t st) {
   hipLaunchKernelGGL((gemm_nt_big_kernel<T, NST, WM, WN, MI, NJ>), dim3(tiles), dim3(WM * WN * 64), LDS, st, p);
 }
 
+static bool gemm_pk_vec_ok(const GemmP& p) {        // every epilogue tensor allows 16-byte (8 x bf16) accesses
+  auto ok = [](const void* q, long ld) { return q == nullptr || ((((uintptr_t)q) & 15) == 0 && ld % 8 == 0); };
+  auto okb = [](const float* b) { return b == nullptr || (((uintptr_t)b) & 15) == 0; };
+  return ok(p.C, p.ldc) && ok(p.residual, p.ldr) && ok(p.preact, p.ldp) && ok(p.dact_src, p.ldd) && okb(p.bias) &&
+         (p.A1 == nullptr || (ok(p.C1, p.ldc1) && ok(p.residual1, p.ldr1) && ok(p.preact1, p.ldp1) && ok(p.dact_src1, p.ldd1) && okb(p.bias1)));
+}
+
 static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stream) {
-  const bool nn = variant >= 16;                 // B given as [K,N] (the forward weight itself): bf16 dgrad
-  variant &= 15;
+  const bool nn = (variant & 16) != 0;           // B given as [K,N] (the forward weight itself): bf16 dgrad
+  variant = (variant & 15) + ((variant >> 5) << 4);   // ids above 15 are passed as 32 + (id - 16), so that "+ 16" stays the layout flag
   const int es = dtype == VLNI_F32 ? 4 : 2, bk = ROWB / es;
   const int nkt = cdiv(p.K, bk);
   p.kt_per_split = cdiv(nkt, split_k);
@@ -1358,6 +1722,49 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
   if (!glds_ok) variant = 1;
   if (variant >= 6 && (splits > 1 || p.atomic_f32)) variant = 1;       // large tiles: whole-K, plain stores only
   hipStream_t st = (hipStream_t)stream;
+  // persistent 128 x 128 kernel (NT: variant 14, [K,N] weights: variant 6 + 16): bf16, whole K, 8-element vector epilogue
+  const bool pk_ok = dtype == VLNI_BF16 && splits == 1 && !p.atomic_f32 && p.K % 64 == 0 && p.K >= 128 && p.N % 8 == 0 && gemm_pk_vec_ok(p);
+  const int ring = (!nn && variant == 15) || (nn && variant == 7) ? 4 : variant == 16 ? 5 : 0;     // persistent ring kernels: slots
+  if ((variant == 14 && !nn) || (variant == 6 && nn) || ring) {
+    if (pk_ok) {
+      constexpr int LDS = 2 * (BM + BN) * ROWB;
+      static bool attr_pk = false;
+      if (!attr_pk) {
+        (void)hipFuncSetAttribute((const void*)gemm_pk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_pk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_pkr_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+        (void)hipFuncSetAttribute((const void*)gemm_pkr_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+        (void)hipFuncSetAttribute((const void*)gemm_pkr_kernel<false, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
+        (void)hipFuncSetAttribute((const void*)gemm_pkr_kernel<true, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 16384);
+        attr_pk = true;
+      }
+      const int G = 8 * std::min(64, cdiv(tiles, 8));
+      static const int hack = getenv("VLNI_PK_HACK") ? atoi(getenv("VLNI_PK_HACK")) : 0;
+      if (ring == 4) {
+        if (nn) hipLaunchKernelGGL((gemm_pkr_kernel<true, 4>), dim3(G), dim3(512), 4 * 16384, st, p, tiles);
+        else hipLaunchKernelGGL((gemm_pkr_kernel<false, 4>), dim3(G), dim3(512), 4 * 16384, st, p, tiles);
+      } else if (ring == 5) {
+        if (nn) hipLaunchKernelGGL((gemm_pkr_kernel<true, 5>), dim3(G), dim3(512), 5 * 16384, st, p, tiles);
+        else hipLaunchKernelGGL((gemm_pkr_kernel<false, 5>), dim3(G), dim3(512), 5 * 16384, st, p, tiles);
+      } else if (hack && !nn) {
+        static bool attr_h = false;
+        if (!attr_h) {
+          (void)hipFuncSetAttribute((const void*)gemm_pk_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+          (void)hipFuncSetAttribute((const void*)gemm_pk_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+          (void)hipFuncSetAttribute((const void*)gemm_pk_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+          attr_h = true;
+        }
+        if (hack == 1) hipLaunchKernelGGL((gemm_pk_kernel<false, 1>), dim3(G), dim3(512), LDS, st, p, tiles);
+        else if (hack == 2) hipLaunchKernelGGL((gemm_pk_kernel<false, 2>), dim3(G), dim3(512), LDS, st, p, tiles);
+        else hipLaunchKernelGGL((gemm_pk_kernel<false, 3>), dim3(G), dim3(512), LDS, st, p, tiles);
+      } else if (nn) hipLaunchKernelGGL((gemm_pk_kernel<true>), dim3(G), dim3(512), LDS, st, p, tiles);
+      else hipLaunchKernelGGL((gemm_pk_kernel<false>), dim3(G), dim3(512), LDS, st, p, tiles);
+      VLNI_LAUNCH_CHECK();
+      return VLNI_OK;
+    }
+    variant = nn ? 5 : 0;                            // not eligible: the per-launch pipelines
+    if (!nn) variant = (glds_ok && (long)grid.x * grid.z <= 256) ? 3 : 1;
+  }
   if (nn) {
     VLNI_CHECK(splits == 1 && !p.atomic_f32, VLNI_EUNSUP, "gemm_nt: [K,N] weight layout takes no split-K");
     if (variant < 2 || variant > 5) variant = 5;
@@ -1448,7 +1855,7 @@ extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B,
                               int variant, float drop_p, unsigned drop_seed, void* stream) {
   VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt: bad dtype %d", dtype);
   const int es = dtype == VLNI_F32 ? 4 : 2;
-  int rc = gemm_check_one(es, A, lda, B, ldb, ldc, M, N, K, variant >= 16);
+  int rc = gemm_check_one(es, A, lda, B, ldb, ldc, M, N, K, (variant & 16) != 0);
   if (rc) return rc;
   VLNI_CHECK(!(atomic_f32 && (bias || act || residual || preact || dact)), VLNI_EINVAL, "gemm_nt: atomic output takes no epilogue");
   VLNI_CHECK(split_k >= 1 && (split_k == 1 || atomic_f32), VLNI_EINVAL, "gemm_nt: split_k needs atomic_f32");
@@ -1473,7 +1880,7 @@ extern "C" int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* ld
   VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "gemm_nt_dual: bad dtype %d", dtype);
   const int es = dtype == VLNI_F32 ? 4 : 2;
   for (int i = 0; i < 2; ++i) {
-    int rc = gemm_check_one(es, A[i], lda[i], B[i], ldb[i], ldc[i], M[i], N, K, variant >= 16);
+    int rc = gemm_check_one(es, A[i], lda[i], B[i], ldb[i], ldc[i], M[i], N, K, (variant & 16) != 0);
     if (rc) return rc;
   }
   VLNI_CHECK(drop_p >= 0.f && drop_p < 1.f, VLNI_EINVAL, "gemm_nt_dual: dropout p=%f", drop_p);

@@ -64,7 +64,8 @@ def _rows(t):
 # count fills 256 CUs and on how many operand bytes each CU pulls per output. The first call of a shape
 # times each once with HIP events (a few hundred microseconds) and the winner is cached for the life of the process.
 AUTOTUNE = True
-GEMM_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)
+GEMM_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)   # 15 / 32 (persistent ring of 32-deep half-steps, 4 / 5 slots) exist and
+#                 are tested bit-identical, but lost 8-12 % to 14 on every step shape (tools/gemm_step_probe.py): not tried by the autotune
 _GEMM_BEST = {}
 
 
@@ -81,7 +82,7 @@ NN_DGRAD = os.environ.get("VLNI_NN_DGRAD", "1") == "1"    # bf16 dgrad straight 
                          # shadows to rebuild after every optimizer step and half the shadow memory. Same-box A/B on the bench step
                          # (3 pairs): 37.5-37.8 ms vs 38.1 ms with NT kernels on W^T copies. (Before the LDS-DMA of that kernel was
                          # issued as asm it was the slower choice: the compiler serialised its copies with the reads.)
-NN_VARIANTS = (2, 3, 4, 5)
+NN_VARIANTS = (2, 3, 4, 5, 6)          # 7 / 32: the ring forms of the [K,N] kernel (see GEMM_VARIANTS)
 NN_MIN_ROWS = int(os.environ.get("VLNI_NN_MIN_ROWS", "4096"))   # below this the small-tile NT pipelines on a W^T copy win (DUET's map / viewpoint
                                                                 # streams: 25.0 vs 26.0 ms per step with every dgrad on the NN kernel)
 
