@@ -448,6 +448,7 @@ def main():
     if rank == 0 and not args.no_parity and args.dtype == "bf16":
         ws = Workload(args.model, args, shipped, dev, dtype, batch=8, tag="slice", model=w.model)
         w32 = ws.build(dev, torch.float32)
+        w32.load_state_dict(w.model.state_dict())                 # the timed model has taken optimizer steps: compare at ITS weights
         trainer.zero_grad()
         o16 = ws.run(criterion=ops.cross_entropy_sum, keep=True)
         o16["loss"].backward()
@@ -456,7 +457,8 @@ def main():
         o32["loss"].backward()
         parity = compare_runs(o16, o32, dict(w.model.named_parameters()), dict(w32.named_parameters()), ws.logits_key)
         parity = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in parity.items()}
-        parity["sample"] = f"B=8, T={args.T}, same weights; fp32 = the exact-fp32 MFMA path held to the reference goldens at 1e-4"
+        parity["sample"] = (f"B=8, T={args.T}, fwd+bwd at the timed model's current weights; fp32 = the exact-fp32 MFMA path held to the "
+                            "reference goldens at 1e-4")
         log(f"bf16 vs fp32: {parity}")
         del w32, o16, o32, ws
     if world > 1:

@@ -18,9 +18,12 @@ if "--duet" in sys.argv:
 else:
     from vln_imagine_amd.hamt.config import HamtConfig
     from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
-    import bench
+    from vln_imagine_amd.hamt.models.vilmodel_cmt import NavCMT
+    from vln_imagine_amd.hamt.spec import param_shapes
     cfg = HamtConfig()
-    model = bench.make_model(cfg, torch.bfloat16, torch.device("cuda"))
+    model = NavCMT(cfg)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()})
+    model = model.cuda().eval().set_compute_dtype(torch.bfloat16)
     et = EpisodeTensors(synth.HamtEpisode(tag="hp", B=8, L=80, V=37, I=6, T=6, ragged=False), "cuda")
 tr = FlatTrainer(model)
 def step():
