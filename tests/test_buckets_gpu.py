@@ -1,0 +1,109 @@
+"""Shape-bucketed hipGraph cache (vln_imagine_amd/hamt/buckets.py): a ragged stream of batches - text length, view count and
+episode length change from batch to batch as in VLN-HAMT/finetune_src/r2r/agent_cmt.py:130-176,498-606 - runs from captured
+graphs, one per (L, V, T) bucket, with the batch padded into the bucket's static buffers the way the reference pads inside a batch."""
+import time
+
+import pytest
+import torch
+
+from tests.golden.variants import HAMT_C1
+from tests.test_hamt_gpu import build_product
+from vln_imagine_amd import synth
+from vln_imagine_amd.hamt.config import HamtConfig
+from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+
+pytestmark = pytest.mark.gpu
+B, I = 8, 4
+# (L, V, T) of the stream's batches: three buckets ((48|64|80), (25|31|37), T) are hit, each more than once
+STREAM = [(45, 23, 3), (80, 37, 3), (61, 30, 4), (48, 25, 3), (77, 35, 3), (64, 31, 4), (40, 25, 3), (70, 37, 3), (58, 28, 4)]
+
+
+def _episode(i, L, V, T):
+    return synth.HamtEpisode(tag=f"stream{i}", B=B, L=L, V=V, I=I, T=T, ragged=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_ragged_stream_replays_from_bucket_graphs_with_eager_logits(dtype):
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.buckets import HamtGraphBuckets
+    from vln_imagine_amd.train import FlatTrainer
+    cfg = HamtConfig(**HAMT_C1)
+    model = build_product(cfg, dtype)
+    tr = FlatTrainer(model, lr=1e-4)
+    gb = HamtGraphBuckets(tr, model, B, I)
+    tol = 1e-5 if dtype == torch.float32 else 3e-2
+    try:
+        seen, replays = set(), 0
+        for i, (L, V, T) in enumerate(STREAM):
+            ep = _episode(i, L, V, T)
+            with torch.no_grad():                                     # the unpadded eager forward at the CURRENT weights
+                ref = run_episode(model, EpisodeTensors(ep, "cuda"), criterion=ops.cross_entropy_sum)
+            key = gb.key_for(ep)
+            replay = key in seen
+            replays += replay
+            seen.add(key)
+            pad_logits = None
+            if replay:                                                # the eager forward on the PADDED batch, same weights
+                bufs = gb.buckets[key][0].load(ep)
+                gb.head.set_static_plan(bufs.plan)
+                with torch.no_grad():
+                    pad_logits = [t.clone() for t in run_episode(model, bufs, criterion=ops.cross_entropy_sum)["logits"]]
+                gb.head.set_static_plan(None)
+            p_before = tr.flat_p.clone()
+            loss, logits = gb.step(ep)
+            assert abs(float(loss) - float(ref["loss"])) <= tol * max(1.0, abs(float(ref["loss"])))
+            for t in range(T):
+                a, b = logits[t][:, :V].float(), ref["logits"][t].float()
+                fin = torch.isfinite(b)
+                assert torch.equal(torch.isfinite(a), fin)
+                # against the unpadded run: the imagination tokens sit behind the text padding in the language stream, so the key order
+                # of the softmax sums differs - equal up to rounding, not bitwise (the reference's own batches have the same property)
+                assert (a[fin] - b[fin]).abs().max().item() <= tol * max(1.0, b[fin].abs().max().item()), (i, t)
+                assert bool(torch.isinf(logits[t][:, V:]).all())                                       # padded views can never be chosen
+                if pad_logits is not None:
+                    assert torch.equal(logits[t], pad_logits[t]), (i, t)                               # replay == eager, bit for bit
+            assert not torch.equal(tr.flat_p, p_before)                                              # and the step did train
+        assert len(seen) == 3 and replays == len(STREAM) - 3 and tr.step_no == len(STREAM)
+    finally:
+        tr.close()
+
+
+def test_bucket_replay_costs_what_a_fixed_shape_replay_costs():
+    """Steady state: replaying the bucket graph of a padded batch takes the time of a fixed-shape captured step of the bucket's
+    shape (the refill of the static buffers is a handful of small H2D copies)."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.buckets import HamtGraphBuckets
+    from vln_imagine_amd.train import FlatTrainer
+    cfg = HamtConfig(**HAMT_C1)
+    model = build_product(cfg, torch.bfloat16)
+    tr = FlatTrainer(model, lr=1e-5)
+    try:
+        gb = HamtGraphBuckets(tr, model, B, I)
+        eps = [_episode(100 + i, 70 + i, 33 + (i % 4), 4) for i in range(6)]               # all land in bucket (80, 37, 4)
+        for ep in eps[:2]:
+            gb.step(ep)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for ep in eps[2:]:
+            gb.step(ep)
+        torch.cuda.synchronize()
+        bucket_ms = (time.perf_counter() - t0) / 4 * 1e3
+        et = EpisodeTensors(synth.HamtEpisode(tag="fixed", B=B, L=80, V=37, I=I, T=4, ragged=False), "cuda")
+
+        def fwd_bwd():
+            loss = run_episode(model, et, criterion=ops.cross_entropy_sum, keep=False)["loss"]
+            loss.backward()
+            return loss
+
+        step = tr.capture(fwd_bwd, warmup=1)
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        fixed_ms = (time.perf_counter() - t0) / 4 * 1e3
+        print(f"\nbucket replay {bucket_ms:.2f} ms/step vs fixed-shape replay {fixed_ms:.2f} ms/step")
+        assert bucket_ms <= 1.25 * fixed_ms + 0.5, (bucket_ms, fixed_ms)
+    finally:
+        tr.close()

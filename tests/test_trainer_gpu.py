@@ -129,3 +129,45 @@ def test_marks_are_scoped_to_the_trainers_parameters():
         assert (p.grad is None) == (q.grad is None), n
         if p.grad is not None:
             assert torch.equal(p.grad, q.grad) or (p.grad - q.grad).abs().max().item() <= 1e-6 * max(1.0, q.grad.abs().max().item()), n
+
+
+def test_dynamic_loss_scaling_is_transparent_and_skips_overflowed_steps():
+    """GradScaler semantics of the fused step (VLN-DUET/pretrain_src/train_r2r.py:201-234; what an fp16 run needs): the loss is
+    multiplied by the device-resident scale S before backward and the step divides it out again (same update as without scaling);
+    a non-finite gradient skips the step entirely and halves S; `growth_interval` clean steps double it."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_language")
+    et = EpisodeTensors(ep, "cuda")
+    ma, mb = build_product(cfg), build_product(cfg)
+    ta = FlatTrainer(ma, lr=LR)
+    ta.zero_grad()
+    run_episode(ma, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+    ta.step()
+    pa, na = ta.flat_p.clone(), ta.grad_norm()
+    ta.close()
+    tb = FlatTrainer(mb, lr=LR, loss_scale=1024.0, growth_interval=2)
+    try:
+        p0 = tb.flat_p.clone()
+        tb.zero_grad()
+        (run_episode(mb, et, criterion=ops.cross_entropy_sum)["loss"] * tb.loss_scale).backward()
+        tb.step()
+        assert abs(tb.grad_norm() - na) < 1e-4 * na and float(tb.state[5]) == 0.0 and float(tb.state[4]) == 1024.0
+        d = (tb.flat_p - pa).abs()
+        assert d.max().item() < 2.5e-3 and d.mean().item() < 1e-6, (d.max().item(), d.mean().item())      # same step (power-of-two scale)
+        p1, m1 = tb.flat_p.clone(), tb.m.clone()
+        tb.zero_grad()
+        (run_episode(mb, et, criterion=ops.cross_entropy_sum)["loss"] * tb.loss_scale).backward()
+        tb.flush()
+        tb.flat_g[12345] = float("inf")                               # an overflowed fp16 gradient
+        tb.step()
+        assert float(tb.state[5]) == 1.0 and float(tb.state[4]) == 512.0                  # skipped, scale halved
+        assert torch.equal(tb.flat_p, p1) and torch.equal(tb.m, m1) and float(tb.gstate[0]) == 1.0
+        for _ in range(2):                                                               # two clean steps: scale doubles again
+            tb.zero_grad()
+            (run_episode(mb, et, criterion=ops.cross_entropy_sum)["loss"] * tb.loss_scale).backward()
+            tb.step()
+        assert float(tb.state[4]) == 1024.0 and float(tb.gstate[0]) == 3.0 and not torch.equal(tb.flat_p, p1)
+        assert (tb.flat_p - p0).abs().max().item() > 1e-4
+    finally:
+        tb.close()

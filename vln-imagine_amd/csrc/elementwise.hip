@@ -256,7 +256,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void segmean_fwd_kernel(const T* __restrict__ x, long ldx, const int* __restrict__ off,
                                                           const int* __restrict__ rowidx, T* __restrict__ out, int H) {
   const int s = blockIdx.x, a = off[s], b = off[s + 1];
-  const float inv = 1.0f / (float)(b - a);
+  const float inv = b > a ? 1.0f / (float)(b - a) : 0.f;       // an empty segment (padding of a fixed-capacity plan) is a zero row
   for (int c = threadIdx.x; c < H; c += 256) {
     float acc = 0.f;
     for (int t = a; t < b; ++t) acc += DT<T>::ld(x + (long)rowidx[t] * ldx + c);
@@ -268,7 +268,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void segmean_bwd_kernel(const T* __restrict__ dout, const int* __restrict__ off,
                                                           const int* __restrict__ rowidx, float* __restrict__ dx32, int H) {
   const int s = blockIdx.x, a = off[s], b = off[s + 1];
-  const float inv = 1.0f / (float)(b - a);
+  const float inv = b > a ? 1.0f / (float)(b - a) : 0.f;
   for (int c = threadIdx.x; c < H; c += 256) {
     const float g = DT<T>::ld(dout + (long)s * H + c) * inv;
     for (int t = a; t < b; ++t) atomicAdd(dx32 + (long)rowidx[t] * H + c, g);

@@ -1,0 +1,146 @@
+"""Shape-bucketed hipGraph cache for real (ragged) HAMT batches.
+
+In the reference the text length, the number of candidate views, the imagination count and the episode length change from batch to
+batch (VLN-HAMT/finetune_src/r2r/agent_cmt.py:130-176 pads a batch to ITS longest instruction / largest candidate set,
+:498-606 runs until the longest episode ends). A captured step has fixed shapes and fixed addresses, so batches are padded up to
+the next BUCKET (L, V) - with exactly the padding the reference itself uses inside a batch: text pads are id 0 / mask False,
+observation pads are zero features / mask False / nav type 0 (their logits are -inf, agent_cmt.py:558) - into one set of static
+device buffers per bucket, and each (L, V, T) bucket owns one captured training step (train.GraphedStep). The imagination-grounding
+head's index lists (agent_cmt.py:436-459 -> models/vilmodel_cmt.py:755-785) become fixed-capacity device buffers as well
+(AlignWithContrastiveLoss.set_static_plan), refilled per batch.
+
+Padded key positions carry the additive mask -10000: their softmax weight is exp(-10000 - max) = 0 in float32, so every real row
+of every activation - and every logit - is bit-identical to the unpadded eager run (tests/test_buckets_gpu.py); weight gradients
+differ by summation order only (more zero rows)."""
+import numpy as np
+import torch
+
+from vln_imagine_amd import ops
+
+
+class EpisodeBuffers:
+    """Static device buffers of one bucket; quacks like hamt.episode.EpisodeTensors. `load(ep)` pads a synth.HamtEpisode-shaped
+    numpy episode (B and I as the bucket, L <= bucket L, V <= bucket V, T == bucket T) into them."""
+
+    def __init__(self, B, L, V, I, T, device, feat=768, ang=4, pano=36):
+        dev = torch.device(device)
+        self.B, self.L, self.V, self.I, self.T, self.device = B, L, V, I, T, dev
+        z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)
+        self.txt_ids, self.txt_masks = z(B, L, dt=torch.int64), z(B, L, dt=torch.bool)
+        self.imagine_feats, self.imagine_masks = z(B, I, feat), z(B, I, dt=torch.bool)
+        self.steps = [dict(ob_img_feats=z(B, V, feat), ob_ang_feats=z(B, V, ang), ob_nav_types=z(B, V, dt=torch.int64),
+                           ob_masks=z(B, V, dt=torch.bool), target=z(B, dt=torch.int64), hist_img_feats=z(B, feat),
+                           hist_ang_feats=z(B, ang), hist_pano_img_feats=z(B, pano, feat), hist_pano_ang_feats=z(B, pano, ang))
+                      for _ in range(T)]
+        self.step_ids = [torch.tensor([i], device=dev) for i in range(T)]
+        self.hist_masks = [torch.ones((B, t + 1), dtype=torch.bool, device=dev) for t in range(T)]
+        cap = B * I
+        self.plan = dict(rows=z(cap, dt=torch.int64), scored=z(cap, dt=torch.int64), seg_off=z(cap + 1, dt=torch.int32),
+                         tok_rows=z(B * L, dt=torch.int32), weight=z(cap), count=torch.ones((), dtype=torch.float32, device=dev),
+                         target=torch.full((cap,), cap, dtype=torch.int64, device=dev))
+        self.ep = self                       # run_episode reads the annotation lists from `.ep`; the static plan replaces them
+        self.sub_instr_segs = self.sub_instr_imag_flag = self.noun_phrase_segs = None
+
+    @staticmethod
+    def _put(dst, src):
+        """dst[:src.shape] = src, the rest zero / False (one H2D copy of a host-padded array)."""
+        host = np.zeros(tuple(dst.shape), dtype=src.dtype)
+        host[tuple(slice(0, n) for n in src.shape)] = src
+        dst.copy_(torch.from_numpy(host), non_blocking=False)
+
+    def load(self, ep):
+        assert ep.B == self.B and ep.I == self.I and ep.T == self.T and ep.L <= self.L and ep.V <= self.V, "episode does not fit the bucket"
+        self._put(self.txt_ids, ep.txt_ids)
+        self._put(self.txt_masks, ep.txt_masks)
+        self._put(self.imagine_feats, ep.imagine_feats.astype(np.float32))
+        self._put(self.imagine_masks, ep.imagine_masks)
+        for dst, src in zip(self.steps, ep.steps):
+            for k, buf in dst.items():
+                if k == "target":
+                    buf.copy_(torch.from_numpy(src[k]))
+                else:
+                    self._put(buf, np.asarray(src[k], dtype=np.float32) if buf.dtype == torch.float32 else src[k])
+        # ---- the alignment head's index lists (the reference's triple loop, vilmodel_cmt.py:755-785, with its assertions) ----
+        B, L, I, cap = self.B, self.L, self.I, self.B * self.I
+        rows, scored, seg_off, tok = [], [], [0], []
+        for b in range(B):
+            flags = [x == "True" for x in ep.sub_instr_imag_flag[b]]
+            assert len(flags) == len(ep.sub_instr_segs[b]) == len(ep.noun_phrase_segs[b])
+            for i, f in enumerate(flags):
+                if not f:
+                    continue
+                assert bool(ep.imagine_masks[b, i]), "Imagine embeds is not valid where embedding addition is being applied."
+                s0, s1 = ep.sub_instr_segs[b][i]
+                rows.append(b * I + i)
+                for (a, z) in ep.noun_phrase_segs[b][i]:
+                    assert a >= s0 and z <= s1, "check np indices and sub-instr indices. They seem off."
+                    assert bool(ep.txt_masks[b, a:z + 1].all()), "Text_embeds is not valid where embedding addition is being applied."
+                    tok.extend(range(b * L + a, b * L + z + 1))          # row index in the PADDED [B, L] layout
+                if ep.noun_phrase_segs[b][i]:
+                    scored.append(len(rows) - 1)
+                    seg_off.append(len(tok))
+        n = len(scored)
+        pad = lambda v, size, fill: np.asarray(list(v) + [fill] * (size - len(v)))
+        p = self.plan
+        p["rows"].copy_(torch.from_numpy(pad(rows, cap, 0).astype(np.int64)))
+        p["scored"].copy_(torch.from_numpy(pad(scored, cap, 0).astype(np.int64)))
+        p["seg_off"].copy_(torch.from_numpy(pad(seg_off, cap + 1, seg_off[-1]).astype(np.int32)))      # empty segments behind the real ones
+        p["tok_rows"].copy_(torch.from_numpy(pad(tok, B * L, 0).astype(np.int32)))
+        p["weight"].copy_(torch.from_numpy(pad([1.0] * n, cap, 0.0).astype(np.float32)))
+        p["target"].copy_(torch.from_numpy(pad([rows[j] for j in scored], cap, cap).astype(np.int64)))  # pads -> the scratch row
+        p["count"].fill_(float(max(n, 1)))
+        return self
+
+
+class HamtGraphBuckets:
+    """One captured training step per (L, V, T) bucket. step(ep): pad the batch into its bucket's buffers and replay that bucket's
+    graphs; the first batch of a bucket runs eagerly (lazy initialisation, GEMM autotune at the bucket's row counts) and is captured
+    right after. Returns the loss tensor and the per-step logits (static outputs of the bucket's graph)."""
+
+    def __init__(self, trainer, model, B, I, l_buckets=(48, 64, 80), v_buckets=(25, 31, 37), device="cuda"):
+        self.trainer, self.model, self.B, self.I, self.device = trainer, model, B, I, device
+        self.l_buckets, self.v_buckets = sorted(l_buckets), sorted(v_buckets)
+        self.buckets = {}                # (L, V, T) -> [buffers, captured step or None, outputs dict]
+        self.head = getattr(model, "contrastive_alignment_model", None)
+
+    def key_for(self, ep):
+        L = next(x for x in self.l_buckets if x >= ep.L)
+        V = next(x for x in self.v_buckets if x >= ep.V)
+        return (L, V, ep.T)
+
+    def _fwd_bwd(self, key):
+        from vln_imagine_amd.hamt.episode import run_episode
+        bufs, _, outs = self.buckets[key]
+
+        def fwd_bwd():
+            if self.head is not None:
+                self.head.set_static_plan(bufs.plan)
+            try:
+                out = run_episode(self.model, bufs, criterion=ops.cross_entropy_sum, keep=True)
+            finally:
+                if self.head is not None:
+                    self.head.set_static_plan(None)
+            out["loss"].backward()
+            outs["logits"] = [t.detach() for t in out["logits"]]
+            return out["loss"].detach()
+        return fwd_bwd
+
+    def step(self, ep):
+        key = self.key_for(ep)
+        ent = self.buckets.get(key)
+        if ent is None:
+            ent = self.buckets[key] = [EpisodeBuffers(self.B, key[0], key[1], self.I, key[2], self.device), None, {}]
+        bufs = ent[0].load(ep)
+        fwd_bwd = self._fwd_bwd(key)
+        if ent[1] is None:                       # first batch of this bucket: a real eager step, then the capture (which runs nothing)
+            self.trainer.zero_grad()
+            loss = fwd_bwd()
+            self.trainer.allreduce_grads()
+            self.trainer.step()
+            logits = [t.clone() for t in ent[2]["logits"]]
+            loss = loss.clone()
+            ent[2].clear()
+            ent[1] = self.trainer.capture(fwd_bwd, warmup=0)
+            return loss, logits
+        loss = ent[1]()
+        return loss, ent[2]["logits"]

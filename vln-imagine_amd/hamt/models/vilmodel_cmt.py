@@ -330,6 +330,14 @@ class AlignWithContrastiveLoss(nn.Module):
         self.image_proj = MLPProjectionHead(768, 512, c.hidden_size)
         self.config = c
         self._plans = {}
+        self._static = None          # fixed-capacity device plan (hamt/buckets.py): the head then touches no host data at all
+
+    def set_static_plan(self, bufs):
+        """bufs = dict of FIXED-ADDRESS device tensors, padded to capacity (hamt/buckets.py: EpisodeBuffers.plan), or None.
+        With it the head reads its index lists from those buffers instead of building them from the python annotation lists, so a
+        captured step replays correctly on ANOTHER batch once the buffers are refilled (cosine loss only)."""
+        assert bufs is None or self.config.aux_loss_type == "cosine", "static aux plan: cosine loss only"
+        self._static = bufs
 
     def _index_plan(self, txt_masks, imagine_masks, sub_instr_segs, sub_instr_imag_flag, noun_phrase_segs, B, L, I, typ, dev):
         """Host side of the head: the reference's triple python loop (:755-785) reduced to index lists, with its assertions.
@@ -380,6 +388,15 @@ class AlignWithContrastiveLoss(nn.Module):
         B, L, H = txt.shape
         I = img.shape[1]
         typ = self.config.aux_loss_type
+        if self._static is not None:
+            # padded entries: MLP row 0 / an empty token segment (zero mean) / weight 0 / written to a scratch row behind the tensor
+            sp = self._static
+            img2 = img.reshape(B * I, H)
+            proj_s = self.image_proj(img2.index_select(0, sp["rows"])).index_select(0, sp["scored"])
+            means = ops.segment_mean(txt.reshape(B * L, H), sp["seg_off"], sp["tok_rows"])
+            loss = ((1.0 - ops.cosine(proj_s, means)) * sp["weight"]).sum() / sp["count"]
+            ext = torch.cat([img2, img2.new_zeros((1, H))], 0)
+            return loss, ext.index_copy(0, sp["target"], proj_s.to(img2.dtype))[:B * I].view(B, I, H)
         plan = self._index_plan(txt_masks, imagine_masks, sub_instr_segs, sub_instr_imag_flag, noun_phrase_segs, B, L, I, typ,
                                 img.device)
         if plan is None:

@@ -407,6 +407,7 @@ class ShadowCache:
         self.arena = None              # (flat float32 params, flat bf16 mirror)
         self._tr = {}                  # key -> (mirror view, transposed copy): refreshed together, one launch per optimizer step
         self._tr_table = None          # device table of vlni_transpose_batched (+ n, total tiles); None = rebuild needed
+        self._tr_table_old = None      # the last table handed to a launch (kept alive when it is replaced)
 
     def set_arena(self, flat_p, flat_b):
         self.arena = (flat_p, flat_b) if flat_p is not None else None
@@ -430,7 +431,10 @@ class ShadowCache:
             tile0 += tiles_c * ((dst.shape[1] + 63) // 64)
         dev = next(iter(self._tr.values()))[0].device
         tab = torch.frombuffer(buf, dtype=torch.uint8).to(dev)
+        if self._tr_table_old is not None:
+            _KEEPALIVE.append(self._tr_table_old)       # an earlier capture's transpose node still reads its own table
         self._tr_table = (tab, len(self._tr), tile0)
+        self._tr_table_old = tab
         return True
 
     def _refresh_transposed(self):
@@ -594,7 +598,10 @@ _TN_BEST = {}
 SMALL_TABLE_SCATTER = os.environ.get("VLNI_SMALL_SCATTER", "1") == "1"
 WGRAD_PARTS = os.environ.get("VLNI_WGRAD_PARTS", "1") == "1"   # row splits write partial gradients with plain stores + ONE batched reduction per
                                                               # step instead of float atomics (~1.3 TB/s on this chip, 30-50 % of a launch)
-_PART_BUFS = {}       # (gradient address, chunk, N, K) -> workspace: [splits][N][K] slabs, then [splits][N] column sums
+_PART_BUFS = {}       # (gradient address, N, K) -> workspace: [splits][N][K] slabs, then [splits][N] column sums
+_KEEPALIVE = []       # workspaces / device tables that were replaced by larger ones: captured hipGraphs hold RAW pointers to them, and
+                      # torch.cuda.graph() empties the allocator cache on entry - a freed one would be unmapped under an older graph
+                      # (memory access fault on its next replay). Dropped by train.FlatTrainer.close().
 _PART_TABLES = {}     # signature of a flush -> (device table, entries, blocks)
 _PART_DT = np.dtype([("dst", "<u8"), ("part", "<u8"), ("n4", "<i8"), ("stride4", "<i8"), ("split", "<i4"), ("blk0", "<i4")])
 
@@ -684,6 +691,8 @@ def flush_wgrads(lo=None, hi=None):
             key = (wv.data_ptr(), N, K)                      # one workspace per gradient, grown to the largest split count seen
             buf = _PART_BUFS.get(key)
             if buf is None or buf.numel() < tot * (N * K + N):
+                if buf is not None:
+                    _KEEPALIVE.append(buf)     # a captured step (another shape bucket's graph) may still write its partials there
                 buf = _PART_BUFS[key] = torch.empty((tot * (N * K + N),), dtype=torch.float32, device=wv.device)
             cpart = buf.data_ptr() + 4 * tot * N * K         # [tot][N] column-sum partials behind the [tot][N][K] slabs
         for n, pa, pb, pm, variant, split, z0 in plans:

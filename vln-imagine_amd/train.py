@@ -369,6 +369,7 @@ class FlatTrainer:
         ops._WQ.clear()
         ops._PART_BUFS.clear()                 # row-split workspaces and reduction tables of this arena's gradients
         ops._PART_TABLES.clear()
+        ops._KEEPALIVE.clear()                 # (replaced ones that older captured graphs of this trainer still pointed at)
         for p in self.params:
             p._vlni_direct = p._vlni_defer = False
         if ops.SHADOWS.arena is not None and ops.SHADOWS.arena[0] is self.flat_p:
