@@ -50,6 +50,10 @@ int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, 
                    float drop_p, unsigned drop_seed /* dropout after act, before residual; mask = f(seed, row*N+col) */,
                    void* stream);
 
+/* Diagnostic only: per-block cycle sums (8 x uint64 x <= 768 blocks: DMA wait, barrier, DMA issue, reads + MFMA, epilogue, k-steps,
+   kernel, cold start) of the last launch of the persistent GEMM's stamped build (environment VLNI_PK_HACK=4), tools/gemm_stamps.py */
+int vlni_debug_pk_stamps(void* host_dst, int bytes);
+
 /* Two problems (same N, K, epilogue kind; arrays of 2) in ONE launch: the language / vision streams of a cross-modal layer. */
 int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* lda, const void* const* B, const long* ldb, void* const* C,
                       const long* ldc, const int* M, int N, int K, const float* const* bias, int act,
@@ -92,6 +96,19 @@ int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, long ldk, c
                   const float* kmask, const float* bias, const void* out, long ldo, const void* dout, long lddo,
                   const float* lse, void* dq, long lddq, void* dk, long lddk, void* dv, long lddv, float* dbias, int B,
                   int nh, int Sq, int Sk, float scale, float drop_p, unsigned drop_seed, void* stream);
+/* Two attention problems with the same batch, heads and scale in ONE launch (arrays of 2): the language / vision stream of a
+   cross-modal layer or the two directions of its bidirectional cross-attention (R:385-407). bfloat16, q/k/v (dout) 16-byte
+   aligned, strides multiples of 8, <= 256 keys; additive bias (and dbias0) on problem 0 only; otherwise VLNI_EUNSUP. */
+int vlni_attn_fwd_dual(int dtype, const void* const* q, const long* ldq, const void* const* k, const long* ldk,
+                       const void* const* v, const long* ldv, const float* const* kmask, const float* const* bias,
+                       void* const* out, const long* ldo, float* const* lse, int B, int nh, const int* Sq, const int* Sk,
+                       float scale, float drop_p, const unsigned* drop_seed, void* stream);
+int vlni_attn_bwd_dual(int dtype, const void* const* q, const long* ldq, const void* const* k, const long* ldk,
+                       const void* const* v, const long* ldv, const float* const* kmask, const float* const* bias,
+                       const void* const* out, const long* ldo, const void* const* dout, const long* lddo,
+                       const float* const* lse, void* const* dq, const long* lddq, void* const* dk, const long* lddk,
+                       void* const* dv, const long* lddv, float* dbias0, int B, int nh, const int* Sq, const int* Sk,
+                       float scale, float drop_p, const unsigned* drop_seed, void* stream);
 /* softmax(q k^T * scale + kmask + bias) MATERIALISED as float32 [B][nh][Sq][Sk] (Sk <= 512) - only for the visualisation outputs of
    NavCMT.forward(..., return_cross_attention_probs=True) (reference vilmodel_cmt.py:391,393,438,439); same q / k layout as above */
 int vlni_attn_probs(int dtype, const void* q, long ldq, const void* k, long ldk, const float* kmask, const float* bias, float* probs,

@@ -550,3 +550,43 @@ def test_gemm_persistent_kernel_streams_many_tiles(ops, nn, pk):
                     ops._GEMM_BEST.clear()
             for x, y in zip(outs[0], outs[1]):
                 assert torch.equal(x, y), (nn, N, kind)
+
+
+@pytest.mark.parametrize("with_bias,p_drop", [(False, 0.0), (True, 0.0), (False, 0.1), (True, 0.1)])
+def test_attention_dual_launch_equals_two_launches(ops, with_bias, p_drop):
+    """vlni_attn_fwd_dual / _bwd_dual (two problems per launch: the two directions of the bidirectional cross-attention, or the two
+    streams' self-attention with DUET's graph bias on the first) == two single launches, bit for bit, on strided q/k/v views."""
+    B, nh, H = 5, 12, 768
+    for (S0, K0, S1, K1) in ((86, 38, 38, 86), (86, 86, 41, 41), (20, 130, 33, 7)):
+        g = torch.Generator().manual_seed(7)
+        mk = lambda rows, cols: (torch.randn(rows, cols, generator=g) * 0.7).to(torch.bfloat16).cuda()
+        qa, ka = mk(B * S0, 3 * H), mk(B * K0, 3 * H)
+        qb, kb = mk(B * S1, 3 * H), mk(B * K1, 3 * H)
+        q = (qa[:, :H], qb[:, :H]); k = (ka[:, H:2 * H], kb[:, H:2 * H]); v = (ka[:, 2 * H:], kb[:, 2 * H:])
+        km = ((torch.rand(B, K0, generator=g) < 0.2).float().cuda() * -10000.0, (torch.rand(B, K1, generator=g) < 0.2).float().cuda() * -10000.0)
+        bias0 = (torch.randn(B, S0, K0, generator=g) * 0.3).cuda() if with_bias else None
+        drop1 = lambda i: (p_drop, 100 + i)
+        ref = [ops.attn_fwd(q[i], k[i], v[i], B, (S0, S1)[i], (K0, K1)[i], km[i], bias0 if i == 0 else None, nh, drop=drop1(i)) for i in range(2)]
+        (o0, l0), (o1, l1) = ops.attn_fwd2(q, k, v, B, (S0, S1), (K0, K1), km, bias0, nh, drop=(p_drop, (100, 101)))
+        assert torch.equal(o0, ref[0][0]) and torch.equal(o1, ref[1][0]) and torch.equal(l0, ref[0][1]) and torch.equal(l1, ref[1][1])
+        do = (mk(B * S0, H), mk(B * S1, H))
+        grads = []
+        for dual in (False, True):
+            dqa, dka = torch.zeros_like(qa), torch.zeros_like(ka)
+            dqb, dkb = torch.zeros_like(qb), torch.zeros_like(kb)
+            dq = (dqa[:, :H], dqb[:, :H]); dk = (dka[:, H:2 * H], dkb[:, H:2 * H]); dv = (dka[:, 2 * H:], dkb[:, 2 * H:])
+            db = torch.zeros_like(bias0) if with_bias else None
+            if dual:
+                ops.attn_bwd2(q, k, v, (o0, o1), do, (l0, l1), dq, dk, dv, B, (S0, S1), (K0, K1), km, bias0, db, nh, drop=(p_drop, (100, 101)))
+            else:
+                for i in range(2):
+                    ops.attn_bwd(q[i], k[i], v[i], (o0, o1)[i], do[i], (l0, l1)[i], dq[i], dk[i], dv[i], B, (S0, S1)[i], (K0, K1)[i], km[i],
+                                 bias0 if i == 0 else None, db if i == 0 else None, nh, drop=drop1(i))
+            grads.append((dqa, dka, dqb, dkb, db))
+        for x, y in zip(*grads):
+            if x is None:
+                continue
+            if x.dtype == torch.float32:            # dbias: float atomics over heads, order-dependent in the last bits
+                assert (x - y).abs().max().item() <= 1e-5 * max(1.0, y.abs().max().item())
+            else:
+                assert torch.equal(x, y)

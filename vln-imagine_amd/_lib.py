@@ -19,6 +19,7 @@ P, L, I, F, U = ctypes.c_void_p, ctypes.c_long, ctypes.c_int, ctypes.c_float, ct
 SIGNATURES = {
     "vlni_gemm_nt": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, P],
     "vlni_gemm_nt_v": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, I, F, U, P],
+    "vlni_debug_pk_stamps": [P, I],
     "vlni_gemm_nt_dual": [I, P, P, P, P, P, P, P, I, I, P, I, P, P, P, P, P, P, I, I, F, P, P],
     "vlni_gemm_tn_bf16": [P, L, P, L, P, L, I, I, I, P, I, P],
     "vlni_gemm_tn_bf16_grouped": [I, P, P, P, L, L, P, L, I, I, P, I, P],
@@ -28,6 +29,8 @@ SIGNATURES = {
     "vlni_attn_fwd": [I, P, L, P, L, P, L, P, P, P, L, P, I, I, I, I, F, F, U, P],
     "vlni_attn_probs": [I, P, L, P, L, P, P, P, I, I, I, I, F, P],
     "vlni_attn_bwd": [I, P, L, P, L, P, L, P, P, P, L, P, L, P, P, L, P, L, P, L, P, I, I, I, I, F, F, U, P],
+    "vlni_attn_fwd_dual": [I, P, P, P, P, P, P, P, P, P, P, P, I, I, P, P, F, F, P, P],
+    "vlni_attn_bwd_dual": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, P, F, F, P, P],
     "vlni_layernorm_fwd": [I, P, L, P, P, F, P, L, P, P, I, I, P],
     "vlni_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, P, I, I, P, L, P, L, F, U, P],
     "vlni_sum_layernorm_fwd": [I, I, P, P, P, P, P, P, F, P, L, P, L, P, P, I, I, P],

@@ -362,13 +362,13 @@ __device__ __forceinline__ float dot8_bf16(const uint4& a, const uint4& b) {
 
 // forward: block = 4 waves x 32 query rows; grid = (ceil(Sq/128), B*nh)
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
+__device__ __forceinline__ void attn_fwd_bf16_body(const AttnP& p, int qblk, int bh) {
   constexpr int SKP = NKT * 32;
   __shared__ __attribute__((aligned(16))) char smem[2 * SKP * 128];
   char* Ks = smem;
   char* Vs = smem + SKP * 128;
-  const int bh = blockIdx.y, b = bh / p.nh, hd = bh % p.nh;
-  const int q0 = blockIdx.x * 128;
+  const int b = bh / p.nh, hd = bh % p.nh;
+  const int q0 = qblk * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
   const int qg = q0 + wave * 32 + r;
@@ -458,15 +458,29 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) {
   }
   if (p.lse && hh == 0 && qg < p.Sq) p.lse[((long)b * p.nh + hd) * p.Sq + qg] = m + __logf(l);
 }
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnP p) { attn_fwd_bf16_body<NKT>(p, blockIdx.x, blockIdx.y); }
+
+// Two attention problems in ONE launch (the language and the vision stream of a cross-modal layer, or the two directions of its
+// bidirectional cross-attention: vilmodel_cmt.py:385-407): each alone is 768 latency-bound blocks that use about a third of the wave
+// slots of the chip. Blocks [0, blocks_a) run problem a, the rest problem b; both take the key-tile count of the longer context.
+struct AttnP2 { AttnP a, b; int blocks_a; };
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_dual_kernel(AttnP2 pp) {
+  const bool second = (int)blockIdx.x >= pp.blocks_a;                    // block-uniform
+  const AttnP& p = second ? pp.b : pp.a;
+  const int id = (int)blockIdx.x - (second ? pp.blocks_a : 0), nq = (p.Sq + 127) / 128;
+  attn_fwd_bf16_body<NKT>(p, id % nq, id / nq);
+}
 
 // backward: block = NW waves (4, or 8 for 129..256 keys); wave w owns key tile w; grid = B*nh; query rows in chunks of 64
 // BIAS / DROP are compile-time: the per-element bias / dbias addresses and the dropout hash of 16 x 2 elements otherwise stay
 // live next to the accumulators and push the kernel to ~470 registers (one 4-wave block per CU).
+template <int NKT> constexpr int attn_bwd_lds() { return 2 * NKT * 32 * 128 + 2 * 64 * 128 + 64 * (NKT * 32 * 2 + 16) + 2 * 64 * 4; }
 template <int NKT, int NW, bool BIAS, bool DROP>
-__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_bf16_kernel(AttnP p) {
+__device__ __forceinline__ void attn_bwd_bf16_body(const AttnP& p, int bh, char* smem) {
   constexpr int NTH = NW * 64;
   constexpr int SKP = NKT * 32, DSS = SKP * 2 + 16;       // dS row stride in bytes (odd number of 16-B slots)
-  __shared__ __attribute__((aligned(16))) char smem[2 * SKP * 128 + 2 * 64 * 128 + 64 * DSS + 2 * 64 * 4];
   char* Ks = smem;
   char* Vs = Ks + SKP * 128;
   char* Qs = Vs + SKP * 128;
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_bf16_kernel(AttnP p) {
   char* dSs = dOs + 64 * 128;
   float* lse_s = (float*)(dSs + 64 * DSS);
   float* del_s = lse_s + 64;
-  const int bh = blockIdx.x, b = bh / p.nh, hd = bh % p.nh;
+  const int b = bh / p.nh, hd = bh % p.nh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, hh = lane >> 5;
   const unsigned dseed = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
   const int qq = (lane & 15) >> 2, pp = lane & 3, cb = (lane >> 4) & 1, half8 = 8 * (pp & 1);
@@ -623,6 +637,46 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bwd_bf16_kernel(AttnP p) {
       }
   }
 }
+template <int NKT, int NW, bool BIAS, bool DROP>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_bf16_kernel(AttnP p) {
+  __shared__ __attribute__((aligned(16))) char smem[attn_bwd_lds<NKT>()];
+  attn_bwd_bf16_body<NKT, NW, BIAS, DROP>(p, blockIdx.x, smem);
+}
+// dual form (see attn_fwd_bf16_dual_kernel); an additive bias is supported on problem a only (DUET's graph_sprels stream)
+template <int NKT, int NW, bool BIAS_A, bool DROP>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bwd_bf16_dual_kernel(AttnP2 pp) {
+  __shared__ __attribute__((aligned(16))) char smem[attn_bwd_lds<NKT>()];      // ONE array for both bodies
+  if ((int)blockIdx.x < pp.blocks_a) attn_bwd_bf16_body<NKT, NW, BIAS_A, DROP>(pp.a, blockIdx.x, smem);
+  else attn_bwd_bf16_body<NKT, NW, false, DROP>(pp.b, (int)blockIdx.x - pp.blocks_a, smem);
+}
+
+template <int NKT>
+int launch_bf16_dual(const AttnP2& pp, bool bwd, hipStream_t st) {
+  constexpr int NW = NKT <= 4 ? 4 : 8;
+  if (bwd) {
+    const bool bias = pp.a.bias != nullptr, drop = pp.a.drop_thr != 0;
+    const int blocks = pp.blocks_a + pp.b.B * pp.b.nh;
+    if (bias && drop) hipLaunchKernelGGL((attn_bwd_bf16_dual_kernel<NKT, NW, true, true>), dim3(blocks), dim3(NW * 64), 0, st, pp);
+    else if (bias) hipLaunchKernelGGL((attn_bwd_bf16_dual_kernel<NKT, NW, true, false>), dim3(blocks), dim3(NW * 64), 0, st, pp);
+    else if (drop) hipLaunchKernelGGL((attn_bwd_bf16_dual_kernel<NKT, NW, false, true>), dim3(blocks), dim3(NW * 64), 0, st, pp);
+    else hipLaunchKernelGGL((attn_bwd_bf16_dual_kernel<NKT, NW, false, false>), dim3(blocks), dim3(NW * 64), 0, st, pp);
+  } else {
+    const int blocks = pp.blocks_a + cdiv(pp.b.Sq, 128) * pp.b.B * pp.b.nh;
+    hipLaunchKernelGGL((attn_fwd_bf16_dual_kernel<NKT>), dim3(blocks), dim3(256), 0, st, pp);
+  }
+  return 0;
+}
+int dispatch_bf16_dual(const AttnP2& pp, bool bwd, hipStream_t st) {
+  switch (cdiv(pp.a.Sk > pp.b.Sk ? pp.a.Sk : pp.b.Sk, 32)) {
+    case 1: return launch_bf16_dual<1>(pp, bwd, st);
+    case 2: return launch_bf16_dual<2>(pp, bwd, st);
+    case 3: return launch_bf16_dual<3>(pp, bwd, st);
+    case 4: return launch_bf16_dual<4>(pp, bwd, st);
+    case 5: case 6: return launch_bf16_dual<6>(pp, bwd, st);
+    case 7: case 8: return launch_bf16_dual<8>(pp, bwd, st);
+  }
+  return -1;
+}
 
 template <int NKT>
 int launch_bf16(const AttnP& p, bool bwd, hipStream_t st) {
@@ -736,6 +790,66 @@ extern "C" int vlni_attn_bwd(int dtype, const void* q, long ldq, const void* k, 
   rc = fast ? dispatch_bf16(p, true, (hipStream_t)stream)
             : (dtype == VLNI_F32 ? dispatch<float>(p, true, (hipStream_t)stream) : dispatch<__bf16>(p, true, (hipStream_t)stream));
   VLNI_CHECK(rc == 0, VLNI_EUNSUP, "attn_bwd: no kernel for Sk=%d", Sk);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// Two attention problems (arrays of 2; same batch, heads and scale) in one launch: bfloat16 only, 16-byte aligned q/k/v (and dout),
+// row strides multiples of 8, <= 256 keys each, an additive bias on problem 0 only. VLNI_EUNSUP otherwise (the caller launches twice).
+static int attn_fill(AttnP& p, int i, const void* const* q, const long* ldq, const void* const* k, const long* ldk, const void* const* v,
+                     const long* ldv, const float* const* kmask, const float* const* bias, void* const* out, const long* ldo,
+                     float* const* lse, int B, int nh, const int* Sq, const int* Sk, float scale, float drop_p, const unsigned* drop_seed) {
+  p = AttnP{};
+  p.q = q[i]; p.k = k[i]; p.v = v[i]; p.ldq = ldq[i]; p.ldk = ldk[i]; p.ldv = ldv[i];
+  p.kmask = kmask ? kmask[i] : nullptr; p.bias = bias ? bias[i] : nullptr;
+  p.out = out[i]; p.ldo = ldo[i]; p.lse = lse[i]; p.B = B; p.nh = nh; p.Sq = Sq[i]; p.Sk = Sk[i]; p.scale = scale;
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed ? drop_seed[i] : 0; p.drop_inv = 1.0f / (1.0f - drop_p); p.seed_base = vlni_seed_base();
+  return check_common("attn_dual", VLNI_BF16, p);
+}
+static bool attn_fast_ok(const AttnP& p, bool bwd) {
+  return p.ldq % 8 == 0 && p.ldk % 8 == 0 && p.ldv % 8 == 0 && (!bwd || p.lddo % 8 == 0) &&
+         (((uintptr_t)p.q | (uintptr_t)p.k | (uintptr_t)p.v | (bwd ? (uintptr_t)p.dout : 0)) & 15) == 0;
+}
+
+extern "C" int vlni_attn_fwd_dual(int dtype, const void* const* q, const long* ldq, const void* const* k, const long* ldk,
+                                  const void* const* v, const long* ldv, const float* const* kmask, const float* const* bias,
+                                  void* const* out, const long* ldo, float* const* lse, int B, int nh, const int* Sq, const int* Sk,
+                                  float scale, float drop_p, const unsigned* drop_seed, void* stream) {
+  VLNI_CHECK(dtype == VLNI_BF16, VLNI_EUNSUP, "attn_fwd_dual: bfloat16 only (dtype %d)", dtype);
+  AttnP2 pp;
+  for (int i = 0; i < 2; ++i) {
+    int rc = attn_fill(i ? pp.b : pp.a, i, q, ldq, k, ldk, v, ldv, kmask, bias, out, ldo, lse, B, nh, Sq, Sk, scale, drop_p, drop_seed);
+    if (rc) return rc;
+  }
+  VLNI_CHECK(pp.b.bias == nullptr, VLNI_EUNSUP, "attn_fwd_dual: additive bias on problem 0 only");
+  VLNI_CHECK(attn_fast_ok(pp.a, false) && attn_fast_ok(pp.b, false), VLNI_EUNSUP, "attn_fwd_dual: operands not 16-byte aligned / strides not multiples of 8");
+  pp.blocks_a = cdiv(pp.a.Sq, 128) * B * nh;
+  VLNI_CHECK(dispatch_bf16_dual(pp, false, (hipStream_t)stream) == 0, VLNI_EUNSUP, "attn_fwd_dual: no kernel for Sk=%d/%d", Sk[0], Sk[1]);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_attn_bwd_dual(int dtype, const void* const* q, const long* ldq, const void* const* k, const long* ldk,
+                                  const void* const* v, const long* ldv, const float* const* kmask, const float* const* bias,
+                                  const void* const* out, const long* ldo, const void* const* dout, const long* lddo,
+                                  const float* const* lse, void* const* dq, const long* lddq, void* const* dk, const long* lddk,
+                                  void* const* dv, const long* lddv, float* dbias0, int B, int nh, const int* Sq, const int* Sk,
+                                  float scale, float drop_p, const unsigned* drop_seed, void* stream) {
+  VLNI_CHECK(dtype == VLNI_BF16, VLNI_EUNSUP, "attn_bwd_dual: bfloat16 only (dtype %d)", dtype);
+  AttnP2 pp;
+  for (int i = 0; i < 2; ++i) {
+    AttnP& p = i ? pp.b : pp.a;
+    int rc = attn_fill(p, i, q, ldq, k, ldk, v, ldv, kmask, bias, (void* const*)out, ldo, (float* const*)lse, B, nh, Sq, Sk, scale, drop_p,
+                       drop_seed);
+    if (rc) return rc;
+    p.dout = dout[i]; p.lddo = lddo[i]; p.dq = dq[i]; p.dk = dk[i]; p.dv = dv[i]; p.lddq = lddq[i]; p.lddk = lddk[i]; p.lddv = lddv[i];
+    VLNI_CHECK(p.lddo % 4 == 0 && p.lddq % 4 == 0 && p.lddk % 4 == 0 && p.lddv % 4 == 0 && p.lse != nullptr, VLNI_EINVAL, "attn_bwd_dual: grad strides / lse");
+  }
+  pp.a.dbias = dbias0;
+  VLNI_CHECK(pp.b.bias == nullptr && (dbias0 == nullptr || pp.a.bias != nullptr), VLNI_EUNSUP, "attn_bwd_dual: additive bias on problem 0 only");
+  VLNI_CHECK(attn_fast_ok(pp.a, true) && attn_fast_ok(pp.b, true), VLNI_EUNSUP, "attn_bwd_dual: operands not 16-byte aligned / strides not multiples of 8");
+  pp.blocks_a = B * nh;
+  VLNI_CHECK(dispatch_bf16_dual(pp, true, (hipStream_t)stream) == 0, VLNI_EUNSUP, "attn_bwd_dual: no kernel for Sk=%d/%d", Sk[0], Sk[1]);
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

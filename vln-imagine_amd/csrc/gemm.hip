@@ -1318,6 +1318,18 @@ __global__ __launch_bounds__(512) void gemm_tn_ring_kernel(TnP p) {
 // Same k order and the same products as every other variant -> bit-identical results.
 struct PkSide { const char* A; long lda; const char* B; long ldb; int M, m0, n0; };
 
+// Diagnostic build only (HACK & 4, VLNI_PK_HACK=4): per block, wave 0's cycle sums of the phases of its k-steps; read back with
+// vlni_debug_pk_stamps. [0] waits for its LDS-DMA, [1] barrier, [2] LDS-DMA issue, [3] fragment reads + MFMA issue, [4] epilogue,
+// [5] k-steps, [6] whole kernel, [7] first wait + barrier (cold start). Never executed by the product kernels.
+__device__ unsigned long long g_pk_stamps[768 * 8];
+__device__ __forceinline__ unsigned long long pk_stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
 __device__ __forceinline__ void pk_locate(const GemmP& p, int tile, PkSide& s) {
   int w = tile;
   if (w >= p.tiles0) { w -= p.tiles0; s.A = p.A1; s.lda = p.lda1; s.B = p.B1; s.ldb = p.ldb1; s.M = p.M1; }
@@ -1485,6 +1497,9 @@ __global__ __launch_bounds__(512, 4) void gemm_pk_kernel(GemmP p, int ntiles) {
   const unsigned dseed0 = p.drop_thr ? eff_seed(p.drop_seed, p.seed_base) : 0u;
   const unsigned dseed1 = p.drop_thr ? eff_seed(p.drop_seed1, p.seed_base) : 0u;
 
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_t3 = 0, st_begin = 0;
+  bool first_step = true;
+  if constexpr (HACK & 4) st_begin = pk_stamp();
   PkSide cur, nxt;
   pk_locate(p, tile, cur);
   point_at(cur);
@@ -1494,8 +1509,12 @@ __global__ __launch_bounds__(512, 4) void gemm_pk_kernel(GemmP p, int ntiles) {
     const int ntile = tile + gx;
     const bool more = ntile < c1;
     for (int kt = 0; kt < nk; ++kt) {
+      unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+      if constexpr (HACK & 4) s0 = pk_stamp();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of k-tile kt landed (and its last epilogue's stores)
+      if constexpr (HACK & 4) s1 = pk_stamp();
       __builtin_amdgcn_s_barrier();                        // everybody's share landed; everybody finished reading the other stage
+      if constexpr (HACK & 4) s2 = pk_stamp();
       // the next k-tile's LDS-DMA (this tile's, or the first of the block's next tile) goes out right behind the barrier. (Issuing it
       // piece by piece behind the MFMAs of the k16 steps below was slower: 47.6 vs 43.4 us on the N = 2304 dual launch of a step.)
       const bool in_tile = kt + 1 < nk;
@@ -1504,6 +1523,12 @@ __global__ __launch_bounds__(512, 4) void gemm_pk_kernel(GemmP p, int ntiles) {
         point_at(nxt);
       }
       if (in_tile || more) issue(stage ^ 1, !in_tile);
+      if constexpr (HACK & 4) {
+        s3 = pk_stamp();
+        st_acc[0] += s1 - s0; st_acc[1] += s2 - s1; st_acc[2] += s3 - s2; st_acc[5] += 1;
+        if (first_step) { st_acc[7] = s2 - s0; first_step = false; }
+        st_t3 = s3;
+      }
       const char* As = dsmem + stage * STAGE;
       const char* Bs = As + BM * ROWB;
       bf16x8 a, b[2];
@@ -1520,12 +1545,21 @@ __global__ __launch_bounds__(512, 4) void gemm_pk_kernel(GemmP p, int ntiles) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a, acc[j], 0, 0, 0);   // D^T: lane = row, regs = columns
       }
+      if constexpr (HACK & 4) st_acc[3] += pk_stamp() - st_t3;
       stage ^= 1;
     }
+    unsigned long long e0 = 0;
+    if constexpr (HACK & 4) e0 = pk_stamp();
     pk_epilogue(p, tile, cur, acc, wr, wc, r, h, dseed0, dseed1);
+    if constexpr (HACK & 4) st_acc[4] += pk_stamp() - e0;
     if (!more) break;
     tile = ntile;
     cur = nxt;
+  }
+  if constexpr (HACK & 4) {
+    st_acc[6] = pk_stamp() - st_begin;
+    if (tid == 0 && blockIdx.x < 768)
+      for (int i = 0; i < 8; ++i) g_pk_stamps[blockIdx.x * 8 + i] = st_acc[i];
   }
 }
 
@@ -1752,10 +1786,12 @@ static int gemm_launch(int dtype, GemmP& p, int split_k, int variant, void* stre
           (void)hipFuncSetAttribute((const void*)gemm_pk_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
           (void)hipFuncSetAttribute((const void*)gemm_pk_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
           (void)hipFuncSetAttribute((const void*)gemm_pk_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+          (void)hipFuncSetAttribute((const void*)gemm_pk_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
           attr_h = true;
         }
         if (hack == 1) hipLaunchKernelGGL((gemm_pk_kernel<false, 1>), dim3(G), dim3(512), LDS, st, p, tiles);
         else if (hack == 2) hipLaunchKernelGGL((gemm_pk_kernel<false, 2>), dim3(G), dim3(512), LDS, st, p, tiles);
+        else if (hack == 4) hipLaunchKernelGGL((gemm_pk_kernel<false, 4>), dim3(G), dim3(512), LDS, st, p, tiles);
         else hipLaunchKernelGGL((gemm_pk_kernel<false, 3>), dim3(G), dim3(512), LDS, st, p, tiles);
       } else if (nn) hipLaunchKernelGGL((gemm_pk_kernel<true>), dim3(G), dim3(512), LDS, st, p, tiles);
       else hipLaunchKernelGGL((gemm_pk_kernel<false>), dim3(G), dim3(512), LDS, st, p, tiles);
@@ -1901,6 +1937,14 @@ extern "C" int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* ld
   p.vec_ok = gemm_vec_ok(es, N, p.C, p.ldc, p.residual, p.ldr, p.preact, p.ldp, p.dact_src, p.ldd, p.bias) &&
              gemm_vec_ok(es, N, p.C1, p.ldc1, p.residual1, p.ldr1, p.preact1, p.ldp1, p.dact_src1, p.ldd1, p.bias1);
   return gemm_launch(dtype, p, 1, variant, stream);
+}
+
+// Diagnostic: copies the phase-cycle sums of the last VLNI_PK_HACK=4 launch of the persistent GEMM (8 x u64 per block, 768 blocks) to the host.
+extern "C" int vlni_debug_pk_stamps(void* host_dst, int bytes) {
+  VLNI_CHECK(host_dst && bytes > 0 && bytes <= (int)sizeof(unsigned long long) * 768 * 8, VLNI_EINVAL, "debug_pk_stamps: bytes=%d", bytes);
+  VLNI_CHECK(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g_pk_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess, VLNI_ELAUNCH,
+             "debug_pk_stamps: hipMemcpyFromSymbol failed");
+  return VLNI_OK;
 }
 
 extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N,

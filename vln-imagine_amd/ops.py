@@ -305,6 +305,45 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, Sq, Sk, kmask=None, bias=No
               B, nh, Sq, Sk, 1.0 / 8.0, drop[0] if drop else 0.0, drop[1] if drop else 0, _st())
 
 
+def _dual_attn_ok(*ts):
+    """bf16 operands whose rows start on 16-byte boundaries with strides that are multiples of 8: the dual-problem launch."""
+    return all(t.dtype == torch.bfloat16 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1 for t in ts)
+
+
+def _p2(ts):
+    return (ctypes.c_void_p * 2)(*[_p(t) for t in ts])
+
+
+def _l2(ts):
+    return (ctypes.c_long * 2)(*[t.stride(0) if t is not None else 0 for t in ts])
+
+
+def attn_fwd2(q, k, v, B, Sq, Sk, kmask=(None, None), bias0=None, nh=12, drop=None):
+    """Two attention problems (tuples of 2: the two streams / directions of a cross-modal layer) in ONE launch (vlni_attn_fwd_dual);
+    drop = (p, (seed0, seed1)). Returns ((ctx0, lse0), (ctx1, lse1)). Falls back to two launches outside the bf16 fast path."""
+    p_, seeds = (drop[0], drop[1]) if drop else (0.0, (0, 0))       # one dropout probability for both (it is one config value)
+    if not _dual_attn_ok(*q, *k, *v) or max(Sk) > 256:
+        return (attn_fwd(q[0], k[0], v[0], B, Sq[0], Sk[0], kmask[0], bias0, nh, drop=(p_, seeds[0])),
+                attn_fwd(q[1], k[1], v[1], B, Sq[1], Sk[1], kmask[1], None, nh, drop=(p_, seeds[1])))
+    outs = tuple(torch.empty((B * Sq[i], nh * 64), dtype=q[i].dtype, device=q[i].device) for i in range(2))
+    lses = tuple(torch.empty((B, nh, Sq[i]), dtype=torch.float32, device=q[i].device) for i in range(2))
+    _lib.call("vlni_attn_fwd_dual", BF16, _p2(q), _l2(q), _p2(k), _l2(k), _p2(v), _l2(v), _p2(kmask), _p2((bias0, None)), _p2(outs), _l2(outs),
+              _p2(lses), B, nh, (ctypes.c_int * 2)(*Sq), (ctypes.c_int * 2)(*Sk), 1.0 / 8.0, p_, (ctypes.c_uint * 2)(*seeds), _st())
+    return (outs[0], lses[0]), (outs[1], lses[1])
+
+
+def attn_bwd2(q, k, v, out, dout, lse, dq, dk, dv, B, Sq, Sk, kmask=(None, None), bias0=None, dbias0=None, nh=12, drop=None):
+    """Backward of attn_fwd2 in one launch (vlni_attn_bwd_dual); every argument but bias0 / dbias0 is a tuple of 2."""
+    p_, seeds = (drop[0], drop[1]) if drop else (0.0, (0, 0))
+    if not _dual_attn_ok(*q, *k, *v, *dout) or max(Sk) > 256:
+        attn_bwd(q[0], k[0], v[0], out[0], dout[0], lse[0], dq[0], dk[0], dv[0], B, Sq[0], Sk[0], kmask[0], bias0, dbias0, nh, drop=(p_, seeds[0]))
+        attn_bwd(q[1], k[1], v[1], out[1], dout[1], lse[1], dq[1], dk[1], dv[1], B, Sq[1], Sk[1], kmask[1], None, None, nh, drop=(p_, seeds[1]))
+        return
+    _lib.call("vlni_attn_bwd_dual", BF16, _p2(q), _l2(q), _p2(k), _l2(k), _p2(v), _l2(v), _p2(kmask), _p2((bias0, None)), _p2(out), _l2(out),
+              _p2(dout), _l2(dout), _p2(lse), _p2(dq), _l2(dq), _p2(dk), _l2(dk), _p2(dv), _l2(dv), _p(dbias0), B, nh,
+              (ctypes.c_int * 2)(*Sq), (ctypes.c_int * 2)(*Sk), 1.0 / 8.0, p_, (ctypes.c_uint * 2)(*seeds), _st())
+
+
 def dropout_apply(x, p, seed):
     """x * mask/(1-p) with the library's counter-based mask over the linear index (x contiguous)."""
     if p <= 0.0:
@@ -850,8 +889,8 @@ class _XAttPairBlock(torch.autograd.Function):
         dt = lang.dtype
         wqkv, bqkv, wo_c = _w((wq, wk, wv), dt), _w((bq, bk, bv), torch.float32), _w((wo,), dt)
         ql, qv = gemm_nt2((l2, v2), (wqkv, wqkv), bias=(bqkv, bqkv))
-        cl, lse_l = attn_fwd(ql[:, :H], qv[:, H:2 * H], qv[:, 2 * H:], B, Sl, Sv, mask_v, drop=(pa, sd))
-        cv, lse_v = attn_fwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], B, Sv, Sl, mask_l, drop=(pa, sd + 1))
+        (cl, lse_l), (cv, lse_v) = attn_fwd2((ql[:, :H], qv[:, :H]), (qv[:, H:2 * H], ql[:, H:2 * H]), (qv[:, 2 * H:], ql[:, 2 * H:]), B,
+                                             (Sl, Sv), (Sv, Sl), (mask_v, mask_l), drop=(pa, (sd, sd + 1)))
         pre_l, pre_v = gemm_nt2((cl, cv), (wo_c, wo_c), bias=(bo, bo), residual=(l2, v2), drop=(ph, (sd + 2, sd + 3)))
         yl, mean_l, rstd_l = ln_fwd(pre_l, g, b, eps)
         yv, mean_v, rstd_v = ln_fwd(pre_v, g, b, eps)
@@ -887,10 +926,9 @@ class _XAttPairBlock(torch.autograd.Function):
         wot = _w((wo,), dt, True)
         dcl, dcv = gemm_nt2((dml, dmv), (wot, wot))
         dql, dqv = torch.empty_like(ql), torch.empty_like(qv)
-        attn_bwd(ql[:, :H], qv[:, H:2 * H], qv[:, 2 * H:], cl, dcl, lse_l, dql[:, :H], dqv[:, H:2 * H], dqv[:, 2 * H:],
-                 B, Sl, Sv, mask_v, drop=(pa, sd))
-        attn_bwd(qv[:, :H], ql[:, H:2 * H], ql[:, 2 * H:], cv, dcv, lse_v, dqv[:, :H], dql[:, H:2 * H], dql[:, 2 * H:],
-                 B, Sv, Sl, mask_l, drop=(pa, sd + 1))
+        attn_bwd2((ql[:, :H], qv[:, :H]), (qv[:, H:2 * H], ql[:, H:2 * H]), (qv[:, 2 * H:], ql[:, 2 * H:]), (cl, cv), (dcl, dcv),
+                  (lse_l, lse_v), (dql[:, :H], dqv[:, :H]), (dqv[:, H:2 * H], dql[:, H:2 * H]), (dqv[:, 2 * H:], dql[:, 2 * H:]),
+                  B, (Sl, Sv), (Sv, Sl), (mask_v, mask_l), drop=(pa, (sd, sd + 1)))
         if direct:
             _wb_grad_to((wq, wk, wv), (bq, bk, bv), dql, l2); _wb_grad_to((wq, wk, wv), (bq, bk, bv), dqv, v2)
         elif wparams:
@@ -915,8 +953,8 @@ class _DualSelfAttBlock(torch.autograd.Function):
         wqkv = [_w((Pi[0], Pi[2], Pi[4]), dt) for Pi in (P0, P1)]
         bqkv = [_w((Pi[1], Pi[3], Pi[5]), torch.float32) for Pi in (P0, P1)]
         q0, q1 = gemm_nt2((a0, a1), wqkv, bias=bqkv)
-        c0, lse0 = attn_fwd(q0[:, :H], q0[:, H:2 * H], q0[:, 2 * H:], B, S0, S0, km0, bias0, drop=(drop0[0], drop0[2]))
-        c1, lse1 = attn_fwd(q1[:, :H], q1[:, H:2 * H], q1[:, 2 * H:], B, S1, S1, km1, drop=(drop1[0], drop1[2]))
+        (c0, lse0), (c1, lse1) = attn_fwd2((q0[:, :H], q1[:, :H]), (q0[:, H:2 * H], q1[:, H:2 * H]), (q0[:, 2 * H:], q1[:, 2 * H:]), B,
+                                           (S0, S1), (S0, S1), (km0, km1), bias0, drop=(max(drop0[0], drop1[0]), (drop0[2], drop1[2])))
         ph = max(drop0[1], drop1[1])
         pre0, pre1 = gemm_nt2((c0, c1), (_w((P0[6],), dt), _w((P1[6],), dt)), bias=(P0[7], P1[7]), residual=(a0, a1),
                               drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
@@ -945,10 +983,9 @@ class _DualSelfAttBlock(torch.autograd.Function):
             (g1[6],), (g1[7],) = _wb_grad_to((P1[6],), (P1[7],), dm1, c1)
         dc0, dc1 = gemm_nt2((dm0, dm1), (_w((P0[6],), dt, True), _w((P1[6],), dt, True)))
         dq0, dq1 = torch.empty_like(q0), torch.empty_like(q1)
-        attn_bwd(q0[:, :H], q0[:, H:2 * H], q0[:, 2 * H:], c0, dc0, lse0, dq0[:, :H], dq0[:, H:2 * H], dq0[:, 2 * H:],
-                 B, S0, S0, km0, bias0, dbias0, drop=(drop0[0], drop0[2]))
-        attn_bwd(q1[:, :H], q1[:, H:2 * H], q1[:, 2 * H:], c1, dc1, lse1, dq1[:, :H], dq1[:, H:2 * H], dq1[:, 2 * H:],
-                 B, S1, S1, km1, drop=(drop1[0], drop1[2]))
+        attn_bwd2((q0[:, :H], q1[:, :H]), (q0[:, H:2 * H], q1[:, H:2 * H]), (q0[:, 2 * H:], q1[:, 2 * H:]), (c0, c1), (dc0, dc1),
+                  (lse0, lse1), (dq0[:, :H], dq1[:, :H]), (dq0[:, H:2 * H], dq1[:, H:2 * H]), (dq0[:, 2 * H:], dq1[:, 2 * H:]),
+                  B, (S0, S1), (S0, S1), (km0, km1), bias0, dbias0, drop=(max(drop0[0], drop1[0]), (drop0[2], drop1[2])))
         if w0:
             (g0[0], g0[2], g0[4]), (g0[1], g0[3], g0[5]) = _wb_grad_to((P0[0], P0[2], P0[4]), (P0[1], P0[3], P0[5]), dq0, a0)
         if w1:
@@ -971,8 +1008,8 @@ class _DualXAttQBlock(torch.autograd.Function):
         a0, a1 = _rows(_chk(x0, "x0")), _rows(_chk(x1, "x1"))
         dt = x0.dtype
         q0, q1 = gemm_nt2((a0, a1), (_w((P0[0],), dt), _w((P1[0],), dt)), bias=(P0[1], P1[1]))
-        c0, lse0 = attn_fwd(q0, kv0[:, :H], kv0[:, H:], B, S0, Sk, mask_c, drop=(drop0[0], drop0[2]))
-        c1, lse1 = attn_fwd(q1, kv1[:, :H], kv1[:, H:], B, S1, Sk, mask_c, drop=(drop1[0], drop1[2]))
+        (c0, lse0), (c1, lse1) = attn_fwd2((q0, q1), (kv0[:, :H], kv1[:, :H]), (kv0[:, H:], kv1[:, H:]), B, (S0, S1), (Sk, Sk),
+                                           (mask_c, mask_c), drop=(max(drop0[0], drop1[0]), (drop0[2], drop1[2])))
         ph = max(drop0[1], drop1[1])
         pre0, pre1 = gemm_nt2((c0, c1), (_w((P0[2],), dt), _w((P1[2],), dt)), bias=(P0[3], P1[3]), residual=(a0, a1),
                               drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
@@ -1001,8 +1038,9 @@ class _DualXAttQBlock(torch.autograd.Function):
         dc0, dc1 = gemm_nt2((dm0, dm1), (_w((P0[2],), dt, True), _w((P1[2],), dt, True)))
         dq0, dq1 = torch.empty_like(q0), torch.empty_like(q1)
         dkv0, dkv1 = torch.empty_like(kv0), torch.empty_like(kv1)
-        attn_bwd(q0, kv0[:, :H], kv0[:, H:], c0, dc0, lse0, dq0, dkv0[:, :H], dkv0[:, H:], B, S0, Sk, mask_c, drop=(drop0[0], drop0[2]))
-        attn_bwd(q1, kv1[:, :H], kv1[:, H:], c1, dc1, lse1, dq1, dkv1[:, :H], dkv1[:, H:], B, S1, Sk, mask_c, drop=(drop1[0], drop1[2]))
+        attn_bwd2((q0, q1), (kv0[:, :H], kv1[:, :H]), (kv0[:, H:], kv1[:, H:]), (c0, c1), (dc0, dc1), (lse0, lse1), (dq0, dq1),
+                  (dkv0[:, :H], dkv1[:, :H]), (dkv0[:, H:], dkv1[:, H:]), B, (S0, S1), (Sk, Sk), (mask_c, mask_c),
+                  drop=(max(drop0[0], drop1[0]), (drop0[2], drop1[2])))
         if w0:
             (g0[0],), (g0[1],) = _wb_grad_to((P0[0],), (P0[1],), dq0, a0)
         if w1:
