@@ -475,6 +475,7 @@ class NavCMT(nn.Module):
             self.fix_imagine_embeds = c.fix_imagine_embeds
         self.compute_dtype = torch.bfloat16 if os.environ.get("VLNI_DTYPE", "fp32").lower() in ("bf16", "bfloat16") \
             else torch.float32
+        self._lang_side = None           # (keys, lang, lm, nt): the language stream of the episode in flight (see _language_side)
         self.apply(self._init_weights)
 
     @staticmethod
@@ -494,6 +495,32 @@ class NavCMT(nn.Module):
             sd = {(k[5:] if k.startswith("bert.") else k): v for k, v in state_dict.items()}
             m.load_state_dict(sd, strict=False)
         return m
+
+    def _language_side(self, txt_embeds, txt_masks, imagine_embeds, imagine_masks, dt):
+        """Language stream of a `visual` call: text (+ imagination tokens when concat_imagine_with == 'language') and its additive
+        mask (vilmodel_cmt.py:1059-1061,1106-1112). The agent passes the SAME txt_embeds / imagine_embeds / masks at every step of an
+        episode (r2r/agent_cmt.py:498-606), so the concatenation and the two mask conversions are built once per episode and reused
+        while those tensors are the same objects at the same versions; their gradients then arrive through one concatenation node."""
+        keys = tuple((id(t), t._version) if torch.is_tensor(t) else None for t in (txt_embeds, txt_masks, imagine_embeds, imagine_masks)) \
+            + (dt, torch.is_grad_enabled())
+        hit = self._lang_side
+        if hit is not None and hit[0] == keys and all(a is b for a, b in zip(hit[1], (txt_embeds, txt_masks, imagine_embeds, imagine_masks))):
+            return hit[2], hit[3], hit[4]
+        txt = txt_embeds.to(dt)
+        nt = txt.shape[1]
+        lang, lm = txt, ops.additive_mask(txt_masks)
+        if self.config.imagine_enc_pano and self.config.concat_imagine_with == "language":
+            lang = torch.cat([lang, imagine_embeds.to(dt)], 1)
+            lm = torch.cat([lm, ops.additive_mask(imagine_masks)], 1)
+        lang, lm = lang.contiguous(), lm.contiguous()
+        self._lang_side = (keys, (txt_embeds, txt_masks, imagine_embeds, imagine_masks), lang, lm, nt)      # strong refs keep the ids unique
+        if lang.requires_grad:                 # once a backward pass has consumed this node its buffers are gone: build it anew next time
+            lang.register_hook(self._drop_language_side)
+        return lang, lm, nt
+
+    def _drop_language_side(self, grad):
+        self._lang_side = None
+        return grad
 
     def set_compute_dtype(self, dtype):
         assert dtype in (torch.float32, torch.bfloat16)
@@ -558,7 +585,7 @@ class NavCMT(nn.Module):
         if return_cross_attention_probs and c.no_lang_ca:
             raise NotImplementedError("return_cross_attention_probs with no_lang_ca (the reference's own comment: 'this might break')")
         cross_probs, self_probs = [], []
-        hm, om, tm = ops.additive_mask(hist_masks), ops.additive_mask(ob_masks), ops.additive_mask(txt_masks)
+        hm, om = ops.additive_mask(hist_masks), ops.additive_mask(ob_masks)
         hist = hist_embeds.to(dt)
         if self.encoder.h_layers is not None:
             for l in self.encoder.h_layers:
@@ -572,18 +599,19 @@ class NavCMT(nn.Module):
             ob = ob.detach()
         nh, no = hist.shape[1], ob.shape[1]
         txt_list = txt_embeds if isinstance(txt_embeds, list) else None
-        txt = (txt_list[0] if txt_list else txt_embeds).to(dt)
-        nt = txt.shape[1]
-        visn, vm, lang, lm = torch.cat([hist, ob], 1), torch.cat([hm, om], 1), txt, tm
-        img_side = None
+        visn, vm = torch.cat([hist, ob], 1), torch.cat([hm, om], 1)
+        img_side = c.concat_imagine_with if c.imagine_enc_pano else None
         if c.imagine_enc_pano:
             assert imagine_embeds is not None
-            im = ops.additive_mask(imagine_masks)
-            img_side = c.concat_imagine_with
-            if img_side == "visual":
-                visn, vm = torch.cat([visn, imagine_embeds.to(dt)], 1), torch.cat([vm, im], 1)
-            elif img_side == "language":
-                lang, lm = torch.cat([lang, imagine_embeds.to(dt)], 1), torch.cat([lm, im], 1)
+        if txt_list is None:
+            lang, lm, nt = self._language_side(txt_embeds, txt_masks, imagine_embeds, imagine_masks, dt)
+        else:                                  # no_lang_ca: per-layer precomputed text states (:1138-1145)
+            lang, lm = txt_list[0].to(dt), ops.additive_mask(txt_masks)
+            nt = lang.shape[1]
+            if img_side == "language":
+                lang, lm = torch.cat([lang, imagine_embeds.to(dt)], 1), torch.cat([lm, ops.additive_mask(imagine_masks)], 1)
+        if img_side == "visual":
+            visn, vm = torch.cat([visn, imagine_embeds.to(dt)], 1), torch.cat([vm, ops.additive_mask(imagine_masks)], 1)
         visn, lang, vm, lm = visn.contiguous(), lang.contiguous(), vm.contiguous(), lm.contiguous()
         for i, xl in enumerate(self.encoder.x_layers):
             if txt_list is not None:       # no_lang_ca: per-layer precomputed text states (:1138-1145)
@@ -604,7 +632,7 @@ class NavCMT(nn.Module):
         if c.no_lang_ca or tok == "ob":
             f = ob_o
         elif tok == "ob_txt":
-            f = ob_o * txt_o[:, :1]
+            f = ops.gate_rows(visn, lang, nh, no)            # ob_o * txt_o[:, :1] without slice / broadcast autograd nodes
         elif tok == "ob_hist":
             f = ob_o * hist_o[:, :1]
         elif tok == "ob_txt_hist":

@@ -1599,6 +1599,35 @@ class _Cosine(torch.autograd.Function):
         return dx, dy
 
 
+class _GateRows(torch.autograd.Function):
+    """f = visn[:, r0:r0+n] * lang[:, :1]  (NavCMT's action-head input for act_pred_token == 'ob_txt', vilmodel_cmt.py:1192):
+    one node instead of two slices, a broadcast multiply and their backward (three zero-filled full-size gradients + adds)."""
+
+    @staticmethod
+    def forward(ctx, visn, lang, r0, n):
+        ob, g = visn[:, r0:r0 + n], lang[:, :1]
+        ctx.save_for_backward(ob, g)
+        ctx.meta = (visn.shape, lang.shape, r0, n)
+        return ob * g
+
+    @staticmethod
+    def backward(ctx, df):
+        ob, g = ctx.saved_tensors
+        vshape, lshape, r0, n = ctx.meta
+        dvisn = dlang = None
+        if ctx.needs_input_grad[0]:
+            dvisn = df.new_zeros(vshape)
+            torch.mul(df, g, out=dvisn[:, r0:r0 + n])
+        if ctx.needs_input_grad[1]:
+            dlang = df.new_zeros(lshape)
+            dlang[:, 0] = (df.float() * ob.float()).sum(1).to(df.dtype)
+        return dvisn, dlang, None, None
+
+
+def gate_rows(visn, lang, r0, n):
+    return _GateRows.apply(visn, lang, r0, n)
+
+
 # ---- functional front-ends ------------------------------------------------------------
 NO_DROP = (0.0, 0.0, 0)
 
