@@ -210,7 +210,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
+                    help="compute dtype; fp16 = BASELINE.json configs[4] (float16 MFMA + dynamic loss scaling, float32 masters)")
     ap.add_argument("--batch", type=int, default=None, help="episodes per GPU (default: 64 HAMT, 32 DUET = BASELINE.json configs[1] / [3])")
     ap.add_argument("--T", type=int, default=6)
     ap.add_argument("--L", type=int, default=80)
@@ -278,8 +279,9 @@ def main():
     from vln_imagine_amd.train import FlatTrainer
 
     shipped = args.freeze == "shipped"
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    peak = MFMA_BF16_PEAK_TFLOPS if args.dtype == "bf16" else MFMA_F32_PEAK_TFLOPS
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    peak = MFMA_F32_PEAK_TFLOPS if args.dtype == "fp32" else MFMA_BF16_PEAK_TFLOPS            # f16 and bf16 MFMA run at the same rate
+    scaler = dict(loss_scale=16384.0, growth_interval=2000) if args.dtype == "fp16" else {}      # GradScaler semantics (train_r2r.py:201-234)
     comm = torch.bfloat16 if args.grad_comm == "bf16" else None
 
     def fence():
@@ -301,7 +303,10 @@ def main():
         launch description, last loss, eager step callable)."""
         def fwd_bwd():
             loss = w.run(criterion=ops.cross_entropy_sum, time_batched=time_batched)["loss"]
-            loss.backward()
+            if w.model.compute_dtype == torch.float16:
+                (loss * trainer.loss_scale).backward()           # the fused step divides the scale out again (and skips on overflow)
+            else:
+                loss.backward()
             return loss
 
         def eager():
@@ -360,7 +365,7 @@ def main():
     w = Workload(args.model, args, shipped, dev, dtype, tag=f"bench{rank}")
     if args.train_mode:
         w.model.train()
-    trainer = FlatTrainer(w.model, lr=1e-5, grad_comm_dtype=comm)
+    trainer = FlatTrainer(w.model, lr=1e-5, grad_comm_dtype=comm, **scaler)
     log(f"model + episode ready on {dev}; warmup {args.warmup}, steps {args.steps}, dtype {args.dtype}, world {world}")
     sec, launch, last_loss, eager_step = measure(w, trainer, args.steps, args.warmup, time_batched=args.time_batched, graph=args.graph)
     ms = sec * 1e3
@@ -432,7 +437,7 @@ def main():
         except Exception:
             traffic = None
         alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec)
-        roof = {"bound": "mfma", "kernel": "gemm_nt_* / gemm_nn_* <%s>" % ("__bf16" if args.dtype == "bf16" else "float"),
+        roof = {"bound": "mfma", "kernel": "gemm_nt_* / gemm_nn_* <%s>" % {"bf16": "__bf16", "fp16": "_Float16", "fp32": "float"}[args.dtype],
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": round(alg / len(rec)),
@@ -445,14 +450,19 @@ def main():
 
     # ---- error of the timed path against the fp32 parity path (same model, same weights, B = 8 slice, fwd + bwd) -------------
     parity = None
-    if rank == 0 and not args.no_parity and args.dtype == "bf16":
+    if rank == 0 and not args.no_parity and args.dtype in ("bf16", "fp16"):
         ws = Workload(args.model, args, shipped, dev, dtype, batch=8, tag="slice", model=w.model)
         w32 = ws.build(dev, torch.float32)
         w32.load_state_dict(w.model.state_dict())                 # the timed model has taken optimizer steps: compare at ITS weights
         trainer.zero_grad()
         o16 = ws.run(criterion=ops.cross_entropy_sum, keep=True)
-        o16["loss"].backward()
-        trainer.flush()
+        if dtype == torch.float16:                                # backward on S * loss as in a training step, then divide S out
+            (o16["loss"] * trainer.loss_scale).backward()
+            trainer.flush()
+            trainer.flat_g.mul_(1.0 / float(trainer.state[4]))
+        else:
+            o16["loss"].backward()
+            trainer.flush()
         o32 = ws.run(criterion=ops.cross_entropy_sum, keep=True, model=w32)
         o32["loss"].backward()
         parity = compare_runs(o16, o32, dict(w.model.named_parameters()), dict(w32.named_parameters()), ws.logits_key)
@@ -493,6 +503,20 @@ def main():
             e_ = line(s_, w.flops, "the parity path: every contraction on v_mfma_f32_32x32x2_f32 (exact fp32), eager launches")
             e_["step_frac_of_fp32_mfma_peak"] = round(w.flops / s_ / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
             extras["fp32"] = e_
+        if args.dtype == "bf16":
+            # BASELINE.json configs[4] names fp16 (the reference's only mixed precision: torch.cuda.amp in VLN-DUET/pretrain_src/
+            # train_r2r.py:201-234): the same step on the f16 MFMA with dynamic loss scaling
+            trainer.close()
+            w16 = Workload(args.model, args, shipped, dev, torch.float16, tag=f"bench{rank}")
+            tr16 = FlatTrainer(w16.model, lr=1e-5, grad_comm_dtype=comm, loss_scale=16384.0, growth_interval=2000)
+            trainer = tr16                                   # measure()'s closures read `trainer`
+            s_, _, _, _ = measure(w16, tr16, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="fp16")
+            e_ = line(s_, w16.flops, "float16 compute + GradScaler-style dynamic loss scaling in the fused step (float32 masters, f16 mirror)")
+            e_["skipped_steps"] = int(float(tr16.state[5]))
+            e_["loss_scale"] = float(tr16.state[4])
+            extras["fp16"] = e_
+            tr16.close()
+            del w16
         if not shipped:
             trainer.close()
             del trainer

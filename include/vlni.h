@@ -6,7 +6,8 @@
  * plain device pointers + explicit shapes/strides + a hipStream_t (as void*), no torch types, no
  * allocation inside, no global state except the thread-local error string and the optional dropout seed base.
  * Every function returns 0 (VLNI_OK) or a negative code; the message is vlni_last_error().
- * Row strides (`ld*`) are in ELEMENTS of the tensor's dtype. dtype: 0 = float32, 1 = bfloat16.
+ * Row strides (`ld*`) are in ELEMENTS of the tensor's dtype. dtype: 0 = float32, 1 = bfloat16, 2 = float16 (every entry point
+ * that takes a dtype; float16 runs the bfloat16 kernels with the f16 MFMA opcode: csrc/*_impl.inc are compiled once per type).
  * All reductions accumulate in float32. "R:" = VLN-HAMT/finetune_src/models/vilmodel_cmt.py,
  * "D:" = VLN-DUET/map_nav_src/models/vilmodel.py, "T:" = VLN-DUET/map_nav_src/models/transformer.py.
  */
@@ -84,6 +85,12 @@ int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const void* cons
 int vlni_gemm_tn_bf16_grouped_part(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb, float* part,
                                    long part_stride, int N, int K, float* colsum_part, int split, int variant, void* stream);
 int vlni_reduce_parts(const void* table, int n_entries, int n_blocks, void* stream);
+/* The grouped weight-gradient launches for either 16-bit dtype (1 bfloat16, 2 float16); arguments as the `_bf16_` forms above */
+int vlni_gemm_tn_h16_grouped_v(int dtype, int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
+                               float* C, long ldc, int N, int K, float* colsum, int split, int variant, void* stream);
+int vlni_gemm_tn_h16_grouped_part(int dtype, int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
+                                  float* part, long part_stride, int N, int K, float* colsum_part, int split, int variant,
+                                  void* stream);
 
 /* Fused masked attention, head dim 64, heads packed along the row (head h at column h*64), Sk <= 128.
  * kmask [B,Sk] additive float32 ((1-m)*-10000, R:1010-1012) or NULL; bias [B,Sq,Sk] additive float32

@@ -25,10 +25,10 @@ def _err(a, b):
     return (a.double() - b.double()).abs().max().item()
 
 
-TOL = {torch.float32: 1e-4, torch.bfloat16: 6e-2}
+TOL = {torch.float32: 1e-4, torch.bfloat16: 6e-2, torch.float16: 8e-3}       # float16: 11 bits of mantissa (8x finer than bfloat16)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (148, 768, 768), (300, 2304, 768), (257, 768, 3072), (64, 512, 512),
                                    (5, 1536, 768)])
 def test_gemm_nt_plain(ops, dtype, M, N, K):
@@ -46,12 +46,12 @@ def test_gemm_exact_integers(ops):
     a = torch.randint(-3, 4, (M, K), generator=torch.Generator().manual_seed(3)).float()
     b = torch.randint(-3, 4, (N, K), generator=torch.Generator().manual_seed(4)).float()
     ref = a @ b.t()
-    for dtype in (torch.float32, torch.bfloat16):
+    for dtype in (torch.float32, torch.bfloat16, torch.float16):
         out = ops.gemm_nt(a.to(dtype).cuda(), b.to(dtype).cuda()).float().cpu()
         assert torch.equal(out, ref), dtype
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 def test_gemm_epilogues(ops, dtype):
     M, N, K = 200, 768, 768
     a, b = _rand((M, K), dtype, 1, 0.5), _rand((N, K), dtype, 2, 0.05)
@@ -73,7 +73,7 @@ def test_gemm_epilogues(ops, dtype):
     assert _err(out3, torch.relu(zr)) < TOL[dtype] * 3
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("M,N,K", [(148, 768, 768), (5504, 768, 768), (333, 3072, 768), (70, 768, 3072)])
 def test_wgrad(ops, dtype, M, N, K):
     dy, x = _rand((M, N), dtype, 5, 0.1), _rand((M, K), dtype, 6, 0.5)
@@ -88,7 +88,7 @@ def test_wgrad(ops, dtype, M, N, K):
     assert _err(cs, dy.double().sum(0)) < tol * 10
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("rows,H,eps", [(148, 768, 1e-12), (1, 768, 1e-12), (4099, 768, 1e-5), (37, 512, 1e-12)])
 def test_layernorm(ops, dtype, rows, H, eps):
     x = _rand((rows, H), dtype, 7)
@@ -120,7 +120,7 @@ def _attn_ref(q, k, v, kmask, bias, B, Sq, Sk):
     return (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(B * Sq, nh * dh)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("B,Sq,Sk,use_bias", [(4, 80, 80, False), (3, 86, 38, False), (3, 38, 86, False), (2, 1, 5, False),
                                               (2, 100, 128, False), (2, 33, 65, True), (5, 130, 97, False)])
 def test_attention_fwd_bwd(ops, dtype, B, Sq, Sk, use_bias):
@@ -590,3 +590,31 @@ def test_attention_dual_launch_equals_two_launches(ops, with_bias, p_drop):
                 assert (x - y).abs().max().item() <= 1e-5 * max(1.0, y.abs().max().item())
             else:
                 assert torch.equal(x, y)
+
+
+def test_float16_kernels_are_the_bfloat16_kernels_with_the_f16_mfma(ops):
+    """float16 (BASELINE.json configs[4]) runs csrc/*_impl.inc compiled a second time with _Float16 / v_mfma_f32_32x32x16_f16: every
+    GEMM pipeline (incl. the persistent and the [K,N] dgrad kernels), the dual launches, the grouped weight gradient and the fused
+    attention give the float64 answer within float16 rounding, and all variants agree bit for bit like their bfloat16 twins."""
+    dt = torch.float16
+    M, N, K = 700, 768, 768
+    a, w = _rand((M, K), dt, 91, 0.5), _rand((N, K), dt, 92, 0.05)
+    bias, res = _rand((N,), torch.float32, 93, 0.1), _rand((M, N), dt, 94, 0.5)
+    ref = torch.nn.functional.gelu(a.double() @ w.double().t() + bias.double()) + res.double()
+    outs = []
+    for v in (1, 5, 13, 14):
+        out, z = torch.empty((M, N), dtype=dt, device="cuda"), torch.empty((M, N), dtype=dt, device="cuda")
+        ops._gemm_call(v, a, w, out, bias, 1, res, z, None, 0, 1.0, 1, False, M, N, K)
+        assert _err(out, ref) < 8e-3 * 3
+        outs.append(out)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    wt = w.t().contiguous()                                   # [K, N] operand of the transposing-read kernels
+    o_nn = torch.empty((M, N), dtype=dt, device="cuda")
+    o_nt = torch.empty((M, N), dtype=dt, device="cuda")
+    ops._gemm_call(16 + 6, a, wt, o_nn, None, 0, res, None, None, 0, 1.0, 1, False, M, N, K)
+    ops._gemm_call(1, a, w, o_nt, None, 0, res, None, None, 0, 1.0, 1, False, M, N, K)
+    assert torch.equal(o_nn, o_nt)
+    dy, x = _rand((2048, 768), dt, 95, 0.1), _rand((2048, 768), dt, 96, 0.5)
+    g = ops.wgrad(dy, x)
+    rg = dy.double().t() @ x.double()
+    assert _err(g, rg) < 2e-3 * max(1.0, rg.abs().max().item())

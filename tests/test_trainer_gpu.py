@@ -171,3 +171,37 @@ def test_dynamic_loss_scaling_is_transparent_and_skips_overflowed_steps():
         assert (tb.flat_p - p0).abs().max().item() > 1e-4
     finally:
         tb.close()
+
+
+def test_float16_training_with_dynamic_loss_scaling_tracks_float32():
+    """BASELINE.json configs[4] names fp16: float16 compute (float32 masters, a float16 mirror written by the optimizer kernel) under
+    the GradScaler-style dynamic loss scale keeps up with the float32 path over a few steps; no step is skipped at S = 2^12."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_language")
+    et = EpisodeTensors(ep, "cuda")
+    m32, m16 = build_product(cfg), build_product(cfg, torch.float16)
+    t32 = FlatTrainer(m32, lr=1e-4)
+    losses32 = []
+    for _ in range(3):
+        t32.zero_grad()
+        l = run_episode(m32, et, criterion=ops.cross_entropy_sum)["loss"]
+        l.backward()
+        t32.step()
+        losses32.append(float(l))
+    p32 = t32.flat_p.clone()
+    t32.close()
+    t16 = FlatTrainer(m16, lr=1e-4, loss_scale=4096.0, growth_interval=1000)
+    try:
+        assert t16.flat_b.dtype == torch.float16
+        for i in range(3):
+            t16.zero_grad()
+            l = run_episode(m16, et, criterion=ops.cross_entropy_sum)["loss"]
+            (l * t16.loss_scale).backward()
+            t16.step()
+            assert float(t16.state[5]) == 0.0                                  # not skipped
+            assert abs(float(l) - losses32[i]) < 2e-2, (i, float(l), losses32[i])
+        d = (t16.flat_p - p32).abs()
+        assert d.mean().item() < 2e-5 and d.max().item() < 1e-3, (d.mean().item(), d.max().item())     # 3 steps at lr 1e-4
+    finally:
+        t16.close()

@@ -67,6 +67,23 @@ template <> struct DT<__bf16> {
   }
 };
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <> struct DT<_Float16> {
+  static constexpr int id = VLNI_F16;
+  __device__ static __forceinline__ float ld(const _Float16* p) { return (float)*p; }
+  __device__ static __forceinline__ void st(_Float16* p, float v) { *p = (_Float16)v; }
+  __device__ static __forceinline__ f32x4 ld4(const _Float16* p) {
+    f16x4 t = *(const f16x4*)p;
+    f32x4 r = {(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+    return r;
+  }
+  __device__ static __forceinline__ void st4(_Float16* p, f32x4 v) {
+    f16x4 t = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    *(f16x4*)p = t;
+  }
+};
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

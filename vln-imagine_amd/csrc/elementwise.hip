@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const S* __restrict__ sr
 }
 
 // The same 64x64 tile transpose for MANY matrices in one launch (all transposed weight shadows after an optimizer step):
-// block -> entry by binary search over the entries' first-tile indices. dst is bfloat16.
+// block -> entry by binary search over the entries' first-tile indices. dst has the dtype of src (the compute-dtype mirror).
 struct TrEntry { const void* src; void* dst; long lds, ldd; int R, C, Rpad, tile0, tiles_c, pad_; };
 template <typename S>
 __global__ __launch_bounds__(256) void transpose_batched_kernel(const TrEntry* __restrict__ tab, int n) {
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const TrEntry* _
   const int t = blockIdx.x - e.tile0;
   const int r0 = (t / e.tiles_c) * 64, c0 = (t % e.tiles_c) * 64;
   const S* src = (const S*)e.src;
-  __bf16* dst = (__bf16*)e.dst;
+  S* dst = (S*)e.dst;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const TrEntry* _
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < e.C && r < e.Rpad) DT<__bf16>::st(dst + (long)c * e.ldd + r, tile[tx][i]);
+    if (c < e.C && r < e.Rpad) DT<S>::st(dst + (long)c * e.ldd + r, tile[tx][i]);
   }
 }
 
@@ -579,10 +579,11 @@ __global__ __launch_bounds__(256) void build_views_kernel(const S* __restrict__ 
 
 }  // namespace
 
-#define BY_DTYPE(dtype, CALL_F32, CALL_BF16)        \
+#define BY_DTYPE(dtype, CALL_F32, CALL_BF16, CALL_F16)  \
   do {                                              \
     if ((dtype) == VLNI_F32) { CALL_F32; }          \
     else if ((dtype) == VLNI_BF16) { CALL_BF16; }   \
+    else if ((dtype) == VLNI_F16) { CALL_F16; }     \
     else { vlni_set_error("bad dtype %d", (dtype)); return VLNI_EINVAL; } \
   } while (0)
 
@@ -598,6 +599,12 @@ extern "C" int vlni_cast(int src_dtype, int dst_dtype, const void* src, void* ds
     hipLaunchKernelGGL((cast_kernel<float, float>), grid, block, 0, st, (const float*)src, (float*)dst, n);
   else if (src_dtype == VLNI_BF16 && dst_dtype == VLNI_BF16)
     hipLaunchKernelGGL((cast_kernel<__bf16, __bf16>), grid, block, 0, st, (const __bf16*)src, (__bf16*)dst, n);
+  else if (src_dtype == VLNI_F32 && dst_dtype == VLNI_F16)
+    hipLaunchKernelGGL((cast_kernel<float, _Float16>), grid, block, 0, st, (const float*)src, (_Float16*)dst, n);
+  else if (src_dtype == VLNI_F16 && dst_dtype == VLNI_F32)
+    hipLaunchKernelGGL((cast_kernel<_Float16, float>), grid, block, 0, st, (const _Float16*)src, (float*)dst, n);
+  else if (src_dtype == VLNI_F16 && dst_dtype == VLNI_F16)
+    hipLaunchKernelGGL((cast_kernel<_Float16, _Float16>), grid, block, 0, st, (const _Float16*)src, (_Float16*)dst, n);
   else { vlni_set_error("cast: bad dtypes %d %d", src_dtype, dst_dtype); return VLNI_EINVAL; }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
@@ -612,6 +619,10 @@ extern "C" int vlni_transpose(int src_dtype, int dst_dtype, const void* src, lon
     hipLaunchKernelGGL((transpose_kernel<float, __bf16>), grid, block, 0, st, (const float*)src, lds_, (__bf16*)dst, ldd, R, C, Rpad);
   else if (src_dtype == VLNI_BF16 && dst_dtype == VLNI_BF16)
     hipLaunchKernelGGL((transpose_kernel<__bf16, __bf16>), grid, block, 0, st, (const __bf16*)src, lds_, (__bf16*)dst, ldd, R, C, Rpad);
+  else if (src_dtype == VLNI_F32 && dst_dtype == VLNI_F16)
+    hipLaunchKernelGGL((transpose_kernel<float, _Float16>), grid, block, 0, st, (const float*)src, lds_, (_Float16*)dst, ldd, R, C, Rpad);
+  else if (src_dtype == VLNI_F16 && dst_dtype == VLNI_F16)
+    hipLaunchKernelGGL((transpose_kernel<_Float16, _Float16>), grid, block, 0, st, (const _Float16*)src, lds_, (_Float16*)dst, ldd, R, C, Rpad);
   else if (src_dtype == VLNI_F32 && dst_dtype == VLNI_F32)
     hipLaunchKernelGGL((transpose_kernel<float, float>), grid, block, 0, st, (const float*)src, lds_, (float*)dst, ldd, R, C, Rpad);
   else { vlni_set_error("transpose: bad dtypes %d %d", src_dtype, dst_dtype); return VLNI_EINVAL; }
@@ -626,6 +637,7 @@ extern "C" int vlni_transpose_batched(int src_dtype, const void* table_dev, int 
   const TrEntry* tab = (const TrEntry*)table_dev;
   if (src_dtype == VLNI_F32) hipLaunchKernelGGL((transpose_batched_kernel<float>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
   else if (src_dtype == VLNI_BF16) hipLaunchKernelGGL((transpose_batched_kernel<__bf16>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
+  else if (src_dtype == VLNI_F16) hipLaunchKernelGGL((transpose_batched_kernel<_Float16>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
   else { vlni_set_error("transpose_batched: bad dtype %d", src_dtype); return VLNI_EINVAL; }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
@@ -635,7 +647,8 @@ extern "C" int vlni_colsum(int dtype, const void* x, long ldx, int rows, int N, 
   VLNI_CHECK(rows > 0 && N > 0, VLNI_EINVAL, "colsum: rows=%d N=%d", rows, N);
   dim3 grid(cdiv(N, 256), std::max(1, std::min(rows / 32, 256))), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((colsum_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, ldx, rows, N, out),
-           hipLaunchKernelGGL((colsum_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)x, ldx, rows, N, out));
+           hipLaunchKernelGGL((colsum_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)x, ldx, rows, N, out),
+          hipLaunchKernelGGL((colsum_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)x, ldx, rows, N, out));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -645,7 +658,8 @@ extern "C" int vlni_smallk_linear_fwd(int dtype, const float* x, long ldx, const
   VLNI_CHECK(K >= 1 && K <= 16 && rows > 0 && N > 0, VLNI_EINVAL, "smallk_fwd: rows=%d N=%d K=%d", rows, N, K);
   dim3 grid(cdiv(N, 256), std::min(rows, 1024)), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((smallk_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, x, ldx, W, b, (float*)y, ldy, rows, N, K),
-           hipLaunchKernelGGL((smallk_fwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, x, ldx, W, b, (__bf16*)y, ldy, rows, N, K));
+           hipLaunchKernelGGL((smallk_fwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, x, ldx, W, b, (__bf16*)y, ldy, rows, N, K),
+          hipLaunchKernelGGL((smallk_fwd_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, x, ldx, W, b, (_Float16*)y, ldy, rows, N, K));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -656,7 +670,8 @@ extern "C" int vlni_smallk_linear_bwd(int dtype, const void* dy, long lddy, cons
   const int rpb = std::min(64, std::max(8, rpb_env > 0 ? rpb_env : cdiv(rows, 128)));      // <= 64 rows of x in LDS; ~128 slabs
   dim3 grid(cdiv(N, 256), cdiv(rows, rpb)), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((smallk_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dy, lddy, x, ldx, dW, db, rows, N, K, rpb),
-           hipLaunchKernelGGL((smallk_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)dy, lddy, x, ldx, dW, db, rows, N, K, rpb));
+           hipLaunchKernelGGL((smallk_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)dy, lddy, x, ldx, dW, db, rows, N, K, rpb),
+          hipLaunchKernelGGL((smallk_bwd_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)dy, lddy, x, ldx, dW, db, rows, N, K, rpb));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -666,7 +681,8 @@ extern "C" int vlni_scatter_add_rows(int dtype, const void* src, long lds_, cons
   VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "scatter_add_rows: rows=%d H=%d", rows, H);
   dim3 grid(std::min(rows, 2048)), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((scatter_add_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, lds_, idx, table_grad, rows, H),
-           hipLaunchKernelGGL((scatter_add_rows_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H));
+           hipLaunchKernelGGL((scatter_add_rows_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H),
+          hipLaunchKernelGGL((scatter_add_rows_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)src, lds_, idx, table_grad, rows, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -679,7 +695,8 @@ extern "C" int vlni_scatter_add_rows_small(int dtype, const void* src, long lds_
   dim3 grid(cdiv(rows, 32), cdiv(H, 256)), block(256);
   BY_DTYPE(dtype,
            hipLaunchKernelGGL((scatter_add_rows_small_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, lds_, idx, table_grad, rows, H, table_rows),
-           hipLaunchKernelGGL((scatter_add_rows_small_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H, table_rows));
+           hipLaunchKernelGGL((scatter_add_rows_small_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H, table_rows),
+          hipLaunchKernelGGL((scatter_add_rows_small_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)src, lds_, idx, table_grad, rows, H, table_rows));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -687,14 +704,16 @@ extern "C" int vlni_scatter_add_rows_small(int dtype, const void* src, long lds_
 extern "C" int vlni_seqmean_fwd(int dtype, const void* x, void* out, int B, int S, int H, void* stream) {
   VLNI_CHECK(B > 0 && S > 0 && H > 0, VLNI_EINVAL, "seqmean_fwd: %d %d %d", B, S, H);
   BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_fwd_kernel<float>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, B, S, H),
-           hipLaunchKernelGGL((seqmean_fwd_kernel<__bf16>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)out, B, S, H));
+           hipLaunchKernelGGL((seqmean_fwd_kernel<__bf16>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)out, B, S, H),
+          hipLaunchKernelGGL((seqmean_fwd_kernel<_Float16>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)out, B, S, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
 extern "C" int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, int B, int S, int H, void* stream) {
   VLNI_CHECK(B > 0 && S > 0 && H > 0, VLNI_EINVAL, "seqmean_bwd: %d %d %d", B, S, H);
   BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_bwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)dout, (float*)dx, B, S, H),
-           hipLaunchKernelGGL((seqmean_bwd_kernel<__bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, (__bf16*)dx, B, S, H));
+           hipLaunchKernelGGL((seqmean_bwd_kernel<__bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, (__bf16*)dx, B, S, H),
+          hipLaunchKernelGGL((seqmean_bwd_kernel<_Float16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dout, (_Float16*)dx, B, S, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -704,7 +723,8 @@ extern "C" int vlni_rowdot_fwd(int dtype, const void* h, long ldh, const float* 
   VLNI_CHECK(rows > 0 && H % 4 == 0 && ldh % 4 == 0, VLNI_EINVAL, "rowdot_fwd: rows=%d H=%d", rows, H);
   dim3 grid(std::min(cdiv(rows, 4), 1024)), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((rowdot_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)h, ldh, w, bias, mask, out, rows, H),
-           hipLaunchKernelGGL((rowdot_fwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)h, ldh, w, bias, mask, out, rows, H));
+           hipLaunchKernelGGL((rowdot_fwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)h, ldh, w, bias, mask, out, rows, H),
+          hipLaunchKernelGGL((rowdot_fwd_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)h, ldh, w, bias, mask, out, rows, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -713,7 +733,8 @@ extern "C" int vlni_rowdot_bwd(int dtype, const float* dl, const void* h, long l
   VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "rowdot_bwd: rows=%d H=%d", rows, H);
   dim3 grid(cdiv(H, 256), std::max(1, std::min(rows / 4, 128))), block(256);   // rows strided over grid.y: each dh row written once
   BY_DTYPE(dtype, hipLaunchKernelGGL((rowdot_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, dl, (const float*)h, ldh, w, mask, (float*)dh, lddh, dw, dbias, rows, H),
-           hipLaunchKernelGGL((rowdot_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, dl, (const __bf16*)h, ldh, w, mask, (__bf16*)dh, lddh, dw, dbias, rows, H));
+           hipLaunchKernelGGL((rowdot_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, dl, (const __bf16*)h, ldh, w, mask, (__bf16*)dh, lddh, dw, dbias, rows, H),
+          hipLaunchKernelGGL((rowdot_bwd_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, dl, (const _Float16*)h, ldh, w, mask, (_Float16*)dh, lddh, dw, dbias, rows, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -730,7 +751,8 @@ extern "C" int vlni_segment_mean_fwd(int dtype, const void* x, long ldx, const i
                                      int nseg, int H, void* stream) {
   VLNI_CHECK(nseg > 0 && H > 0, VLNI_EINVAL, "segment_mean_fwd: nseg=%d H=%d", nseg, H);
   BY_DTYPE(dtype, hipLaunchKernelGGL((segmean_fwd_kernel<float>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, seg_off, rowidx, (float*)out, H),
-           hipLaunchKernelGGL((segmean_fwd_kernel<__bf16>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, ldx, seg_off, rowidx, (__bf16*)out, H));
+           hipLaunchKernelGGL((segmean_fwd_kernel<__bf16>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, ldx, seg_off, rowidx, (__bf16*)out, H),
+          hipLaunchKernelGGL((segmean_fwd_kernel<_Float16>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, ldx, seg_off, rowidx, (_Float16*)out, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -738,7 +760,8 @@ extern "C" int vlni_segment_mean_bwd(int dtype, const void* dout, const int* seg
                                      int H, void* stream) {
   VLNI_CHECK(nseg > 0 && H > 0, VLNI_EINVAL, "segment_mean_bwd: nseg=%d H=%d", nseg, H);
   BY_DTYPE(dtype, hipLaunchKernelGGL((segmean_bwd_kernel<float>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const float*)dout, seg_off, rowidx, dx32, H),
-           hipLaunchKernelGGL((segmean_bwd_kernel<__bf16>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, seg_off, rowidx, dx32, H));
+           hipLaunchKernelGGL((segmean_bwd_kernel<__bf16>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, seg_off, rowidx, dx32, H),
+          hipLaunchKernelGGL((segmean_bwd_kernel<_Float16>), dim3(nseg), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dout, seg_off, rowidx, dx32, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -747,7 +770,8 @@ extern "C" int vlni_cosine_fwd(int dtype, const void* x, const void* y, float ep
                                int H, void* stream) {
   VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "cosine_fwd: rows=%d H=%d", rows, H);
   BY_DTYPE(dtype, hipLaunchKernelGGL((cosine_fwd_kernel<float>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const float*)x, (const float*)y, eps, cosv, nx, ny, H),
-           hipLaunchKernelGGL((cosine_fwd_kernel<__bf16>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const __bf16*)x, (const __bf16*)y, eps, cosv, nx, ny, H));
+           hipLaunchKernelGGL((cosine_fwd_kernel<__bf16>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const __bf16*)x, (const __bf16*)y, eps, cosv, nx, ny, H),
+          hipLaunchKernelGGL((cosine_fwd_kernel<_Float16>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const _Float16*)x, (const _Float16*)y, eps, cosv, nx, ny, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -755,7 +779,8 @@ extern "C" int vlni_cosine_bwd(int dtype, const void* x, const void* y, const fl
                                const float* ny, void* dx, void* dy, int rows, int H, void* stream) {
   VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "cosine_bwd: rows=%d H=%d", rows, H);
   BY_DTYPE(dtype, hipLaunchKernelGGL((cosine_bwd_kernel<float>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const float*)x, (const float*)y, gcos, cosv, nx, ny, (float*)dx, (float*)dy, H),
-           hipLaunchKernelGGL((cosine_bwd_kernel<__bf16>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const __bf16*)x, (const __bf16*)y, gcos, cosv, nx, ny, (__bf16*)dx, (__bf16*)dy, H));
+           hipLaunchKernelGGL((cosine_bwd_kernel<__bf16>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const __bf16*)x, (const __bf16*)y, gcos, cosv, nx, ny, (__bf16*)dx, (__bf16*)dy, H),
+          hipLaunchKernelGGL((cosine_bwd_kernel<_Float16>), dim3(rows), dim3(64), 0, (hipStream_t)stream, (const _Float16*)x, (const _Float16*)y, gcos, cosv, nx, ny, (_Float16*)dx, (_Float16*)dy, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -764,7 +789,8 @@ extern "C" int vlni_act_bwd(int dtype, int act, const void* da, const void* z, v
   VLNI_CHECK(n > 0 && n % 4 == 0 && (act == 1 || act == 2), VLNI_EINVAL, "act_bwd: n=%ld act=%d", n, act);
   dim3 grid((unsigned)std::min<long>(2048, (n / 4 + 255) / 256)), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((act_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, act, (const float*)da, (const float*)z, (float*)dz, n),
-           hipLaunchKernelGGL((act_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, act, (const __bf16*)da, (const __bf16*)z, (__bf16*)dz, n));
+           hipLaunchKernelGGL((act_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, act, (const __bf16*)da, (const __bf16*)z, (__bf16*)dz, n),
+          hipLaunchKernelGGL((act_bwd_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, act, (const _Float16*)da, (const _Float16*)z, (_Float16*)dz, n));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -777,7 +803,8 @@ extern "C" int vlni_dropout(int dtype, const void* x, void* y, long n, float p, 
   const unsigned thr = drop_thr(p);
   const float inv = 1.0f / (1.0f - p);
   BY_DTYPE(dtype, hipLaunchKernelGGL((dropout_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)x, (float*)y, n, thr, seed, inv, vlni_seed_base()),
-           hipLaunchKernelGGL((dropout_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, n, thr, seed, inv, vlni_seed_base()));
+           hipLaunchKernelGGL((dropout_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)y, n, thr, seed, inv, vlni_seed_base()),
+          hipLaunchKernelGGL((dropout_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, n, thr, seed, inv, vlni_seed_base()));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -811,6 +838,8 @@ extern "C" int vlni_build_views(int table_dtype, const void* table, const long* 
            hipLaunchKernelGGL((build_views_kernel<float>), dim3(B * V), dim3(256), 0, (hipStream_t)stream, (const float*)table, vp_row, view,
                               cand_he, is_cand, base_view, angle_table, out_img, out_ang, V, D, A),
            hipLaunchKernelGGL((build_views_kernel<__bf16>), dim3(B * V), dim3(256), 0, (hipStream_t)stream, (const __bf16*)table, vp_row, view,
+                              cand_he, is_cand, base_view, angle_table, out_img, out_ang, V, D, A),
+          hipLaunchKernelGGL((build_views_kernel<_Float16>), dim3(B * V), dim3(256), 0, (hipStream_t)stream, (const _Float16*)table, vp_row, view,
                               cand_he, is_cand, base_view, angle_table, out_img, out_ang, V, D, A));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;

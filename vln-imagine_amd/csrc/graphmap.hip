@@ -193,6 +193,8 @@ extern "C" int vlni_gather_rows_or_zero(int dtype, const void* table, long ld, c
     hipLaunchKernelGGL((gather_rows_or_zero_kernel<float>), dim3(n), dim3(256), 0, (hipStream_t)stream, (const float*)table, ld, rows, out, D);
   else if (dtype == VLNI_BF16)
     hipLaunchKernelGGL((gather_rows_or_zero_kernel<__bf16>), dim3(n), dim3(256), 0, (hipStream_t)stream, (const __bf16*)table, ld, rows, out, D);
+  else if (dtype == VLNI_F16)
+    hipLaunchKernelGGL((gather_rows_or_zero_kernel<_Float16>), dim3(n), dim3(256), 0, (hipStream_t)stream, (const _Float16*)table, ld, rows, out, D);
   else
     VLNI_CHECK(false, VLNI_EINVAL, "gather_rows_or_zero: dtype %d", dtype);
   VLNI_LAUNCH_CHECK();

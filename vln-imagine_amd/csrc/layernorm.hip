@@ -218,7 +218,7 @@ int ln_bwd_grid(int rows) { return max(1, min(cdiv(rows, BWAVES), 128)); }
   } while (0)
 
 static int ln_check(const char* who, int dtype, int rows, int H, long ld) {
-  VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16, VLNI_EINVAL, "%s: bad dtype %d", who, dtype);
+  VLNI_CHECK(dtype == VLNI_F32 || dtype == VLNI_BF16 || dtype == VLNI_F16, VLNI_EINVAL, "%s: bad dtype %d", who, dtype);
   VLNI_CHECK(H == 256 || H == 512 || H == 768, VLNI_EUNSUP, "%s: H=%d not in {256,512,768}", who, H);
   VLNI_CHECK(rows > 0 && ld >= H && ld % 4 == 0, VLNI_EINVAL, "%s: rows=%d ld=%ld", who, rows, ld);
   return VLNI_OK;
@@ -232,9 +232,13 @@ extern "C" int vlni_layernorm_fwd(int dtype, const void* x, long ldx, const floa
     using TT = float;
     const float* xx = (const float*)x; float* yy = (float*)y;
     LN_DISPATCH(ln_fwd_kernel, TT, xx, ldx, gamma, beta, eps, yy, ldy, mean, rstd, rows);
-  } else {
+  } else if (dtype == VLNI_BF16) {
     using TT = __bf16;
     const __bf16* xx = (const __bf16*)x; __bf16* yy = (__bf16*)y;
+    LN_DISPATCH(ln_fwd_kernel, TT, xx, ldx, gamma, beta, eps, yy, ldy, mean, rstd, rows);
+  } else {
+    using TT = _Float16;
+    const _Float16* xx = (const _Float16*)x; _Float16* yy = (_Float16*)y;
     LN_DISPATCH(ln_fwd_kernel, TT, xx, ldx, gamma, beta, eps, yy, ldy, mean, rstd, rows);
   }
   VLNI_LAUNCH_CHECK();
@@ -252,9 +256,13 @@ extern "C" int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const vo
     using TT = float;
     const float* d = (const float*)dy; const float* xx = (const float*)x; float* o = (float*)dx; const float* dr = (const float*)dres; float* dd = (float*)dx_drop;
     LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p), vlni_seed_base());
-  } else {
+  } else if (dtype == VLNI_BF16) {
     using TT = __bf16;
     const __bf16* d = (const __bf16*)dy; const __bf16* xx = (const __bf16*)x; __bf16* o = (__bf16*)dx; const __bf16* dr = (const __bf16*)dres; __bf16* dd = (__bf16*)dx_drop;
+    LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p), vlni_seed_base());
+  } else {
+    using TT = _Float16;
+    const _Float16* d = (const _Float16*)dy; const _Float16* xx = (const _Float16*)x; _Float16* o = (_Float16*)dx; const _Float16* dr = (const _Float16*)dres; _Float16* dd = (_Float16*)dx_drop;
     LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p), vlni_seed_base());
   }
   VLNI_LAUNCH_CHECK();
@@ -281,9 +289,13 @@ extern "C" int vlni_sum_layernorm_fwd(int dtype, int n, const void* const* src, 
     using TT = float;
     float* yy = (float*)y; float* xs = (float*)xsum;
     LN_DISPATCH(sum_ln_fwd_kernel, TT, sp, gamma, beta, eps, yy, ldy, xs, ldxs, mean, rstd, rows);
-  } else {
+  } else if (dtype == VLNI_BF16) {
     using TT = __bf16;
     __bf16* yy = (__bf16*)y; __bf16* xs = (__bf16*)xsum;
+    LN_DISPATCH(sum_ln_fwd_kernel, TT, sp, gamma, beta, eps, yy, ldy, xs, ldxs, mean, rstd, rows);
+  } else {
+    using TT = _Float16;
+    _Float16* yy = (_Float16*)y; _Float16* xs = (_Float16*)xsum;
     LN_DISPATCH(sum_ln_fwd_kernel, TT, sp, gamma, beta, eps, yy, ldy, xs, ldxs, mean, rstd, rows);
   }
   VLNI_LAUNCH_CHECK();

@@ -523,7 +523,7 @@ class NavCMT(nn.Module):
         return grad
 
     def set_compute_dtype(self, dtype):
-        assert dtype in (torch.float32, torch.bfloat16)
+        assert dtype in (torch.float32, torch.bfloat16, torch.float16)
         self.compute_dtype = dtype
         return self
 

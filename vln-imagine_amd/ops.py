@@ -18,8 +18,9 @@ import torch
 
 from . import _lib
 
-F32, BF16 = 0, 1
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+F32, BF16, F16 = 0, 1, 2
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+H16 = (torch.bfloat16, torch.float16)       # the two throughput dtypes: same kernels, bf16 or f16 MFMA (csrc/*_impl.inc)
 NEG_MASK = -10000.0
 
 
@@ -27,7 +28,7 @@ def _dt(t):
     try:
         return _DT[t.dtype]
     except KeyError:
-        raise TypeError(f"vlni ops take float32 or bfloat16 activations, got {t.dtype}")
+        raise TypeError(f"vlni ops take float32, bfloat16 or float16 activations, got {t.dtype}")
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
@@ -123,7 +124,7 @@ def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_s
     if kn:
         b = b.t
         N = b.shape[1]
-        assert b.shape[0] == K and a.dtype == b.dtype == torch.bfloat16 and a.stride(1) == 1 and b.stride(1) == 1 and not atomic
+        assert b.shape[0] == K and a.dtype == b.dtype and a.dtype in H16 and a.stride(1) == 1 and b.stride(1) == 1 and not atomic
     else:
         N = b.shape[0]
         assert b.shape[1] == K and a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1
@@ -172,7 +173,7 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
         b0, b1 = b0.t, b1.t
         b = (b0, b1)
         N = b0.shape[1]
-        assert b0.shape[0] == K and a0.dtype == torch.bfloat16
+        assert b0.shape[0] == K and a0.dtype in H16
     else:
         N = b0.shape[0]
     assert b1.shape == b0.shape and a1.shape[1] == K and a0.dtype == a1.dtype == b0.dtype == b1.dtype
@@ -228,15 +229,15 @@ def wgrad(dy, x, out=None, colsum_out=None, want_colsum=False):
     if (want_colsum or colsum_out is not None) and colsum_out is None:
         colsum_out = torch.zeros((N,), dtype=torch.float32, device=dev)
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
-    if dy.dtype == torch.bfloat16 and N % 8 == 0 and K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
+    if dy.dtype in H16 and N % 8 == 0 and K % 8 == 0 and dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0:
         split = max(1, min(8, ((M + 63) // 64) // 8, round(768 / tiles)))
-        _lib.call("vlni_gemm_tn_bf16", dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0),
-                  M, N, K, _p(colsum_out), split, _st())
+        _lib.call("vlni_gemm_tn_h16_grouped_v", _dt(dy), 1, (ctypes.c_void_p * 1)(dy.data_ptr()), (ctypes.c_void_p * 1)(x.data_ptr()),
+                  (ctypes.c_int * 1)(M), dy.stride(0), x.stride(0), out.data_ptr(), out.stride(0), N, K, _p(colsum_out), split, 0, _st())
     else:
         mp = (M + 63) // 64 * 64
         dyt = transpose_pad(dy, mp)
         xt = transpose_pad(x, mp)
-        bk = 64 if dy.dtype == torch.bfloat16 else 32
+        bk = 64 if dy.dtype in H16 else 32
         nkt = (mp + bk - 1) // bk
         split = max(1, min(nkt, 8, round(512 / tiles)))
         gemm_nt(dyt, xt, out=out, split_k=split, atomic=True)
@@ -307,7 +308,7 @@ def attn_bwd(q, k, v, out, dout, lse, dq, dk, dv, B, Sq, Sk, kmask=None, bias=No
 
 def _dual_attn_ok(*ts):
     """bf16 operands whose rows start on 16-byte boundaries with strides that are multiples of 8: the dual-problem launch."""
-    return all(t.dtype == torch.bfloat16 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1 for t in ts)
+    return all(t.dtype in H16 and t.dtype == ts[0].dtype and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 and t.stride(1) == 1 for t in ts)
 
 
 def _p2(ts):
@@ -327,7 +328,7 @@ def attn_fwd2(q, k, v, B, Sq, Sk, kmask=(None, None), bias0=None, nh=12, drop=No
                 attn_fwd(q[1], k[1], v[1], B, Sq[1], Sk[1], kmask[1], None, nh, drop=(p_, seeds[1])))
     outs = tuple(torch.empty((B * Sq[i], nh * 64), dtype=q[i].dtype, device=q[i].device) for i in range(2))
     lses = tuple(torch.empty((B, nh, Sq[i]), dtype=torch.float32, device=q[i].device) for i in range(2))
-    _lib.call("vlni_attn_fwd_dual", BF16, _p2(q), _l2(q), _p2(k), _l2(k), _p2(v), _l2(v), _p2(kmask), _p2((bias0, None)), _p2(outs), _l2(outs),
+    _lib.call("vlni_attn_fwd_dual", _dt(q[0]), _p2(q), _l2(q), _p2(k), _l2(k), _p2(v), _l2(v), _p2(kmask), _p2((bias0, None)), _p2(outs), _l2(outs),
               _p2(lses), B, nh, (ctypes.c_int * 2)(*Sq), (ctypes.c_int * 2)(*Sk), 1.0 / 8.0, p_, (ctypes.c_uint * 2)(*seeds), _st())
     return (outs[0], lses[0]), (outs[1], lses[1])
 
@@ -339,7 +340,7 @@ def attn_bwd2(q, k, v, out, dout, lse, dq, dk, dv, B, Sq, Sk, kmask=(None, None)
         attn_bwd(q[0], k[0], v[0], out[0], dout[0], lse[0], dq[0], dk[0], dv[0], B, Sq[0], Sk[0], kmask[0], bias0, dbias0, nh, drop=(p_, seeds[0]))
         attn_bwd(q[1], k[1], v[1], out[1], dout[1], lse[1], dq[1], dk[1], dv[1], B, Sq[1], Sk[1], kmask[1], None, None, nh, drop=(p_, seeds[1]))
         return
-    _lib.call("vlni_attn_bwd_dual", BF16, _p2(q), _l2(q), _p2(k), _l2(k), _p2(v), _l2(v), _p2(kmask), _p2((bias0, None)), _p2(out), _l2(out),
+    _lib.call("vlni_attn_bwd_dual", _dt(q[0]), _p2(q), _l2(q), _p2(k), _l2(k), _p2(v), _l2(v), _p2(kmask), _p2((bias0, None)), _p2(out), _l2(out),
               _p2(dout), _l2(dout), _p2(lse), _p2(dq), _l2(dq), _p2(dk), _l2(dk), _p2(dv), _l2(dv), _p(dbias0), B, nh,
               (ctypes.c_int * 2)(*Sq), (ctypes.c_int * 2)(*Sk), 1.0 / 8.0, p_, (ctypes.c_uint * 2)(*seeds), _st())
 
@@ -481,7 +482,7 @@ class ShadowCache:
         if not self.prepare():
             return False
         tab, n, tiles = self._tr_table
-        _lib.call("vlni_transpose_batched", _DT[torch.bfloat16], tab.data_ptr(), n, tiles, _st())
+        _lib.call("vlni_transpose_batched", _DT[self.arena[1].dtype], tab.data_ptr(), n, tiles, _st())
         for k in self._tr:
             e = self._c[k]
             self._c[k] = (e[0], e[1], e[2], self.opt_epoch, e[4])
@@ -522,7 +523,7 @@ class ShadowCache:
         with torch.no_grad():
             for p in params:
                 _chk(p, "parameter")
-            mir = self._mirror(params) if dtype == torch.bfloat16 else None
+            mir = self._mirror(params) if (self.arena is not None and dtype == self.arena[1].dtype) else None
             if mir is not None and (hit is None or hit[0] != ver):
                 # (re)fill this slice of the mirror once per epoch; afterwards the optimizer kernel maintains it
                 _lib.call("vlni_cast", _DT[torch.float32], _DT[dtype], mir[0].data_ptr(), mir[1].data_ptr(), mir[0].numel(), _st())
@@ -557,7 +558,7 @@ def _w(params, dtype, transposed=False):
     """Operand form of a (possibly row-packed) parameter. transposed=True is the dgrad operand: W^T [in, out] for the NT kernels,
     or - bf16 with NN_DGRAD - a WT handle that the GEMM front-ends turn into the untransposed weight (KN, transposing-read kernels,
     no copy to rebuild) or the W^T copy depending on the launch's row count."""
-    if transposed and NN_DGRAD and dtype == torch.bfloat16 and params[0].dim() == 2:
+    if transposed and NN_DGRAD and dtype in H16 and params[0].dim() == 2:
         out_f = sum(p.shape[0] for p in params)
         if out_f % 64 == 0 and out_f >= 192 and params[0].shape[1] % 8 == 0:
             return WT(params, dtype)
@@ -656,7 +657,7 @@ def _parts_ok(variant, nmt, split):
     return WGRAD_PARTS and eff > 1 and variant >= 2 and per >= 3
 
 
-def _tn_choice(n, pa, pb, pm, N, K, nmt, dev):
+def _tn_choice(n, pa, pb, pm, N, K, nmt, dev, dtid=BF16):
     """(kernel variant, row split) of a grouped weight-gradient launch. Which of the 128x128 LDS-DMA kernel (more, smaller blocks)
     and the 256x256 tiles (half the operand traffic, one block per CU) wins, and at which split, depends on the output size and on
     the length of the reduction (tools/tn_probe.py): the first launch of a (N, K, rows) class times the candidates on a scratch
@@ -681,11 +682,11 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev):
     for v, sp in sorted(cands):
         if _parts_ok(v, nmt, sp):
             eff = _eff_split(nmt, sp)[0]
-            args = ("vlni_gemm_tn_bf16_grouped_part", n, pa, pb, pm, N, K, scratch.data_ptr(), N * K, N, K,
+            args = ("vlni_gemm_tn_h16_grouped_part", dtid, n, pa, pb, pm, N, K, scratch.data_ptr(), N * K, N, K,
                     scratch.data_ptr() + 4 * smax * N * K, sp, v, _st())
             extra = (eff + 2) * (N * K + N) * 4 / 4e9            # ms: its share of the batched reduction
         else:
-            args = ("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, scratch.data_ptr(), K, N, K, scratch.data_ptr() + 4 * N * K,
+            args = ("vlni_gemm_tn_h16_grouped_v", dtid, n, pa, pb, pm, N, K, scratch.data_ptr(), K, N, K, scratch.data_ptr() + 4 * N * K,
                     sp, v, _st())
             extra = 0.0
         _lib.call(*args)
@@ -720,10 +721,11 @@ def flush_wgrads(lo=None, hi=None):
             pb = (ctypes.c_void_p * n)(*[x.data_ptr() for _, x in chunk])
             pm = (ctypes.c_int * n)(*[d.shape[0] for d, _ in chunk])
             nmt = sum((d.shape[0] + 63) // 64 for d, _ in chunk)
-            variant, split = _tn_choice(n, pa, pb, pm, N, K, nmt, wv.device)
+            dtid = _dt(chunk[0][0])
+            variant, split = _tn_choice(n, pa, pb, pm, N, K, nmt, wv.device, dtid)
             parts = _parts_ok(variant, nmt, split) and wv.is_contiguous() and bv.is_contiguous() and N % 4 == 0
             eff = _eff_split(nmt, split)[0] if parts else 0
-            plans.append((n, pa, pb, pm, variant, split, tot if parts else -1))
+            plans.append((n, pa, pb, pm, variant, split, tot if parts else -1, dtid))
             tot += eff
         buf = None
         if tot:
@@ -734,12 +736,12 @@ def flush_wgrads(lo=None, hi=None):
                     _KEEPALIVE.append(buf)     # a captured step (another shape bucket's graph) may still write its partials there
                 buf = _PART_BUFS[key] = torch.empty((tot * (N * K + N),), dtype=torch.float32, device=wv.device)
             cpart = buf.data_ptr() + 4 * tot * N * K         # [tot][N] column-sum partials behind the [tot][N][K] slabs
-        for n, pa, pb, pm, variant, split, z0 in plans:
+        for n, pa, pb, pm, variant, split, z0, dtid in plans:
             if z0 >= 0:
-                _lib.call("vlni_gemm_tn_bf16_grouped_part", n, pa, pb, pm, N, K, buf.data_ptr() + 4 * z0 * N * K, N * K, N, K,
+                _lib.call("vlni_gemm_tn_h16_grouped_part", dtid, n, pa, pb, pm, N, K, buf.data_ptr() + 4 * z0 * N * K, N * K, N, K,
                           cpart + 4 * z0 * N, split, variant, _st())
             else:                                            # unsplit (or register-staged) launch: float atomics straight into the arena
-                _lib.call("vlni_gemm_tn_bf16_grouped_v", n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
+                _lib.call("vlni_gemm_tn_h16_grouped_v", dtid, n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
                           split, variant, _st())
         if tot:
             # exactly ONE reduction entry per destination: reduce_parts_kernel's read-modify-write of dst is not atomic
@@ -765,7 +767,7 @@ def _wb_grad_to(ws, bs, dy, x):
         wv = _packed_grad(ws) if len(ws) > 1 else ws[0].grad
         bv = _packed_grad(bs) if len(bs) > 1 else bs[0].grad
         if wv is not None and bv is not None:
-            if getattr(ws[0], "_vlni_defer", False) and dy.dtype == torch.bfloat16 and dy.is_contiguous() and x.is_contiguous() \
+            if getattr(ws[0], "_vlni_defer", False) and dy.dtype in H16 and dy.is_contiguous() and x.is_contiguous() \
                     and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
                 ent = _WQ.get(wv.data_ptr())
                 if ent is None:

@@ -194,8 +194,10 @@ class FlatTrainer:
         self.overlap_chunks = max(1, int(overlap_chunks))
         self._side = None
         self.graph_epoch = 0
-        # compute-dtype mirror of the parameter arena, kept current by the AdamW kernel (ops.ShadowCache hands out views of it)
-        self.flat_b = torch.empty(n, dtype=torch.bfloat16, device=dev)
+        # compute-dtype mirror of the parameter arena, kept current by the AdamW kernel (ops.ShadowCache hands out views of it):
+        # bfloat16, or float16 when the model computes in float16 (then pair it with loss_scale / growth_interval)
+        cd = getattr(model, "compute_dtype", torch.bfloat16)
+        self.flat_b = torch.empty(n, dtype=cd if cd in ops.H16 else torch.bfloat16, device=dev)
         if broadcast and _world() > 1:
             self.broadcast_from(0)
         ops.SHADOWS.set_arena(self.flat_p, self.flat_b)
@@ -304,7 +306,7 @@ class FlatTrainer:
         _lib.call("vlni_optim_prepare_groups", self.sumsq.data_ptr(), self.max_norm, b1, b2, self.state.data_ptr(),
                   self.gstate.data_ptr(), self.grp_lr.data_ptr(), G, self.growth_interval, st)
         _lib.call("vlni_adamw_step_groups", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                  self.flat_b.data_ptr(), ops.BF16, self.n, self.grp_end.data_ptr(), self.grp_lr.data_ptr(), self.gstate.data_ptr(),
+                  self.flat_b.data_ptr(), ops._DT[self.flat_b.dtype], self.n, self.grp_end.data_ptr(), self.grp_lr.data_ptr(), self.gstate.data_ptr(),
                   G, b1, b2, eps, wd, self.state.data_ptr(), st)
         ops.SHADOWS.invalidate(optimizer_step=ops.SHADOWS.arena is not None and ops.SHADOWS.arena[0] is self.flat_p)
 
