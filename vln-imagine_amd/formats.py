@@ -8,8 +8,9 @@ What the reference reads at run time, and where:
   * feature stores        r2r/data_utils.py:15-47  HDF5, one dataset per key: view features 'scan_viewpoint' -> [36, >= D],
                           imagination features 'pathid_instridx' -> [n_true, >= D]; first D columns, float32
 The reference re-opens the HDF5 file per key inside the rollout and pads on the host every batch; here each file is walked once
-and its rows live in HBM afterwards. HDF5 needs h5py (not part of this image: `from_hdf5` raises ImportError with that message);
-the same tables load from a directory of .npy files or an .npz archive with identical keys."""
+and its rows live in HBM afterwards. HDF5 goes through h5py where it is installed and through hdf5_lite.py (a pure-Python reader of
+the classic HDF5 subset these stores use: symbol-table root group, contiguous or chunked + gzip 2-D datasets) where it is not - it
+is not part of this image; the same tables also load from a directory of .npy files or an .npz archive with identical keys."""
 import json
 import os
 
@@ -58,12 +59,17 @@ def _iter_store(path, feat_size):
     else:
         try:
             import h5py
-        except ImportError as e:
-            raise ImportError("reading the reference's HDF5 feature stores needs h5py (not in this image); export them once to .npz / "
-                              "a directory of .npy files with the same keys") from e
-        with h5py.File(path, "r") as f:
+        except ImportError:
+            h5py = None
+        if h5py is not None:
+            with h5py.File(path, "r") as f:
+                for k in f.keys():
+                    yield k, f[k][...][:, :feat_size].astype(np.float32)
+        else:                               # no h5py in this image: the classic-HDF5 subset these stores use, read in pure Python
+            from .hdf5_lite import Hdf5File
+            f = Hdf5File(path)
             for k in f.keys():
-                yield k, f[k][...][:, :feat_size].astype(np.float32)
+                yield k, f[k][:, :feat_size].astype(np.float32)
 
 
 def load_view_features(path, feat_size=768, device="cuda", dtype=None):
