@@ -73,3 +73,53 @@ def test_superblock_fields_follow_the_specification(tmp_path):
     base, _, eof, _ = struct.unpack_from("<QQQQ", b, 24)
     assert base == 0 and eof == len(b)
     assert struct.unpack_from("<I", b, 56 + 16)[0] == 1           # root entry caches the B-tree / heap addresses
+
+
+# ---- cross-checks against the HDF5 library's own tools, where the image carries them (HDF5 1.10.6 under /opt/conda/bin) ----
+H5TOOLS = os.environ.get("H5TOOLS", "/opt/conda/bin")
+needs_h5tools = pytest.mark.skipif(not all(os.path.exists(os.path.join(H5TOOLS, t)) for t in ("h5repack", "h5dump")),
+                                   reason="HDF5 command-line tools not installed")
+
+
+@needs_h5tools
+@pytest.mark.parametrize("args", [["-f", "SHUF", "-f", "GZIP=6"], ["-f", "GZIP=1", "-f", "FLET"], ["-l", "CHUNK=36x800", "-f", "GZIP=9"],
+                                  ["-l", "CHUNK=5x33"], ["-l", "CONTI", "-f", "NONE"], ["-l", "COMPA", "-f", "NONE"]])
+def test_reader_on_library_written_variants(tmp_path, args):
+    """h5repack rewrites the view store with other layouts / filter pipelines (shuffle + deflate is h5py's `shuffle=True`; a 5 x 33
+    chunking gives a B-tree with more than one level); the reader returns the same arrays."""
+    import subprocess
+    want = {k: v[:8, :100] if "COMPA" in args else v for k, v in view_arrays().items()}
+    src = os.path.join(GOLDEN, "views_tiny.hdf5")
+    if "COMPA" in args:                                        # compact data lives in the object header: at most 64 KB
+        src = str(tmp_path / "small.hdf5")
+        write_store(src, want)
+    dst = str(tmp_path / "v.hdf5")
+    subprocess.run([os.path.join(H5TOOLS, "h5repack")] + args + [src, dst], check=True, capture_output=True)
+    got = read_store(dst)
+    assert sorted(got) == sorted(want)
+    for k, a in want.items():
+        assert got[k].dtype == a.dtype and np.array_equal(got[k], a), k
+
+
+@needs_h5tools
+def test_reader_refuses_the_new_file_format_by_name(tmp_path):
+    import subprocess
+    dst = str(tmp_path / "latest.hdf5")
+    subprocess.run([os.path.join(H5TOOLS, "h5repack"), "-L", os.path.join(GOLDEN, "imag_tiny.hdf5"), dst], check=True, capture_output=True)
+    with pytest.raises(NotImplementedError, match="superblock version"):
+        Hdf5File(dst)
+
+
+@needs_h5tools
+@pytest.mark.parametrize("chunks,compress", [(None, False), ((9, 250), True), ((7, 64), False)])
+def test_library_reads_what_the_fixture_writer_writes(tmp_path, chunks, compress):
+    """write_store is test infrastructure; the library's h5dump must read its files back to the same bytes."""
+    import subprocess
+    rng = np.random.default_rng(5)
+    arrays = {f"k{i:02d}": rng.standard_normal((36, 300)).astype([np.float64, np.float32][i % 2]) for i in range(11)}
+    path = str(tmp_path / "w.hdf5")
+    write_store(path, arrays, chunks=chunks, compress=compress)
+    for k, a in arrays.items():
+        out = str(tmp_path / "d.bin")
+        subprocess.run([os.path.join(H5TOOLS, "h5dump"), "-d", "/" + k, "-b", "LE", "-o", out, path], check=True, capture_output=True)
+        assert np.array_equal(np.fromfile(out, a.dtype.newbyteorder("<")).reshape(a.shape), a), k

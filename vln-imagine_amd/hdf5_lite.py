@@ -234,6 +234,9 @@ def read_store(path):
 # =====================================================================================================================
 #  fixture writer (classic layout: superblock v0, symbol-table root group, v1 object headers)
 # =====================================================================================================================
+GROUP_K, CHUNK_K = 16, 32                                     # library defaults: children per B-tree node = 2 K
+
+
 def _pad8(b):
     return b + b"\0" * (-len(b) % 8)
 
@@ -297,14 +300,16 @@ def write_store(path, arrays, chunks=None, compress=True, leaf_k=4):
             node = b"TREE" + struct.pack("<BBHQQ", 1, 0, len(keys), UNDEF, UNDEF)
             for nbytes, r0, c0, addr in keys:
                 node += struct.pack("<IIQQQ", nbytes, 0, r0, c0, 0) + struct.pack("<Q", addr)
-            node += struct.pack("<IIQQQ", 0, 0, a.shape[0], a.shape[1], 0)        # the final key
+            node += struct.pack("<IIQQQ", 0, 0, -(-a.shape[0] // cr) * cr, -(-a.shape[1] // cc) * cc, 0)   # the final key: one chunk past the last
+            assert len(keys) <= 2 * CHUNK_K, "fixture writer: one chunk B-tree node"
+            node += b"\0" * (24 + 2 * CHUNK_K * 8 + (2 * CHUNK_K + 1) * 32 - len(node))   # nodes are allocated at full size
             bt = put(node)
             if compress:
                 msgs.append(_msg(0xB, struct.pack("<BB6x", 1, 1) + struct.pack("<HHHH", 1, 0, 1, 1) + struct.pack("<II", 4, 0)))
             msgs.append(_msg(0x8, struct.pack("<BBBQIII", 3, 2, 3, bt, cr, cc, a.dtype.itemsize)))
         hdr_addr[k] = put(_object_header(msgs))
     heap_seg = put(bytes(heap_data))
-    heap = put(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), UNDEF, heap_seg))
+    heap = put(b"HEAP" + struct.pack("<B3xQQQ", 0, len(heap_data), 1, heap_seg))       # free-list head 1 = no free block (H5HL_FREE_NULL)
     per = 2 * leaf_k
     leaves = []
     for i in range(0, len(names), per):
@@ -317,9 +322,11 @@ def write_store(path, arrays, chunks=None, compress=True, leaf_k=4):
     tree = b"TREE" + struct.pack("<BBHQQ", 0, 0, len(leaves), UNDEF, UNDEF) + struct.pack("<Q", 0)
     for addr, last in leaves:
         tree += struct.pack("<QQ", addr, last)
+    assert len(leaves) <= 2 * GROUP_K, "fixture writer: one group B-tree node"
+    tree += b"\0" * (24 + 2 * GROUP_K * 8 + (2 * GROUP_K + 1) * 8 - len(tree))
     btree = put(tree)
     root = put(_object_header([_msg(0x11, struct.pack("<QQ", btree, heap))]))
-    sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, leaf_k, 16, 0) + struct.pack("<QQQQ", 0, UNDEF, len(out), UNDEF)
+    sb = SIG + struct.pack("<BBBBBBBBHHI", 0, 0, 0, 0, 0, 8, 8, 0, leaf_k, GROUP_K, 0) + struct.pack("<QQQQ", 0, UNDEF, len(out), UNDEF)
     sb += struct.pack("<QQII", 0, root, 1, 0) + struct.pack("<QQ", btree, heap)
     out[:len(sb)] = sb
     with open(path, "wb") as f:
