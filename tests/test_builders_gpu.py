@@ -154,16 +154,22 @@ def test_hamt_rollout_with_device_builders_matches_reference_golden(golden_dir):
             assert abs(nrm - ref) <= max(2e-4 * ref, 2e-5), (n, nrm, ref)
 
 
-def test_feature_stores_from_disk_feed_the_resident_tables(tmp_path):
-    """formats.load_view_features / load_imagination_table (.npz stand-ins for the reference's HDF5 stores, same keys) -> the device
-    builders give what the in-memory construction gives."""
+@pytest.mark.parametrize("kind", ["npz", "hdf5"])
+def test_feature_stores_from_disk_feed_the_resident_tables(tmp_path, kind):
+    """formats.load_view_features / load_imagination_table (the reference's HDF5 stores - float64, chunked + gzip for the views - or .npz
+    archives with the same keys) -> the device builders give what the in-memory construction gives."""
     from oracle import graph_oracle as GO
     from vln_imagine_amd import formats
     from vln_imagine_amd.builders import ViewBuilder
+    from vln_imagine_amd.hdf5_lite import write_store
     feats, keys, obs = _fake_env(seed=11)
     wide = np.concatenate([feats, np.zeros(feats.shape[:2] + (4,), np.float32)], 2)          # stores carry >= D columns
-    np.savez(tmp_path / "views.npz", **{k: wide[i] for i, k in enumerate(keys)})
-    table = formats.load_view_features(str(tmp_path / "views.npz"))
+    store = {k: wide[i] for i, k in enumerate(keys)}
+    if kind == "npz":
+        np.savez(tmp_path / "views.npz", **store)
+    else:
+        write_store(str(tmp_path / "views.hdf5"), {k: v.astype(np.float64) for k, v in store.items()}, chunks=(9, 256), compress=True)
+    table = formats.load_view_features(str(tmp_path / f"views.{kind}"))
     assert sorted(table.index) == sorted(keys)
     img, ang, nav, lens, cl = ViewBuilder(table, A).hamt_observation(obs)
     from vln_imagine_amd.builders import ResidentFeatures
@@ -172,8 +178,11 @@ def test_feature_stores_from_disk_feed_the_resident_tables(tmp_path):
     flags = {"7_0": ["True", "False", "True"], "7_1": ["False", "False"], "9_2": ["False", "True"]}
     rng = np.random.default_rng(3)
     imag = {"7_0": rng.standard_normal((2, 770)).astype(np.float32), "9_2": rng.standard_normal((1, 770)).astype(np.float32)}
-    np.savez(tmp_path / "imag.npz", **imag)
-    t = formats.load_imagination_table(str(tmp_path / "imag.npz"), flags)
+    if kind == "npz":
+        np.savez(tmp_path / "imag.npz", **imag)
+    else:
+        write_store(str(tmp_path / "imag.hdf5"), imag)
+    t = formats.load_imagination_table(str(tmp_path / f"imag.{kind}"), flags)
     f, m = t.batch(["9_2", "7_1", "7_0"])
     rf, rm = GO.imaginations_v2(["9_2", "7_1", "7_0"], flags, imag)
     assert np.array_equal(f.cpu().numpy(), rf) and np.array_equal(m.cpu().numpy(), rm)

@@ -7,7 +7,7 @@ from vln_imagine_amd import ops
 dt = torch.bfloat16
 shapes = [(5120, 3072, 768), (8192, 3072, 768), (8192, 768, 3072), (8192, 2304, 768), (8192, 768, 768), (5120, 3072, 768), (5120, 768, 3072),
           (2304, 768, 768), (2304, 3072, 768), (2304, 768, 3072), (30720, 3072, 768), (30720, 768, 3072), (30720, 768, 768), (4096, 4096, 4096)]
-variants = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)
+variants = tuple(int(v) for v in os.environ.get("VARIANTS", "1,2,3,4,5,6,7,8,9,10,11,12,13").split(","))
 for (M, N, K) in shapes:
     a = (torch.randn(M, K, device="cuda") * 0.5).to(dt); b = (torch.randn(N, K, device="cuda") * 0.05).to(dt)
     bias = torch.randn(N, device="cuda"); out = torch.empty(M, N, device="cuda", dtype=dt); z = torch.empty_like(out)
