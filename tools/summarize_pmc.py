@@ -18,7 +18,7 @@ def load(d):
 
 
 def fam(name):
-    for k in ("gemm_nt_big", "gemm_nt_glds", "gemm_nt_kernel", "gemm_nn_glds", "gemm_tn_ring", "gemm_tn_big", "gemm_tn_glds", "gemm_tn_bf16", "reduce_parts", "attn_bwd_bf16",
+    for k in ("gemm_pkr", "gemm_pk", "gemm_nt_big", "gemm_nt_glds", "gemm_nt_kernel", "gemm_nn_glds", "gemm_tn_ring", "gemm_tn_big", "gemm_tn_glds", "gemm_tn_bf16", "reduce_parts", "attn_bwd_bf16",
               "attn_fwd_bf16", "ln_bwd", "ln_fwd", "adamw"):
         if k in name:
             return k
@@ -38,13 +38,13 @@ def per_family(rows, counter):
 
 
 fe, wr = per_family(load(fetch_dir), "FETCH_SIZE"), per_family(load(write_dir), "WRITE_SIZE")
-nt = [k for k in fe if k.startswith("gemm_nt") or k.startswith("gemm_nn")]
+nt = [k for k in fe if k.startswith(("gemm_nt", "gemm_nn", "gemm_pk"))]
 launches = sum(fe[k][0] for k in nt)
 fetch_kb = sum(fe[k][1] for k in nt) / launches
 write_kb = sum(wr[k][1] for k in nt) / max(1, sum(wr[k][0] for k in nt))
 traffic = {
-    "kernel_family": "gemm_nt_kernel / gemm_nt_glds_kernel / gemm_nt_big_kernel / gemm_nn_glds_kernel (bf16): every forward and dgrad projection",
-    "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 2 --no-graph; launches of the last step only (no autotune trials)",
+    "kernel_family": "gemm_pk_kernel / gemm_nt_kernel / gemm_nt_glds_kernel / gemm_nt_big_kernel / gemm_nn_glds_kernel (bf16): every forward and dgrad projection",
+    "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 2 --no-graph --no-cpu-baseline --no-extras --no-parity --no-roofline; launches of the last step only (no autotune trials)",
     "launches": launches, "fetch_kb_per_launch_raw": fetch_kb, "write_kb_per_launch": write_kb,
     "correction": "gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads: doubled (MI355X_MICROARCH.md, HBM section); Infinity-Cache hits are counted too",
     "bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
@@ -56,7 +56,7 @@ names = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT", 
 agg = {n: per_family(sq, n) for n in names}
 out = [f"# rocprofv3 --pmc (SQ / GRBM) on the bench step ({tag})", "",
        "command: `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES",
-       "--output-format csv -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-time-batched-extra --no-roofline --no-graph`",
+       "--output-format csv -- python3 bench.py --steps 1 --warmup 2 --no-cpu-baseline --no-extras --no-parity --no-roofline --no-graph`",
        "(own pass, no trace domains; sums over the launches of the last step, i.e. without the autotune trials of the warm-up).", "",
        "MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); LDS busy = SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES.", "",
        "| kernel family | launches | MFMA busy cycles | GRBM_GUI_ACTIVE | MFMA utilisation | SQ_LDS_BANK_CONFLICT | conflict / LDS active |", "|---|---|---|---|---|---|---|"]
