@@ -218,6 +218,9 @@ def main():
     ap.add_argument("--V", type=int, default=37)
     ap.add_argument("--I", type=int, default=6)
     ap.add_argument("--freeze", default="none", choices=["none", "shipped"])
+    ap.add_argument("--lang-rows", default="all", choices=["all", "cls"],
+                    help="HAMT: 'all' = every language row through the last cross-modal layer like the reference's NavCMT (the headline); "
+                         "'cls' = only the row the agent reads (what the VLNBertCMT wrapper selects; identical results)")
     ap.add_argument("--time-batched", action="store_true",
                     help="HAMT: run the T teacher-forced steps as one [T*B] batch (same results, SURVEY 8f rank 1)")
     ap.add_argument("--train-mode", action="store_true", help="model.train(): in-kernel dropout p = 0.1 (the reference's training mode)")
@@ -363,6 +366,8 @@ def main():
 
     # ---- the metric's workload -------------------------------------------------------------------------------------------
     w = Workload(args.model, args, shipped, dev, dtype, tag=f"bench{rank}")
+    if args.model == "hamt":
+        w.model.visual_lang_rows = args.lang_rows
     if args.train_mode:
         w.model.train()
     trainer = FlatTrainer(w.model, lr=1e-5, grad_comm_dtype=comm, **scaler)
@@ -486,6 +491,13 @@ def main():
         if args.model == "hamt" and not args.time_batched:
             s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=True, graph=args.graph, what="time-batched")
             extras["time_batched"] = line(s_, w.flops, "T steps as one [T*B] batch under teacher forcing; same results as the step-by-step calls")
+        if args.model == "hamt" and args.lang_rows == "all":
+            w.model.visual_lang_rows = "cls"
+            s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="cls-rows")
+            w.model.visual_lang_rows = "all"
+            extras["cls_rows"] = line(s_, w.flops, "what the VLNBertCMT wrapper runs: the last cross-modal layer computes only the language [CLS] row it "
+                                                   "reads (NavCMT.visual_lang_rows = 'cls'); logits, loss and gradients identical "
+                                                   "(tests/test_hamt_gpu.py), step_algorithmic_tflops still counts the reference's full rows")
         if not args.train_mode:
             w.model.train()
             s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="train-mode")
@@ -539,7 +551,8 @@ def main():
             "config": {"workload": f"{w.label}, batch {args.batch}/GPU, {args.L} text, {args.V} obs tokens, "
                                    f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, "
                                    + ("train mode: in-kernel dropout p=0.1" if args.train_mode else "dropout p=0 (eval)")
-                                   + (", steps time-batched (teacher forcing)" if args.time_batched else ", step-by-step calls"),
+                                   + (", steps time-batched (teacher forcing)" if args.time_batched else ", step-by-step calls")
+                                   + (", last X-layer: language [CLS] row only" if args.model == "hamt" and args.lang_rows == "cls" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": launch, "rccl": rccl,
                        "grad_allreduce": (args.grad_comm + " payload, flat arena, flush -> all-reduce pipeline, RCCL") if world > 1 else "none (1 GPU)",

@@ -227,6 +227,38 @@ def test_time_batched_episode_equals_stepwise():
         assert d <= 3e-5 * max(1.0, p.grad.abs().max().item()), (n, d)
 
 
+@pytest.mark.parametrize("variant", ["c1_T3_dense", "c1_shipped"])
+def test_cls_row_mode_of_the_last_cross_modal_layer_changes_nothing(variant):
+    """NavCMT.visual_lang_rows = 'cls' (what the VLNBertCMT wrapper selects): the last cross-modal layer computes the language
+    stream's [CLS] row only. Logits, loss and every gradient equal the all-rows run (fp32; sums run in another order)."""
+    cfg, ep = hamt_variant_setup(variant)
+    et = EpisodeTensors(ep, "cuda")
+    m1, m2 = build_product(cfg), build_product(cfg)
+    m2.visual_lang_rows = "cls"
+    o1 = run_episode(m1, et)
+    o1["loss"].backward()
+    o2 = run_episode(m2, et)
+    o2["loss"].backward()
+    assert abs(o1["loss"].item() - o2["loss"].item()) < 1e-5
+    for t in range(ep.T):
+        a, b = o1["logits"][t], o2["logits"][t]
+        fin = torch.isfinite(a)
+        assert (torch.isfinite(b) == fin).all() and (a[fin] - b[fin]).abs().max().item() < 2e-5
+    seen = 0
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None or float(q.grad.abs().max()) == 0, n
+            continue
+        seen += 1
+        d = (p.grad - q.grad).abs().max().item()
+        assert d <= 3e-5 * max(1.0, p.grad.abs().max().item()), (n, d)
+    assert seen > 20
+    assert o2["txt_o"][0].shape[1] == 1 and o1["txt_o"][0].shape[1] == ep.L          # txt_embeds comes back as [B, 1, H] in this mode
+    assert (o1["txt_o"][-1][:, :1] - o2["txt_o"][-1]).abs().max().item() < 1e-5
+    for t in range(ep.T):
+        assert (o1["states"][t] - o2["states"][t]).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("family", ["hamt", "duet"])
 def test_graphed_step_replays_the_eager_step(family):
     """FlatTrainer.capture: zero_grad + fwd + bwd + wgrad flush in one hipGraph, clip + AdamW in a second (step count, bias

@@ -19,6 +19,9 @@ class VLNBertCMT(nn.Module):
         super().__init__()
         self.args = args
         self.vln_bert = get_vlnbert_models(args, config=None)
+        # this wrapper reads txt_embeds[:, 0] only (the `states` below, like model_HAMT.py:61-72): the last cross-modal layer need not
+        # compute the other language rows (NavCMT.visual_lang_rows; identical logits / states / gradients)
+        self.vln_bert.visual_lang_rows = "cls"
         self.drop_env = nn.Dropout(p=args.feat_dropout)
 
     def forward(self, mode, txt_ids=None, txt_masks=None, txt_embeds=None, hist_img_feats=None, hist_ang_feats=None,

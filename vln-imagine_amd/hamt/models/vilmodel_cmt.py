@@ -179,6 +179,20 @@ class LXRTXLayer(nn.Module):
                              drop=_drop(self.visn_output))
         return lang, visn
 
+    def forward_cls(self, lang, lang_mask, visn, visn_mask):
+        """The LAST cross-modal layer when only the language stream's [CLS] row is read afterwards (NavCMT.visual_lang_rows): the
+        cross-attention still updates every language row - they are the keys and values of the language self-attention - but the
+        self-attention query, its output projection + LayerNorm and the whole language FFN run for row 0 of each sample only
+        (10 of the 14 row-wise projections of the language side). Returns (lang[:, :1] as the reference would compute it, visn)."""
+        xa, la, va = self.visual_attention, _att(self.lang_self_att), _att(self.visn_self_att)
+        lang, visn = ops.xatt_pair_block(lang, visn, lang_mask, visn_mask, _att(xa), drop=_drop(xa))
+        # both streams as query blocks over their own projected keys / values, so that the 64 [CLS] rows ride in the vision stream's
+        # launches (dual-problem GEMMs and attention) instead of a chain of latency-bound 64-row launches of their own
+        cls, visn = ops.dual_xatt_q_block(lang[:, :1].contiguous(), visn, ops.kv_proj(lang, la), ops.kv_proj(visn, va),
+                                          (lang_mask, visn_mask), la, va, drop0=_drop(self.lang_self_att), drop1=_drop(self.visn_self_att))
+        return ops.dual_ffn_block(cls, visn, _ffn(self.lang_inter, self.lang_output), _ffn(self.visn_inter, self.visn_output),
+                                  drop0=_drop(self.lang_output), drop1=_drop(self.visn_output))
+
 
 class LxmertEncoder(nn.Module):
     def __init__(self, c):
@@ -476,6 +490,12 @@ class NavCMT(nn.Module):
         self.compute_dtype = torch.bfloat16 if os.environ.get("VLNI_DTYPE", "fp32").lower() in ("bf16", "bfloat16") \
             else torch.float32
         self._lang_side = None           # (keys, lang, lm, nt): the language stream of the episode in flight (see _language_side)
+        # "all": `visual` returns every language row like the reference. "cls": the caller reads txt_embeds[:, :1] at most (the
+        # reference's own VLNBertCMT wrapper and agents do, model_HAMT.py:61-72) - the last cross-modal layer then computes only that
+        # row of the language stream (LXRTXLayer.forward_cls) and txt_embeds comes back as [B, 1, H]; logits, loss and every gradient
+        # are unchanged because nothing reads the other rows. Ignored where other rows are read (act_pred_token 'ob_imagine_text',
+        # no_lang_ca, return_cross_attention_probs).
+        self.visual_lang_rows = "all"
         self.apply(self._init_weights)
 
     @staticmethod
@@ -613,6 +633,8 @@ class NavCMT(nn.Module):
         if img_side == "visual":
             visn, vm = torch.cat([visn, imagine_embeds.to(dt)], 1), torch.cat([vm, ops.additive_mask(imagine_masks)], 1)
         visn, lang, vm, lm = visn.contiguous(), lang.contiguous(), vm.contiguous(), lm.contiguous()
+        cls_only = (self.visual_lang_rows == "cls" and txt_list is None and not c.no_lang_ca and not return_cross_attention_probs
+                    and c.act_pred_token in ("ob", "ob_txt", "ob_hist", "ob_txt_hist"))
         for i, xl in enumerate(self.encoder.x_layers):
             if txt_list is not None:       # no_lang_ca: per-layer precomputed text states (:1138-1145)
                 lang = txt_list[i].to(dt) if img_side != "language" else lang
@@ -620,7 +642,10 @@ class NavCMT(nn.Module):
                 lq, vq, ls, vs = xl.attention_probs(lang, lm, visn, vm)
                 cross_probs.append((lq, vq))
                 self_probs.append((ls, vs))
-            lang, visn = xl(lang, lm, visn, vm)
+            if cls_only and i == len(self.encoder.x_layers) - 1:
+                lang, visn = xl.forward_cls(lang, lm, visn, vm)
+            else:
+                lang, visn = xl(lang, lm, visn, vm)
         hist_o, ob_o = visn[:, :nh], visn[:, nh:nh + no]
         txt_o = lang[:, :nt]
         img_o = None

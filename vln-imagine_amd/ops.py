@@ -1006,24 +1006,25 @@ class _DualXAttQBlock(torch.autograd.Function):
     def forward(ctx, x0, x1, kv0, kv1, mask_c, eps, drop0, drop1, *P):
         P0, P1 = P[:6], P[6:]                        # (wq, bq, wo, bo, g, b) per branch
         (B, S0, H), S1 = x0.shape, x1.shape[1]
-        Sk = kv0.shape[0] // B
+        Sk = (kv0.shape[0] // B, kv1.shape[0] // B)             # the two contexts may differ (mask_c: one mask or a pair)
+        mk0, mk1 = mask_c if isinstance(mask_c, (tuple, list)) else (mask_c, mask_c)
         a0, a1 = _rows(_chk(x0, "x0")), _rows(_chk(x1, "x1"))
         dt = x0.dtype
         q0, q1 = gemm_nt2((a0, a1), (_w((P0[0],), dt), _w((P1[0],), dt)), bias=(P0[1], P1[1]))
-        (c0, lse0), (c1, lse1) = attn_fwd2((q0, q1), (kv0[:, :H], kv1[:, :H]), (kv0[:, H:], kv1[:, H:]), B, (S0, S1), (Sk, Sk),
-                                           (mask_c, mask_c), drop=(max(drop0[0], drop1[0]), (drop0[2], drop1[2])))
+        (c0, lse0), (c1, lse1) = attn_fwd2((q0, q1), (kv0[:, :H], kv1[:, :H]), (kv0[:, H:], kv1[:, H:]), B, (S0, S1), Sk,
+                                           (mk0, mk1), drop=(max(drop0[0], drop1[0]), (drop0[2], drop1[2])))
         ph = max(drop0[1], drop1[1])
         pre0, pre1 = gemm_nt2((c0, c1), (_w((P0[2],), dt), _w((P1[2],), dt)), bias=(P0[3], P1[3]), residual=(a0, a1),
                               drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
         y0, m0, r0 = ln_fwd(pre0, P0[4], P0[5], eps)
         y1, m1, r1 = ln_fwd(pre1, P1[4], P1[5], eps)
-        ctx.save_for_backward(a0, a1, q0, q1, kv0, kv1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, mask_c)
+        ctx.save_for_backward(a0, a1, q0, q1, kv0, kv1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, mk0, mk1)
         ctx.P, ctx.dims, ctx.drop = (P0, P1), (B, S0, S1, Sk, H), (drop0, drop1, ph)
         return y0.view(B, S0, H), y1.view(B, S1, H)
 
     @staticmethod
     def backward(ctx, dy0, dy1):
-        a0, a1, q0, q1, kv0, kv1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, mask_c = ctx.saved_tensors
+        a0, a1, q0, q1, kv0, kv1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, mk0, mk1 = ctx.saved_tensors
         P0, P1 = ctx.P
         B, S0, S1, Sk, H = ctx.dims
         drop0, drop1, ph = ctx.drop
@@ -1041,7 +1042,7 @@ class _DualXAttQBlock(torch.autograd.Function):
         dq0, dq1 = torch.empty_like(q0), torch.empty_like(q1)
         dkv0, dkv1 = torch.empty_like(kv0), torch.empty_like(kv1)
         attn_bwd2((q0, q1), (kv0[:, :H], kv1[:, :H]), (kv0[:, H:], kv1[:, H:]), (c0, c1), (dc0, dc1), (lse0, lse1), (dq0, dq1),
-                  (dkv0[:, :H], dkv1[:, :H]), (dkv0[:, H:], dkv1[:, H:]), B, (S0, S1), (Sk, Sk), (mask_c, mask_c),
+                  (dkv0[:, :H], dkv1[:, :H]), (dkv0[:, H:], dkv1[:, H:]), B, (S0, S1), Sk, (mk0, mk1),
                   drop=(max(drop0[0], drop1[0]), (drop0[2], drop1[2])))
         if w0:
             (g0[0],), (g0[1],) = _wb_grad_to((P0[0],), (P0[1],), dq0, a0)
