@@ -130,6 +130,17 @@ int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const void* x, long
                        int H, const void* dres /* optional: dx += dres (pre-norm residual path) */, long lddres,
                        void* dx_drop /* optional second output dx*mask/(1-p): grad of the dropped dense output (R:146-147) */,
                        long lddxd, float drop_p, unsigned drop_seed, void* stream);
+/* Two LayerNorm problems in one launch - the language and the vision stream of a cross-modal layer (R:144-148,186-190 on both
+   streams of R:366-445): every pointer / stride / row-count argument is an array of 2; same dtype, H and eps. dres / dx_drop /
+   drop_seed may be NULL. */
+int vlni_layernorm_fwd_dual(int dtype, const void* const* x, const long* ldx, const float* const* gamma, const float* const* beta,
+                            float eps, void* const* y, const long* ldy, float* const* mean, float* const* rstd, const int* rows, int H,
+                            void* stream);
+int vlni_layernorm_bwd_dual(int dtype, const void* const* dy, const long* lddy, const void* const* x, const long* ldx,
+                            const float* const* gamma, const float* const* mean, const float* const* rstd, void* const* dx,
+                            const long* lddx, float* const* dgamma, float* const* dbeta, const int* rows, int H,
+                            const void* const* dres, const long* lddres, void* const* dx_drop, const long* lddxd, float drop_p,
+                            const unsigned* drop_seed, void* stream);
 /* y = LayerNorm(sum_k src_k), 1..4 sources, each dense / broadcast row (ld 0) / gathered by int64 row index,
  * float32 (parameter tables) or activation dtype; xsum (optional) keeps the pre-norm sum for backward.
  * Replaces BertEmbeddings R:58-73, ImageEmbeddings R:535-544, HistoryEmbeddings R:576-618, D:1087-1131. */
@@ -162,6 +173,11 @@ int vlni_scatter_add_rows_small(int dtype, const void* src, long lds_, const lon
 /* out[b] = mean_s x[b][s] (torch.mean(pano_embeddings, 1) R:612) */
 int vlni_seqmean_fwd(int dtype, const void* x, void* out, int B, int S, int H, void* stream);
 int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, int B, int S, int H, void* stream);
+/* f[b][j][:] = visn[b][r0+j][:] * lang[b][0][:]  (action-head input `ob_embeds * txt_embeds[:, :1]`, R:1192; visn [B,Sv,H], lang [B,Sl,H], f [B,n,H],
+   all contiguous) and its backward: dvisn / dlang are written in full (zero outside the gated rows / row 0); either may be NULL */
+int vlni_gate_rows_fwd(int dtype, const void* visn, const void* lang, void* f, int B, int Sv, int Sl, int r0, int n, int H, void* stream);
+int vlni_gate_rows_bwd(int dtype, const void* df, const void* visn, const void* lang, void* dvisn, void* dlang, int B, int Sv, int Sl,
+                       int r0, int n, int H, void* stream);
 /* logits[r] = mask[r] ? -inf : <h[r], w> + bias  (NextActionPrediction.net.4 R:960 + masked_fill_ R:1200) */
 int vlni_rowdot_fwd(int dtype, const void* h, long ldh, const float* w, const float* bias, const unsigned char* mask,
                     float* out, int rows, int H, void* stream);

@@ -618,3 +618,50 @@ def test_float16_kernels_are_the_bfloat16_kernels_with_the_f16_mfma(ops):
     g = ops.wgrad(dy, x)
     rg = dy.double().t() @ x.double()
     assert _err(g, rg) < 2e-3 * max(1.0, rg.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("Sl", [86, 1])
+def test_gate_rows_matches_torch(ops, dtype, Sl):
+    """f = visn[:, r0:r0+n] * lang[:, :1] (vilmodel_cmt.py:1192) and both full-size gradients, against torch in float64."""
+    B, Sv, H, r0, n = 5, 23, 768, 4, 17
+    visn, lang = _rand((B, Sv, H), dtype, 71, 1.0).requires_grad_(), _rand((B, Sl, H), dtype, 72, 1.0).requires_grad_()
+    df = _rand((B, n, H), dtype, 73, 1.0)
+    f = ops.gate_rows(visn, lang, r0, n)
+    f.backward(df)
+    v64, l64 = visn.detach().double().requires_grad_(), lang.detach().double().requires_grad_()
+    ref = v64[:, r0:r0 + n] * l64[:, :1]
+    ref.backward(df.double())
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    assert (f.double() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    assert (visn.grad.double() - v64.grad).abs().max().item() <= tol * v64.grad.abs().max().item()
+    assert (lang.grad.double() - l64.grad).abs().max().item() <= tol * l64.grad.abs().max().item()
+    assert float(visn.grad[:, :r0].abs().max()) == 0.0 and float(visn.grad[:, r0 + n:].abs().max()) == 0.0
+    if Sl > 1:
+        assert float(lang.grad[:, 1:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_dual_layernorm_equals_two_launches(ops, dtype, p_drop):
+    """vlni_layernorm_fwd_dual / _bwd_dual (the two streams of a cross-modal layer in one launch) == the single-problem launches:
+    outputs, statistics, dx and the dropped dx bit for bit; dgamma / dbeta up to the order of their float atomics."""
+    H, rows = 768, (5 * 86, 5 * 41 + 3)
+    xs = tuple(_rand((r, H), dtype, 81 + i, 1.0) for i, r in enumerate(rows))
+    dys = tuple(_rand((r, H), dtype, 83 + i, 1.0) for i, r in enumerate(rows))
+    gs = tuple(_rand((H,), torch.float32, 85 + i, 1.0) for i in range(2))
+    bs = tuple(_rand((H,), torch.float32, 87 + i, 1.0) for i in range(2))
+    singles = [ops.ln_fwd(xs[i], gs[i], bs[i], 1e-12) for i in range(2)]
+    duals = ops.ln_fwd2(xs, gs, bs, 1e-12)
+    for i in range(2):
+        for a, b in zip(singles[i], duals[i]):
+            assert torch.equal(a, b)
+    means, rstds = tuple(s[1] for s in singles), tuple(s[2] for s in singles)
+    drop1 = [ops.ln_bwd(dys[i], xs[i], gs[i], means[i], rstds[i], drop=(p_drop, 11 + i)) for i in range(2)]
+    drop2 = ops._ln_bwd_to2(dys, xs, gs, bs, means, rstds, (True, True), drop=(p_drop, (11, 12)))
+    for i in range(2):
+        assert torch.equal(drop1[i][0], drop2[i][0]) and torch.equal(drop1[i][3], drop2[i][3])
+        for a, b in ((drop1[i][1], drop2[i][1]), (drop1[i][2], drop2[i][2])):
+            assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())
+    none = ops._ln_bwd_to2(dys, xs, gs, bs, means, rstds, (False, True))
+    assert none[0][1] is None and none[1][1] is not None and torch.equal(none[0][0], ops.ln_bwd(dys[0], xs[0], gs[0], means[0], rstds[0])[0])

@@ -35,6 +35,8 @@ SIGNATURES = {
     "vlni_attn_bwd_dual": [I, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, P, P, F, F, P, P],
     "vlni_layernorm_fwd": [I, P, L, P, P, F, P, L, P, P, I, I, P],
     "vlni_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, P, I, I, P, L, P, L, F, U, P],
+    "vlni_layernorm_fwd_dual": [I, P, P, P, P, F, P, P, P, P, P, I, P],
+    "vlni_layernorm_bwd_dual": [I, P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, F, P, P],
     "vlni_sum_layernorm_fwd": [I, I, P, P, P, P, P, P, F, P, L, P, L, P, P, I, I, P],
     "vlni_cast": [I, I, P, P, L, P],
     "vlni_transpose": [I, I, P, L, P, L, I, I, I, P],
@@ -45,6 +47,8 @@ SIGNATURES = {
     "vlni_scatter_add_rows_small": [I, P, L, P, P, I, I, I, P],
     "vlni_seqmean_fwd": [I, P, P, I, I, I, P],
     "vlni_seqmean_bwd": [I, P, P, I, I, I, P],
+    "vlni_gate_rows_fwd": [I, P, P, P, I, I, I, I, I, I, P],
+    "vlni_gate_rows_bwd": [I, P, P, P, P, P, I, I, I, I, I, I, P],
     "vlni_rowdot_fwd": [I, P, L, P, P, P, P, I, I, P],
     "vlni_rowdot_bwd": [I, P, P, L, P, P, P, L, P, P, I, I, P],
     "vlni_cross_entropy": [P, L, P, L, P, P, L, I, I, P],

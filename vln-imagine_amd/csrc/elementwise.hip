@@ -189,6 +189,47 @@ __global__ __launch_bounds__(256) void seqmean_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// f[b][j][:] = visn[b][r0 + j][:] * lang[b][0][:]: the action head's input for act_pred_token == 'ob_txt'
+// (VLN-HAMT/finetune_src/models/vilmodel_cmt.py:1192, `ob_embeds * txt_embeds[:, :1]`), and its backward, which writes BOTH full-size
+// gradients in one launch: dvisn rows [r0, r0 + n) = df * lang[b][0], its other rows zero; dlang row 0 = sum_j df[b][j] * visn[b][r0 + j],
+// its other rows zero. One block per output row (grid (B, Sv + Sl)); torch needed ten kernels for it (two zero fills, two slices'
+// copies, casts, a multiply, a reduction).
+template <typename T>
+__global__ __launch_bounds__(256) void gate_rows_fwd_kernel(const T* __restrict__ visn, const T* __restrict__ lang, T* __restrict__ f,
+                                                            int Sv, int Sl, int r0, int n, int H) {
+  const int b = blockIdx.x, j = blockIdx.y, c = threadIdx.x * 4;
+  if (c >= H) return;
+  const f32x4 v = DT<T>::ld4(visn + ((long)b * Sv + r0 + j) * H + c), g = DT<T>::ld4(lang + (long)b * Sl * H + c);
+  DT<T>::st4(f + ((long)b * n + j) * H + c, v * g);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gate_rows_bwd_kernel(const T* __restrict__ df, const T* __restrict__ visn, const T* __restrict__ lang,
+                                                            T* __restrict__ dvisn, T* __restrict__ dlang, int Sv, int Sl, int r0, int n, int H) {
+  const int b = blockIdx.x, y = blockIdx.y, c = threadIdx.x * 4;
+  if (c >= H) return;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  if (y < Sv) {                                   // one row of dvisn
+    if (dvisn == nullptr) return;
+    f32x4 o = zero;
+    if (y >= r0 && y < r0 + n) o = DT<T>::ld4(df + ((long)b * n + (y - r0)) * H + c) * DT<T>::ld4(lang + (long)b * Sl * H + c);
+    DT<T>::st4(dvisn + ((long)b * Sv + y) * H + c, o);
+  } else if (dlang != nullptr) {                  // one row of dlang
+    const int row = y - Sv;
+    f32x4 a0 = zero, a1 = zero;
+    if (row == 0) {
+      const T* dp = df + (long)b * n * H + c;
+      const T* vp = visn + ((long)b * Sv + r0) * H + c;
+      int j = 0;
+      for (; j + 1 < n; j += 2) {                 // two rows in flight
+        a0 += DT<T>::ld4(dp + (long)j * H) * DT<T>::ld4(vp + (long)j * H);
+        a1 += DT<T>::ld4(dp + (long)(j + 1) * H) * DT<T>::ld4(vp + (long)(j + 1) * H);
+      }
+      if (j < n) a0 += DT<T>::ld4(dp + (long)j * H) * DT<T>::ld4(vp + (long)j * H);
+    }
+    DT<T>::st4(dlang + ((long)b * Sl + row) * H + c, a0 + a1);
+  }
+}
+
 // logits[r] = mask[r] ? -inf : (bias + sum_c h[r][c] w[c])      (NextActionPrediction.net.4 + masked_fill)
 template <typename T>
 __global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T* __restrict__ h, long ldh, const float* __restrict__ w,
@@ -714,6 +755,29 @@ extern "C" int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, int B, in
   BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_bwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)dout, (float*)dx, B, S, H),
            hipLaunchKernelGGL((seqmean_bwd_kernel<__bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, (__bf16*)dx, B, S, H),
           hipLaunchKernelGGL((seqmean_bwd_kernel<_Float16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dout, (_Float16*)dx, B, S, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_gate_rows_fwd(int dtype, const void* visn, const void* lang, void* f, int B, int Sv, int Sl, int r0, int n, int H,
+                                  void* stream) {
+  VLNI_CHECK(B > 0 && n > 0 && r0 >= 0 && r0 + n <= Sv && Sl > 0 && H % 4 == 0 && H <= 1024, VLNI_EINVAL,
+             "gate_rows_fwd: B=%d Sv=%d Sl=%d r0=%d n=%d H=%d", B, Sv, Sl, r0, n, H);
+  dim3 grid(B, n), block(256);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((gate_rows_fwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)visn, (const float*)lang, (float*)f, Sv, Sl, r0, n, H),
+           hipLaunchKernelGGL((gate_rows_fwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)visn, (const __bf16*)lang, (__bf16*)f, Sv, Sl, r0, n, H),
+          hipLaunchKernelGGL((gate_rows_fwd_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)visn, (const _Float16*)lang, (_Float16*)f, Sv, Sl, r0, n, H));
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_gate_rows_bwd(int dtype, const void* df, const void* visn, const void* lang, void* dvisn, void* dlang, int B, int Sv,
+                                  int Sl, int r0, int n, int H, void* stream) {
+  VLNI_CHECK(B > 0 && n > 0 && r0 >= 0 && r0 + n <= Sv && Sl > 0 && H % 4 == 0 && H <= 1024 && (dvisn || dlang), VLNI_EINVAL,
+             "gate_rows_bwd: B=%d Sv=%d Sl=%d r0=%d n=%d H=%d", B, Sv, Sl, r0, n, H);
+  dim3 grid(B, Sv + Sl), block(256);
+  BY_DTYPE(dtype, hipLaunchKernelGGL((gate_rows_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)df, (const float*)visn, (const float*)lang, (float*)dvisn, (float*)dlang, Sv, Sl, r0, n, H),
+           hipLaunchKernelGGL((gate_rows_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)df, (const __bf16*)visn, (const __bf16*)lang, (__bf16*)dvisn, (__bf16*)dlang, Sv, Sl, r0, n, H),
+          hipLaunchKernelGGL((gate_rows_bwd_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)df, (const _Float16*)visn, (const _Float16*)lang, (_Float16*)dvisn, (_Float16*)dlang, Sv, Sl, r0, n, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

@@ -10,10 +10,10 @@ namespace {
 
 constexpr int WAVES = 4;
 
-template <typename T, int NC>     // H = 256 * NC
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ g,
-                                                     const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows) {
+template <typename T, int NC>     // H = 256 * NC; blk / nblk: this block's index and the block count of ITS problem (dual launches)
+__device__ __forceinline__ void ln_fwd_body(const T* __restrict__ x, long ldx, const float* __restrict__ g, const float* __restrict__ b,
+                                            float eps, T* __restrict__ y, long ldy, float* __restrict__ mean, float* __restrict__ rstd,
+                                            int rows, int blk, int nblk) {
   constexpr int H = 256 * NC;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gv[NC], bv[NC];
@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
     gv[c] = *(const f32x4*)(g + c * 256 + lane * 4);
     bv[c] = *(const f32x4*)(b + c * 256 + lane * 4);
   }
-  for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
+  for (int row = blk * WAVES + wave; row < rows; row += nblk * WAVES) {
     f32x4 v[NC];
     float s = 0.f;
 #pragma unroll
@@ -53,21 +53,39 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, lo
     }
   }
 }
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ g,
+                                                     const float* __restrict__ b, float eps, T* __restrict__ y, long ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows) {
+  ln_fwd_body<T, NC>(x, ldx, g, b, eps, y, ldy, mean, rstd, rows, blockIdx.x, gridDim.x);
+}
+// Two LayerNorms in one launch (the language and the vision stream of a cross-modal layer: different rows, different parameters):
+// blocks [0, nb0) take problem 0, the rest problem 1
+struct LnFwd2 {
+  const void* x[2]; long ldx[2]; const float* g[2]; const float* b[2]; void* y[2]; long ldy[2]; float* mean[2]; float* rstd[2];
+  int rows[2]; int nb0;
+};
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_fwd_dual_kernel(LnFwd2 p, float eps) {
+  const int i = (int)blockIdx.x >= p.nb0 ? 1 : 0;
+  ln_fwd_body<T, NC>((const T*)p.x[i], p.ldx[i], p.g[i], p.b[i], eps, (T*)p.y[i], p.ldy[i], p.mean[i], p.rstd[i], p.rows[i],
+                     i ? blockIdx.x - p.nb0 : blockIdx.x, i ? gridDim.x - p.nb0 : p.nb0);
+}
 
 // dx = rstd * (g*dy - mean_H(g*dy) - xhat * mean_H(g*dy*xhat)); dgamma += sum_rows dy*xhat; dbeta += sum_rows dy
 // backward: 16 waves per block so that the 2*H float atomics per block (dgamma / dbeta, every block into the same 6 KiB)
 // are issued by <= 128 blocks instead of 512
 constexpr int BWAVES = 16;
 template <typename T, int NC>
-__global__ __launch_bounds__(BWAVES * 64) void ln_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx,
-                                                     const float* __restrict__ g, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, T* __restrict__ dx, long lddx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                     const T* __restrict__ dres, long lddres, T* __restrict__ dxd,
-                                                     long lddxd, unsigned dthr, unsigned dseed0, float dinv, const unsigned* sbase) {
+__device__ __forceinline__ void ln_bwd_body(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx,
+                                            const float* __restrict__ g, const float* __restrict__ mean,
+                                            const float* __restrict__ rstd, T* __restrict__ dx, long lddx,
+                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
+                                            const T* __restrict__ dres, long lddres, T* __restrict__ dxd,
+                                            long lddxd, unsigned dthr, unsigned dseed0, float dinv, const unsigned* sbase,
+                                            int blk, int nblk, float (*red)[2][256 * NC]) {
   const unsigned dseed = dxd ? eff_seed(dseed0, sbase) : 0u;
   constexpr int H = 256 * NC;
-  __shared__ float red[BWAVES][2][H];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 gv[NC], pg[NC], pb[NC];
 #pragma unroll
@@ -76,7 +94,7 @@ __global__ __launch_bounds__(BWAVES * 64) void ln_bwd_kernel(const T* __restrict
     pg[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     pb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  for (int row = blockIdx.x * BWAVES + wave; row < rows; row += gridDim.x * BWAVES) {
+  for (int row = blk * BWAVES + wave; row < rows; row += nblk * BWAVES) {
     const float mu = mean[row], rs = rstd[row];
     f32x4 xh[NC], d[NC];
     float s1 = 0.f, s2 = 0.f;
@@ -130,6 +148,30 @@ __global__ __launch_bounds__(BWAVES * 64) void ln_bwd_kernel(const T* __restrict
     atomicAdd(dgamma + i, a);
     atomicAdd(dbeta + i, bsum);
   }
+}
+template <typename T, int NC>
+__global__ __launch_bounds__(BWAVES * 64) void ln_bwd_kernel(const T* __restrict__ dy, long lddy, const T* __restrict__ x, long ldx,
+                                                     const float* __restrict__ g, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, T* __restrict__ dx, long lddx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
+                                                     const T* __restrict__ dres, long lddres, T* __restrict__ dxd,
+                                                     long lddxd, unsigned dthr, unsigned dseed0, float dinv, const unsigned* sbase) {
+  __shared__ float red[BWAVES][2][256 * NC];
+  ln_bwd_body<T, NC>(dy, lddy, x, ldx, g, mean, rstd, dx, lddx, dgamma, dbeta, rows, dres, lddres, dxd, lddxd, dthr, dseed0, dinv, sbase,
+                     blockIdx.x, gridDim.x, red);
+}
+struct LnBwd2 {
+  const void* dy[2]; long lddy[2]; const void* x[2]; long ldx[2]; const float* g[2]; const float* mean[2]; const float* rstd[2];
+  void* dx[2]; long lddx[2]; float* dgamma[2]; float* dbeta[2]; int rows[2]; const void* dres[2]; long lddres[2]; void* dxd[2]; long lddxd[2];
+  unsigned dseed[2]; int nb0;
+};
+template <typename T, int NC>
+__global__ __launch_bounds__(BWAVES * 64) void ln_bwd_dual_kernel(LnBwd2 p, unsigned dthr, float dinv, const unsigned* sbase) {
+  __shared__ float red[BWAVES][2][256 * NC];
+  const int i = (int)blockIdx.x >= p.nb0 ? 1 : 0;
+  ln_bwd_body<T, NC>((const T*)p.dy[i], p.lddy[i], (const T*)p.x[i], p.ldx[i], p.g[i], p.mean[i], p.rstd[i], (T*)p.dx[i], p.lddx[i],
+                     p.dgamma[i], p.dbeta[i], p.rows[i], (const T*)p.dres[i], p.lddres[i], (T*)p.dxd[i], p.lddxd[i], dthr, p.dseed[i], dinv,
+                     sbase, i ? blockIdx.x - p.nb0 : blockIdx.x, i ? gridDim.x - p.nb0 : p.nb0, red);
 }
 
 // ---- sum of up to 4 row sources, then LayerNorm --------------------------------------------------
@@ -265,6 +307,53 @@ extern "C" int vlni_layernorm_bwd(int dtype, const void* dy, long lddy, const vo
     const _Float16* d = (const _Float16*)dy; const _Float16* xx = (const _Float16*)x; _Float16* o = (_Float16*)dx; const _Float16* dr = (const _Float16*)dres; _Float16* dd = (_Float16*)dx_drop;
     LN_DISPATCH_G(ln_bwd_grid(rows), ln_bwd_kernel, TT, d, lddy, xx, ldx, gamma, mean, rstd, o, lddx, dgamma, dbeta, rows, dr, lddres, dd, lddxd, drop_thr(drop_p), drop_seed, 1.0f / (1.0f - drop_p), vlni_seed_base());
   }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// Two LayerNorm problems in one launch (arrays of 2; same dtype, H and eps; block ranges [0, nb0) and [nb0, nb0 + nb1))
+extern "C" int vlni_layernorm_fwd_dual(int dtype, const void* const* x, const long* ldx, const float* const* gamma,
+                                       const float* const* beta, float eps, void* const* y, const long* ldy, float* const* mean,
+                                       float* const* rstd, const int* rows, int H, void* stream) {
+  LnFwd2 p;
+  for (int i = 0; i < 2; ++i) {
+    int rc = ln_check("layernorm_fwd_dual", dtype, rows[i], H, ldx[i] < ldy[i] ? ldx[i] : ldy[i]);
+    if (rc) return rc;
+    p.x[i] = x[i]; p.ldx[i] = ldx[i]; p.g[i] = gamma[i]; p.b[i] = beta[i]; p.y[i] = y[i]; p.ldy[i] = ldy[i];
+    p.mean[i] = mean[i]; p.rstd[i] = rstd[i]; p.rows[i] = rows[i];
+  }
+  p.nb0 = ln_grid(rows[0]);
+  const int nblk = p.nb0 + ln_grid(rows[1]);
+  if (dtype == VLNI_F32) { using TT = float; LN_DISPATCH_GB(nblk, 256, ln_fwd_dual_kernel, TT, p, eps); }
+  else if (dtype == VLNI_BF16) { using TT = __bf16; LN_DISPATCH_GB(nblk, 256, ln_fwd_dual_kernel, TT, p, eps); }
+  else { using TT = _Float16; LN_DISPATCH_GB(nblk, 256, ln_fwd_dual_kernel, TT, p, eps); }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_layernorm_bwd_dual(int dtype, const void* const* dy, const long* lddy, const void* const* x, const long* ldx,
+                                       const float* const* gamma, const float* const* mean, const float* const* rstd, void* const* dx,
+                                       const long* lddx, float* const* dgamma, float* const* dbeta, const int* rows, int H,
+                                       const void* const* dres, const long* lddres, void* const* dx_drop, const long* lddxd, float drop_p,
+                                       const unsigned* drop_seed, void* stream) {
+  LnBwd2 p;
+  for (int i = 0; i < 2; ++i) {
+    int rc = ln_check("layernorm_bwd_dual", dtype, rows[i], H,
+                      ldx[i] < lddx[i] ? (ldx[i] < lddy[i] ? ldx[i] : lddy[i]) : (lddx[i] < lddy[i] ? lddx[i] : lddy[i]));
+    if (rc) return rc;
+    VLNI_CHECK((dgamma[i] == nullptr) == (dbeta[i] == nullptr), VLNI_EINVAL, "layernorm_bwd_dual: dgamma/dbeta both or neither");
+    p.dy[i] = dy[i]; p.lddy[i] = lddy[i]; p.x[i] = x[i]; p.ldx[i] = ldx[i]; p.g[i] = gamma[i]; p.mean[i] = mean[i]; p.rstd[i] = rstd[i];
+    p.dx[i] = dx[i]; p.lddx[i] = lddx[i]; p.dgamma[i] = dgamma[i]; p.dbeta[i] = dbeta[i]; p.rows[i] = rows[i];
+    p.dres[i] = dres ? dres[i] : nullptr; p.lddres[i] = dres && lddres ? lddres[i] : 0;
+    p.dxd[i] = dx_drop ? dx_drop[i] : nullptr; p.lddxd[i] = dx_drop && lddxd ? lddxd[i] : 0;
+    p.dseed[i] = drop_seed ? drop_seed[i] : 0u;
+  }
+  p.nb0 = ln_bwd_grid(rows[0]);
+  const int nblk = p.nb0 + ln_bwd_grid(rows[1]);
+  const unsigned thr = drop_thr(drop_p);
+  const float inv = 1.0f / (1.0f - drop_p);
+  if (dtype == VLNI_F32) { using TT = float; LN_DISPATCH_GB(nblk, BWAVES * 64, ln_bwd_dual_kernel, TT, p, thr, inv, vlni_seed_base()); }
+  else if (dtype == VLNI_BF16) { using TT = __bf16; LN_DISPATCH_GB(nblk, BWAVES * 64, ln_bwd_dual_kernel, TT, p, thr, inv, vlni_seed_base()); }
+  else { using TT = _Float16; LN_DISPATCH_GB(nblk, BWAVES * 64, ln_bwd_dual_kernel, TT, p, thr, inv, vlni_seed_base()); }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

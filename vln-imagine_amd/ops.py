@@ -281,6 +281,55 @@ def ln_bwd(dy, x, gamma, mean, rstd, dgamma=None, dbeta=None, want_param_grads=T
     return dx, dgamma, dbeta
 
 
+def _i2(a, b):
+    return (ctypes.c_int * 2)(a, b)
+
+
+def ln_fwd2(xs, gs, bs, eps):
+    """Two LayerNorms (tuples of 2: the two streams of a cross-modal layer) in ONE launch. Returns ((y0, mean0, rstd0), (y1, mean1, rstd1))."""
+    H = xs[0].shape[1]
+    if xs[0].dtype != xs[1].dtype or xs[1].shape[1] != H:
+        return ln_fwd(xs[0], gs[0], bs[0], eps), ln_fwd(xs[1], gs[1], bs[1], eps)
+    ys = tuple(torch.empty((x.shape[0], H), dtype=x.dtype, device=x.device) for x in xs)
+    ms = tuple(torch.empty((x.shape[0],), dtype=torch.float32, device=x.device) for x in xs)
+    rs = tuple(torch.empty((x.shape[0],), dtype=torch.float32, device=x.device) for x in xs)
+    _lib.call("vlni_layernorm_fwd_dual", _dt(xs[0]), _p2(xs), _l2(xs), _p2(gs), _p2(bs), eps, _p2(ys), _l2(ys), _p2(ms), _p2(rs),
+              _i2(xs[0].shape[0], xs[1].shape[0]), H, _st())
+    return (ys[0], ms[0], rs[0]), (ys[1], ms[1], rs[1])
+
+
+def _ln_bwd_to2(dys, xs, gs, bs, means, rstds, wants, drop=None):
+    """Two LayerNorm backwards in ONE launch; per problem the return value of _ln_bwd_to: (dx, dgamma, dbeta[, dx_dropped]) with
+    dgamma / dbeta None where they were accumulated in place. drop = (p, (seed0, seed1))."""
+    H = xs[0].shape[1]
+    if xs[0].dtype != xs[1].dtype or xs[1].shape[1] != H:
+        return tuple(_ln_bwd_to(dys[i], xs[i], gs[i], bs[i], means[i], rstds[i], wants[i],
+                                drop=(drop[0], drop[1][i]) if drop is not None else None) for i in range(2))
+    dev = xs[0].device
+    dxs = tuple(torch.empty((x.shape[0], H), dtype=x.dtype, device=dev) for x in xs)
+    dropping = drop is not None and drop[0] > 0.0
+    dxd = tuple(torch.empty((x.shape[0], H), dtype=x.dtype, device=dev) for x in xs) if dropping else (None, None)
+    dgs, dbs, ret = [], [], []
+    for i in range(2):
+        if wants[i] and _direct(gs[i], bs[i]):
+            dgs.append(gs[i].grad); dbs.append(bs[i].grad); ret.append(False)
+        elif wants[i]:
+            dgs.append(torch.zeros((H,), dtype=torch.float32, device=dev)); dbs.append(torch.zeros((H,), dtype=torch.float32, device=dev)); ret.append(True)
+        else:
+            dgs.append(None); dbs.append(None); ret.append(False)
+    _lib.call("vlni_layernorm_bwd_dual", _dt(xs[0]), _p2(dys), _l2(dys), _p2(xs), _l2(xs), _p2(gs), _p2(means), _p2(rstds), _p2(dxs), _l2(dxs),
+              _p2(dgs), _p2(dbs), _i2(xs[0].shape[0], xs[1].shape[0]), H, None, None, _p2(dxd) if dropping else None,
+              (ctypes.c_long * 2)(H, H) if dropping else None, drop[0] if dropping else 0.0,
+              (ctypes.c_uint * 2)(*drop[1]) if dropping else None, _st())
+    out = []
+    for i in range(2):
+        r = (dxs[i], dgs[i] if ret[i] else None, dbs[i] if ret[i] else None)
+        if drop is not None:
+            r = r + (dxd[i] if dropping else dxs[i],)
+        out.append(r)
+    return tuple(out)
+
+
 def attn_fwd(q, k, v, B, Sq, Sk, kmask=None, bias=None, nh=12, drop=None):
     """q [B*Sq, >=nh*64] (strided view), k/v [B*Sk, ...]; returns ctx [B*Sq, nh*64], lse [B,nh,Sq]."""
     out = torch.empty((B * Sq, nh * 64), dtype=q.dtype, device=q.device)
@@ -894,8 +943,7 @@ class _XAttPairBlock(torch.autograd.Function):
         (cl, lse_l), (cv, lse_v) = attn_fwd2((ql[:, :H], qv[:, :H]), (qv[:, H:2 * H], ql[:, H:2 * H]), (qv[:, 2 * H:], ql[:, 2 * H:]), B,
                                              (Sl, Sv), (Sv, Sl), (mask_v, mask_l), drop=(pa, (sd, sd + 1)))
         pre_l, pre_v = gemm_nt2((cl, cv), (wo_c, wo_c), bias=(bo, bo), residual=(l2, v2), drop=(ph, (sd + 2, sd + 3)))
-        yl, mean_l, rstd_l = ln_fwd(pre_l, g, b, eps)
-        yv, mean_v, rstd_v = ln_fwd(pre_v, g, b, eps)
+        (yl, mean_l, rstd_l), (yv, mean_v, rstd_v) = ln_fwd2((pre_l, pre_v), (g, g), (b, b), eps)
         ctx.save_for_backward(l2, v2, ql, qv, cl, cv, lse_l, lse_v, pre_l, pre_v, mean_l, rstd_l, mean_v, rstd_v,
                               mask_l, mask_v)
         ctx.P = (wq, bq, wk, bk, wv, bv, wo, bo, g, b)
@@ -915,8 +963,8 @@ class _XAttPairBlock(torch.autograd.Function):
         direct = wparams and _direct(wq, bq, wk, bk, wv, bv, wo, bo, g, b)
         dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = dg = db = None
         if direct or not wparams:
-            dpl, _, _, dml = _ln_bwd_to(_rows(dyl), pre_l, g, b, mean_l, rstd_l, wparams, drop=(ph, sd + 2))
-            dpv, _, _, dmv = _ln_bwd_to(_rows(dyv), pre_v, g, b, mean_v, rstd_v, wparams, drop=(ph, sd + 3))
+            (dpl, _, _, dml), (dpv, _, _, dmv) = _ln_bwd_to2((_rows(dyl), _rows(dyv)), (pre_l, pre_v), (g, g), (b, b), (mean_l, mean_v),
+                                                             (rstd_l, rstd_v), (wparams, wparams), drop=(ph, (sd + 2, sd + 3)))
         else:
             dpl, dg, db, dml = ln_bwd(_rows(dyl), pre_l, g, mean_l, rstd_l, drop=(ph, sd + 2))
             dpv, dg, db, dmv = ln_bwd(_rows(dyv), pre_v, g, mean_v, rstd_v, dg, db, drop=(ph, sd + 3))
@@ -960,8 +1008,7 @@ class _DualSelfAttBlock(torch.autograd.Function):
         ph = max(drop0[1], drop1[1])
         pre0, pre1 = gemm_nt2((c0, c1), (_w((P0[6],), dt), _w((P1[6],), dt)), bias=(P0[7], P1[7]), residual=(a0, a1),
                               drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
-        y0, m0, r0 = ln_fwd(pre0, P0[8], P0[9], eps)
-        y1, m1, r1 = ln_fwd(pre1, P1[8], P1[9], eps)
+        (y0, m0, r0), (y1, m1, r1) = ln_fwd2((pre0, pre1), (P0[8], P1[8]), (P0[9], P1[9]), eps)
         ctx.save_for_backward(a0, a1, q0, q1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, km0, km1, bias0)
         ctx.P, ctx.dims, ctx.drop = (P0, P1), (B, S0, S1, H), (drop0, drop1, ph)
         return y0.view(B, S0, H), y1.view(B, S1, H)
@@ -976,8 +1023,8 @@ class _DualSelfAttBlock(torch.autograd.Function):
         ng = ctx.needs_input_grad
         w0, w1 = any(ng[8:18]), any(ng[18:28])
         dbias0 = torch.zeros_like(bias0) if (bias0 is not None and ng[4]) else None
-        dp0, dg0, db0, dm0 = _ln_bwd_to(_rows(dy0), pre0, P0[8], P0[9], m0, r0, w0, drop=(ph, drop0[2] + 1))
-        dp1, dg1, db1, dm1 = _ln_bwd_to(_rows(dy1), pre1, P1[8], P1[9], m1, r1, w1, drop=(ph, drop1[2] + 1))
+        (dp0, dg0, db0, dm0), (dp1, dg1, db1, dm1) = _ln_bwd_to2((_rows(dy0), _rows(dy1)), (pre0, pre1), (P0[8], P1[8]), (P0[9], P1[9]),
+                                                                 (m0, m1), (r0, r1), (w0, w1), drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
         g0, g1 = [None] * 8, [None] * 8
         if w0:
             (g0[6],), (g0[7],) = _wb_grad_to((P0[6],), (P0[7],), dm0, c0)
@@ -1016,8 +1063,7 @@ class _DualXAttQBlock(torch.autograd.Function):
         ph = max(drop0[1], drop1[1])
         pre0, pre1 = gemm_nt2((c0, c1), (_w((P0[2],), dt), _w((P1[2],), dt)), bias=(P0[3], P1[3]), residual=(a0, a1),
                               drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
-        y0, m0, r0 = ln_fwd(pre0, P0[4], P0[5], eps)
-        y1, m1, r1 = ln_fwd(pre1, P1[4], P1[5], eps)
+        (y0, m0, r0), (y1, m1, r1) = ln_fwd2((pre0, pre1), (P0[4], P1[4]), (P0[5], P1[5]), eps)
         ctx.save_for_backward(a0, a1, q0, q1, kv0, kv1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, mk0, mk1)
         ctx.P, ctx.dims, ctx.drop = (P0, P1), (B, S0, S1, Sk, H), (drop0, drop1, ph)
         return y0.view(B, S0, H), y1.view(B, S1, H)
@@ -1031,8 +1077,8 @@ class _DualXAttQBlock(torch.autograd.Function):
         dt = a0.dtype
         ng = ctx.needs_input_grad
         w0, w1 = any(ng[8:14]), any(ng[14:20])
-        dp0, dg0, db0, dm0 = _ln_bwd_to(_rows(dy0), pre0, P0[4], P0[5], m0, r0, w0, drop=(ph, drop0[2] + 1))
-        dp1, dg1, db1, dm1 = _ln_bwd_to(_rows(dy1), pre1, P1[4], P1[5], m1, r1, w1, drop=(ph, drop1[2] + 1))
+        (dp0, dg0, db0, dm0), (dp1, dg1, db1, dm1) = _ln_bwd_to2((_rows(dy0), _rows(dy1)), (pre0, pre1), (P0[4], P1[4]), (P0[5], P1[5]),
+                                                                 (m0, m1), (r0, r1), (w0, w1), drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
         g0, g1 = [None] * 4, [None] * 4
         if w0:
             (g0[2],), (g0[3],) = _wb_grad_to((P0[2],), (P0[3],), dm0, c0)
@@ -1069,8 +1115,7 @@ class _DualFfnBlock(torch.autograd.Function):
         ph = max(drop0[1], drop1[1])
         pre0, pre1 = gemm_nt2((h0, h1), (_w((P0[2],), dt), _w((P1[2],), dt)), bias=(P0[3], P1[3]), residual=(a0, a1),
                               drop=(ph, (drop0[2], drop1[2])))
-        y0, m0, r0 = ln_fwd(pre0, P0[4], P0[5], eps)
-        y1, m1, r1 = ln_fwd(pre1, P1[4], P1[5], eps)
+        (y0, m0, r0), (y1, m1, r1) = ln_fwd2((pre0, pre1), (P0[4], P1[4]), (P0[5], P1[5]), eps)
         ctx.save_for_backward(a0, a1, z0, z1, h0, h1, pre0, pre1, m0, r0, m1, r1)
         ctx.P, ctx.shp, ctx.drop = (P0, P1), (s0, s1), (drop0, drop1, ph)
         return y0.view(s0), y1.view(s1)
@@ -1083,8 +1128,8 @@ class _DualFfnBlock(torch.autograd.Function):
         dt = a0.dtype
         ng = ctx.needs_input_grad
         w0, w1 = any(ng[5:11]), any(ng[11:17])
-        dp0, dg0, db0, dm0 = _ln_bwd_to(_rows(dy0), pre0, P0[4], P0[5], m0, r0, w0, drop=(ph, drop0[2]))
-        dp1, dg1, db1, dm1 = _ln_bwd_to(_rows(dy1), pre1, P1[4], P1[5], m1, r1, w1, drop=(ph, drop1[2]))
+        (dp0, dg0, db0, dm0), (dp1, dg1, db1, dm1) = _ln_bwd_to2((_rows(dy0), _rows(dy1)), (pre0, pre1), (P0[4], P1[4]), (P0[5], P1[5]),
+                                                                 (m0, m1), (r0, r1), (w0, w1), drop=(ph, (drop0[2], drop1[2])))
         g0, g1 = [None] * 4, [None] * 4
         if w0:
             (g0[2],), (g0[3],) = _wb_grad_to((P0[2],), (P0[3],), dm0, h0)
@@ -1604,26 +1649,29 @@ class _Cosine(torch.autograd.Function):
 
 class _GateRows(torch.autograd.Function):
     """f = visn[:, r0:r0+n] * lang[:, :1]  (NavCMT's action-head input for act_pred_token == 'ob_txt', vilmodel_cmt.py:1192):
-    one node instead of two slices, a broadcast multiply and their backward (three zero-filled full-size gradients + adds)."""
+    one kernel forward and one backward (vlni_gate_rows_*) instead of two slices, a broadcast multiply and their backward (zero-filled
+    full-size gradients, casts, a reduction: ~14 launches per navigation step)."""
 
     @staticmethod
     def forward(ctx, visn, lang, r0, n):
-        ob, g = visn[:, r0:r0 + n], lang[:, :1]
-        ctx.save_for_backward(ob, g)
-        ctx.meta = (visn.shape, lang.shape, r0, n)
-        return ob * g
+        visn, lang = _chk(visn, "visn").contiguous(), _chk(lang, "lang").contiguous()
+        (B, Sv, H), Sl = visn.shape, lang.shape[1]
+        f = torch.empty((B, n, H), dtype=visn.dtype, device=visn.device)
+        _lib.call("vlni_gate_rows_fwd", _dt(visn), visn.data_ptr(), lang.data_ptr(), f.data_ptr(), B, Sv, Sl, r0, n, H, _st())
+        ctx.save_for_backward(visn, lang)
+        ctx.meta = (r0, n)
+        return f
 
     @staticmethod
     def backward(ctx, df):
-        ob, g = ctx.saved_tensors
-        vshape, lshape, r0, n = ctx.meta
-        dvisn = dlang = None
-        if ctx.needs_input_grad[0]:
-            dvisn = df.new_zeros(vshape)
-            torch.mul(df, g, out=dvisn[:, r0:r0 + n])
-        if ctx.needs_input_grad[1]:
-            dlang = df.new_zeros(lshape)
-            dlang[:, 0] = (df.float() * ob.float()).sum(1).to(df.dtype)
+        visn, lang = ctx.saved_tensors
+        r0, n = ctx.meta
+        (B, Sv, H), Sl = visn.shape, lang.shape[1]
+        dvisn = torch.empty_like(visn) if ctx.needs_input_grad[0] else None       # the kernel writes every row of both
+        dlang = torch.empty_like(lang) if ctx.needs_input_grad[1] else None
+        if dvisn is not None or dlang is not None:
+            _lib.call("vlni_gate_rows_bwd", _dt(visn), _chk(df, "df").contiguous().data_ptr(), visn.data_ptr(), lang.data_ptr(), _p(dvisn), _p(dlang),
+                      B, Sv, Sl, r0, n, H, _st())
         return dvisn, dlang, None, None
 
 
