@@ -100,33 +100,57 @@ template <typename T>
 __global__ __launch_bounds__(256) void smallk_bwd_kernel(const T* __restrict__ dy, long lddy, const float* __restrict__ x,
                                                          long ldx, float* __restrict__ dW, float* __restrict__ db, int rows,
                                                          int N, int K, int rpb) {
-  __shared__ float xs[64 * 16];
+  // block = 64 output columns x one slab of <= 256 rows; its 4 waves take every 4th row of the slab, their partial sums meet in LDS
+  // and only 64 x (K + 1) block totals go out as float atomics (one thread per column and slab of 8-64 rows, as before, made
+  // (rows / 8) x N x (K + 1) contended atomics: 45-90 us for DUET's 1184 x 14 position features)
+  __shared__ float xs[256 * 16];
+  __shared__ float red[4][17][64];
   const int r0 = blockIdx.y * rpb, nr = min(rpb, rows - r0);
   for (int i = threadIdx.x; i < nr * K; i += 256) xs[i] = x[(long)(r0 + i / K) * ldx + i % K];
   __syncthreads();
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N || nr <= 0) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
   float a[16], s = 0.f;
+#pragma unroll
   for (int k = 0; k < 16; ++k) a[k] = 0.f;
-  const T* dp = dy + (long)r0 * lddy + n;
-  int r = 0;
-  for (; r + 7 < nr; r += 8) {
-    float d[8];
+  if (n < N) {
+    const T* dp = dy + (long)r0 * lddy + n;
+    int r = w;
+    for (; r + 28 < nr; r += 32) {                           // eight of this wave's rows in flight (the loop is latency-bound)
+      float d[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) d[u] = DT<T>::ld(dp + (long)(r + u) * lddy);
+      for (int u = 0; u < 8; ++u) d[u] = DT<T>::ld(dp + (long)(r + 4 * u) * lddy);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      s += d[u];
-      for (int k = 0; k < K; ++k) a[k] += d[u] * xs[(r + u) * K + k];
+      for (int u = 0; u < 8; ++u) {
+        s += d[u];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)                         // full unroll + uniform guard: a[] stays in registers (K is a run-time value)
+          if (k < K) a[k] += d[u] * xs[(r + 4 * u) * K + k];
+      }
+    }
+    for (; r < nr; r += 4) {
+      const float d = DT<T>::ld(dp + (long)r * lddy);
+      s += d;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < K) a[k] += d * xs[r * K + k];
     }
   }
-  for (; r < nr; ++r) {
-    const float d = DT<T>::ld(dp + (long)r * lddy);
-    s += d;
-    for (int k = 0; k < K; ++k) a[k] += d * xs[r * K + k];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) red[w][k][lane] = a[k];
+  red[w][16][lane] = s;
+  __syncthreads();
+  // the block's 64 x K gradient entries are CONTIGUOUS in dW ([N][K] row-major): consecutive threads add to consecutive addresses
+  const int ncol = min(64, N - blockIdx.x * 64);
+  float* const dWb = dW + (long)blockIdx.x * 64 * K;
+  for (int i = threadIdx.x; i < ncol * K; i += 256) {
+    const int c = i / K, k = i - c * K;
+    atomicAdd(dWb + i, (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]));
   }
-  for (int k = 0; k < K; ++k) atomicAdd(dW + (long)n * K + k, a[k]);
-  if (db) atomicAdd(db + n, s);
+  if (db && threadIdx.x < ncol) {
+    const int c = threadIdx.x;
+    atomicAdd(db + blockIdx.x * 64 + c, (red[0][16][c] + red[1][16][c]) + (red[2][16][c] + red[3][16][c]));
+  }
 }
 
 // table_grad[idx[r]][:] += src[r][:]   (embedding backward; idx == null: every row goes to row 0)
@@ -708,8 +732,8 @@ extern "C" int vlni_smallk_linear_bwd(int dtype, const void* dy, long lddy, cons
                                       int rows, int N, int K, void* stream) {
   VLNI_CHECK(K >= 1 && K <= 16 && rows > 0 && N > 0, VLNI_EINVAL, "smallk_bwd: rows=%d N=%d K=%d", rows, N, K);
   static const int rpb_env = getenv("VLNI_SMALLK_RPB") ? atoi(getenv("VLNI_SMALLK_RPB")) : 0;
-  const int rpb = std::min(64, std::max(8, rpb_env > 0 ? rpb_env : cdiv(rows, 128)));      // <= 64 rows of x in LDS; ~128 slabs
-  dim3 grid(cdiv(N, 256), cdiv(rows, rpb)), block(256);
+  const int rpb = std::min(256, std::max(16, rpb_env > 0 ? rpb_env : rows <= 4096 ? 64 : 128));   // <= 256 rows of x in LDS (probe: tools/scratch/smallk_probe.py)
+  dim3 grid(cdiv(N, 64), cdiv(rows, rpb)), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((smallk_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)dy, lddy, x, ldx, dW, db, rows, N, K, rpb),
            hipLaunchKernelGGL((smallk_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)dy, lddy, x, ldx, dW, db, rows, N, K, rpb),
           hipLaunchKernelGGL((smallk_bwd_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)dy, lddy, x, ldx, dW, db, rows, N, K, rpb));
