@@ -53,7 +53,7 @@ def build_reference(cfgd):
 
 
 def run_variant(name, over, epkw):
-    cfgd = duet_config_dict(**DUET_C1, **over)
+    cfgd = duet_config_dict(**{**DUET_C1, **over})
     model = build_reference(cfgd)
     kw = dict(DUET_EP)
     kw.update(epkw)

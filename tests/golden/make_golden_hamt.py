@@ -66,7 +66,7 @@ def build_reference(cfgd):
 
 
 def run_variant(name, over, epkw):
-    cfgd = hamt_config_dict(**HAMT_C1, **over)
+    cfgd = hamt_config_dict(**{**HAMT_C1, **over})
     model = build_reference(cfgd)
     kw = dict(HAMT_EP)
     kw.update(epkw)

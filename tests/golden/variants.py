@@ -13,6 +13,8 @@ HAMT_VARIANTS = {
     "c1_margin": (dict(aux_loss_type="constrastive-margin"), dict()),
     "c1_encoder": (dict(bypass_imag_encoder=False), dict()),
     "c1_T3_dense": (dict(), dict(T=3, ragged=False)),
+    # the released depth (run_r2r.bash: 9 language, 4 cross-modal, 2 history-panorama layers), made by the reference itself at B = 2
+    "c2_depth": (dict(num_l_layers=9, num_x_layers=4, num_h_pano_layers=2), dict(B=2)),
 }
 HAMT_C1 = dict(num_l_layers=2, num_x_layers=2, num_h_pano_layers=2)
 HAMT_EP = dict(tag="golden", B=4, L=80, V=37, I=4, T=2, ragged=True)
@@ -20,7 +22,7 @@ HAMT_EP = dict(tag="golden", B=4, L=80, V=37, I=4, T=2, ragged=True)
 
 def hamt_variant_setup(name):
     over, epkw = HAMT_VARIANTS[name]
-    cfg = HamtConfig(**HAMT_C1, **over)
+    cfg = HamtConfig(**{**HAMT_C1, **over})
     kw = dict(HAMT_EP)
     kw.update(epkw)
     return cfg, synth.HamtEpisode(**kw)
@@ -38,6 +40,8 @@ DUET_VARIANTS = {
     "c1_reverie": (dict(dataset="reverie", obj_feat_size=768), dict(I=1, O=5)),
     "c1_reverie_infonce": (dict(dataset="reverie", obj_feat_size=2048, aux_loss_type="contrastive-InfoNCE",
                                 fix_lang_inside_cosine_model=False), dict(I=1, O=5, obj_feat=2048)),
+    # the released depth (run_r2r.sh:42-44: 9 language, 2 panorama, 4 + 4 cross-modal layers), made by the reference itself at B = 2
+    "c2_depth": (dict(num_l_layers=9, num_pano_layers=2, num_x_layers=4), dict(B=2)),
 }
 DUET_C1 = dict(num_l_layers=2, num_pano_layers=2, num_x_layers=2)
 DUET_EP = dict(tag="golden", B=4, L=80, V=36, I=4, T=2, ragged=True)
@@ -45,7 +49,7 @@ DUET_EP = dict(tag="golden", B=4, L=80, V=36, I=4, T=2, ragged=True)
 
 def duet_variant_setup(name):
     over, epkw = DUET_VARIANTS[name]
-    cfg = DuetConfig(**DUET_C1, **over)
+    cfg = DuetConfig(**{**DUET_C1, **over})
     kw = dict(DUET_EP)
     kw.update(epkw)
     return cfg, synth.DuetEpisode(**kw)
