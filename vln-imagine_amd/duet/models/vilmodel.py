@@ -287,30 +287,37 @@ class GlocalTextPathNavCMT(nn.Module):
         if ge.sprel_linear is not None:                                                     # reference :1145-1147
             sprels = (gmap_pair_dists * ge.sprel_linear.weight[0, 0] + ge.sprel_linear.bias[0]).contiguous()
         vp = vp_img_embeds.to(dt) + le.vp_pos_embeddings.embed(vp_pos_fts, dt)
-        txt, tm = txt_embeds.to(dt), txt_masks
-        if c.imagine_enc_pano and c.concat_imagine_with == "language":
-            assert imagine_embeds is not None and imagine_masks is not None
-            txt, tm = torch.cat([txt, imagine_embeds.to(dt)], 1), torch.cat([tm, imagine_masks], 1)
-        else:
-            assert not c.imagine_enc_pano
-        lm = ops.additive_mask(tm).contiguous()
-        txt = txt.contiguous()
+        def language_side():
+            """text (+ imagination tokens) and its additive key mask (reference :1110-1125)"""
+            txt, tm = txt_embeds.to(dt), txt_masks
+            if c.imagine_enc_pano and c.concat_imagine_with == "language":
+                assert imagine_embeds is not None and imagine_masks is not None
+                txt, tm = torch.cat([txt, imagine_embeds.to(dt)], 1), torch.cat([tm, imagine_masks], 1)
+            else:
+                assert not c.imagine_enc_pano
+            return txt.contiguous(), ops.additive_mask(tm).contiguous()
+
         kv_g = kv_l = None
         if CACHE_TEXT_KV:
             # the language stream is never updated (use_lang2visn_attn False), so its per-layer K/V projections are the same
-            # for every step of an episode: project once, reduce their gradient once. Key = identity of the caller-held
-            # embeddings (strong refs keep the ids unique) + the parameter epoch; a backward through the entry drops it.
+            # for every step of an episode: project once, reduce their gradient once - and build the concatenated stream and its
+            # mask only then. Key = identity of the caller-held embeddings and masks (strong refs keep the ids unique) + the
+            # parameter epoch; a backward through the entry drops it.
             wk = ge.encoder.x_layers[0].visual_attention.att.key.weight
-            key = (id(txt_embeds), id(imagine_embeds), txt_embeds._version, torch.is_grad_enabled(), dt, ops.SHADOWS.epoch,
-                   wk._version, tuple(tm.shape))
+            key = (id(txt_embeds), id(imagine_embeds), id(txt_masks), id(imagine_masks), txt_embeds._version, txt_masks._version,
+                   imagine_masks._version if torch.is_tensor(imagine_masks) else None, torch.is_grad_enabled(), dt, ops.SHADOWS.epoch,
+                   wk._version)
             ent = self._kv_cache
             if ent is None or ent[0] != key:
+                txt, lm = language_side()
                 kvs = (ge.encoder.project_context(txt), le.encoder.project_context(txt))
-                ent = self._kv_cache = (key, (txt_embeds, imagine_embeds), kvs[0], kvs[1])
+                ent = self._kv_cache = (key, (txt_embeds, imagine_embeds, txt_masks, imagine_masks), kvs[0], kvs[1], txt, lm)
                 for kv in kvs[0] + kvs[1]:
                     if kv.requires_grad:
                         kv.register_hook(self._drop_kv_cache)
-            kv_g, kv_l = ent[2], ent[3]
+            kv_g, kv_l, txt, lm = ent[2], ent[3], ent[4], ent[5]
+        else:
+            txt, lm = language_side()
         gmap, vp = gmap.contiguous(), vp.contiguous()
         gm, vm = ops.additive_mask(gmap_masks), ops.additive_mask(vp_masks)
         if DUAL_BRANCHES and kv_g is not None:
