@@ -447,7 +447,7 @@ def test_wgrad_partials_reject_register_staged_kernel(ops):
                   2, 5, torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32, 33])
 def test_gemm_variants_identical(ops, variant):
     """All GEMM pipelines (register-staged, LDS-DMA 2/3-stage with 4 or 8 waves, large tiles 256x128 / 256x256 / 128x256) give
     bit-identical results, incl. epilogues and ragged tile edges."""
@@ -463,7 +463,7 @@ def test_gemm_variants_identical(ops, variant):
             assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (variant, dtype, M, N, K)
 
 
-@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32])
+@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32, 33])
 def test_gemm_dual_launch_variants(ops, variant):
     """Two problems in one launch (language + vision stream) == two single launches, for every tile geometry."""
     saved = (ops.AUTOTUNE, ops.GEMM_VARIANTS)
@@ -486,7 +486,7 @@ def test_gemm_dual_launch_variants(ops, variant):
         ops._GEMM_BEST.clear()
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 32])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 32, 33])
 def test_gemm_nn_weight_layout_matches_transposed_copy(ops, variant):
     """dgrad straight from W[out, in] (transposing LDS reads, variant + 16) == the NT kernel on an explicit W^T copy, bit for bit,
     incl. GELU' / residual epilogues, ragged rows and a partial column tile (zero page)."""
@@ -509,7 +509,7 @@ def test_gemm_nn_weight_layout_matches_transposed_copy(ops, variant):
     assert torch.equal(o0, ops.gemm_nt(a0, w0.t().contiguous())) and torch.equal(o1, ops.gemm_nt(a1, ops.KN(w1)))
 
 
-@pytest.mark.parametrize("nn,pk", [(False, 14), (True, 6), (False, 15), (True, 7), (False, 32), (True, 32)])
+@pytest.mark.parametrize("nn,pk", [(False, 14), (True, 6), (False, 15), (True, 7), (False, 32), (True, 32), (False, 33), (True, 33)])
 def test_gemm_persistent_kernel_streams_many_tiles(ops, nn, pk):
     """The persistent kernel (variant 14; 16 + 6 with the weight as [K, N]) at the bench's row counts: > 512 tiles, so every block walks
     several tiles through its two LDS stages (next tile's first k-tile prefetched under the epilogue), two problems per launch, every
