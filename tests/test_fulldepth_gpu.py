@@ -103,3 +103,30 @@ def test_bf16_timed_path_tracks_fp32_at_bench_shapes(family, B, low):
         assert any(v >= 16 for v in picked) or family == "duet", picked        # the transposing-read dgrad kernel ran (>= 4096 rows)
     finally:
         tr.close()
+
+
+@pytest.mark.parametrize("family", ["duet", "hamt"])
+def test_fp32_parity_path_runs_200_token_instructions(family):
+    """The reference's DUET scripts run --max_instr_len 200 (VLN-DUET/map_nav_src/scripts/run_r2r.sh): 200 + 6 keys are beyond the
+    float32 tile attention kernels (128 keys) and go through the generic ones. fp32 HIP vs the CPU oracle, forward + backward, two
+    layers of each kind."""
+    from tests.golden.variants import DUET_C1, HAMT_C1
+    from vln_imagine_amd import ops
+    if family == "duet":
+        from vln_imagine_amd.duet.config import DuetConfig
+        from vln_imagine_amd.duet.episode import DuetEpisodeTensors as ET, run_episode as run
+        cfg, ep, key = DuetConfig(**DUET_C1), synth.DuetEpisode(tag="long", B=2, L=200, V=36, I=6, T=2, ragged=True), "fused"
+    else:
+        from vln_imagine_amd.hamt.config import HamtConfig
+        from vln_imagine_amd.hamt.episode import EpisodeTensors as ET, run_episode as run
+        cfg, ep, key = HamtConfig(**HAMT_C1), synth.HamtEpisode(tag="long", B=2, L=200, V=37, I=6, T=2, ragged=True), "logits"
+    oracle, sd = _oracle(family, cfg)
+    ref = run(oracle, ET(ep, "cpu"))
+    ref["loss"].backward()
+    model = _product(family, cfg, torch.float32)
+    out = run(model, ET(ep, "cuda"), criterion=ops.cross_entropy_sum)
+    out["loss"].backward()
+    r = compare_runs(out, ref, dict(model.named_parameters()), sd, key)
+    print(f"\n[{family} fp32 HIP vs CPU oracle, L = 200] {r}")
+    assert r["loss_abs"] <= 1e-4 and r["logit_max_abs"] <= 1e-4, r
+    assert r["grad_rel_l2"] <= 2e-5 and r["grad_worst_param_rel_l2"] <= 5e-3, r

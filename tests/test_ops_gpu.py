@@ -170,8 +170,38 @@ def test_attention_long_context_bf16(ops, B, Sq, Sk):
     ops.attn_bwd(qt, k, v, out, dout, lse, dq, dkv[:, :H], dkv[:, H:], B, Sq, Sk, kmask)
     for a, r, n in ((dq, qr.grad, "dq"), (dkv[:, :H], kr.grad, "dk"), (dkv[:, H:], vr.grad, "dv")):
         assert _err(a, r) < 6e-2, (n, _err(a, r))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Sq,Sk,use_bias", [(2, 45, 206, False), (2, 206, 206, True), (1, 70, 300, False), (2, 5, 513, True)])
+def test_attention_beyond_the_tile_kernels(ops, dtype, B, Sq, Sk, use_bias):
+    """More keys than the tile kernels take (128 in float32 - the reference's DUET scripts run --max_instr_len 200 on the parity path -
+    256 in the 16-bit types): the generic kernels behind them, against float64 torch incl. the bias gradient."""
+    if dtype == torch.bfloat16 and Sk <= 256:
+        pytest.skip("the tile kernels' range")
+    H = 768
+    qt, kt = _rand((B * Sq, H), dtype, 21, 0.7), _rand((B * Sk, 2 * H), dtype, 22, 0.7)
+    lens = torch.tensor([Sk] + [Sk - 37] * (B - 1))
+    kmask = ((torch.arange(Sk)[None, :] >= lens[:, None]).float() * -10000.0).cuda()
+    bias = _rand((B, Sq, Sk), torch.float32, 24, 0.5) if use_bias else None
+    k, v = kt[:, :H], kt[:, H:]
+    out, lse = ops.attn_fwd(qt, k, v, B, Sq, Sk, kmask, bias)
+    qr, kr, vr = (t.double().clone().requires_grad_(True) for t in (qt, k, v))
+    br = bias.double().clone().requires_grad_(True) if use_bias else None
+    ref = _attn_ref(qr, kr, vr, kmask, br, B, Sq, Sk)
+    t = 2e-5 if dtype == torch.float32 else 3e-2
+    assert _err(out, ref) < t, _err(out, ref)
+    dout = _rand((B * Sq, H), dtype, 23)
+    ref.backward(dout.double())
+    dq, dkv = torch.zeros_like(qt), torch.zeros_like(kt)
+    dbias = torch.zeros_like(bias) if use_bias else None
+    ops.attn_bwd(qt, k, v, out, dout, lse, dq, dkv[:, :H], dkv[:, H:], B, Sq, Sk, kmask, bias, dbias)
+    for a, r, n in ((dq, qr.grad, "dq"), (dkv[:, :H], kr.grad, "dk"), (dkv[:, H:], vr.grad, "dv")):
+        assert _err(a, r) < 2 * t, (n, _err(a, r))
+    if use_bias:
+        assert _err(dbias, br.grad) < 5 * t, _err(dbias, br.grad)
     with pytest.raises(Exception, match="not covered"):
-        ops.attn_fwd(qt.float(), k.float(), v.float(), B, Sq, Sk, kmask)      # fp32 parity path: <= 128 keys
+        ops.attn_fwd(qt, k[:1].expand(B * 2100, H).contiguous(), v[:1].expand(B * 2100, H).contiguous(), B, Sq, 2100, None)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
