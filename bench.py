@@ -494,10 +494,14 @@ def main():
         if args.model == "hamt" and args.lang_rows == "all":
             w.model.visual_lang_rows = "cls"
             s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="cls-rows")
+            if not args.time_batched:
+                s2_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=True, graph=args.graph, what="cls-rows, time-batched")
             w.model.visual_lang_rows = "all"
             extras["cls_rows"] = line(s_, w.flops, "what the VLNBertCMT wrapper runs: the last cross-modal layer computes only the language [CLS] row it "
                                                    "reads (NavCMT.visual_lang_rows = 'cls'); logits, loss and gradients identical "
                                                    "(tests/test_hamt_gpu.py), step_algorithmic_tflops still counts the reference's full rows")
+            if not args.time_batched:
+                extras["cls_rows"]["time_batched_ms_per_step"] = round(s2_ * 1e3, 3)
         if not args.train_mode:
             w.model.train()
             s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="train-mode")
