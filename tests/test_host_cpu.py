@@ -38,7 +38,7 @@ def test_argument_validation_without_gpu():
     lib = _lib.load()
     rc = lib.vlni_gemm_nt(0, 16, 7, 16, 8, 16, 8, 4, 4, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0, 1, 0, 0)   # K=7 not a multiple of 4
     assert rc == -1 and b"multiples" in lib.vlni_last_error()
-    rc = lib.vlni_attn_fwd(1, 16, 768, 16, 768, 16, 768, 0, 0, 16, 768, 16, 2, 12, 10, 300, 0.125, 0.0, 0, 0)   # Sk > 256
+    rc = lib.vlni_attn_fwd(1, 16, 768, 16, 768, 16, 768, 0, 0, 16, 768, 16, 2, 12, 10, 3000, 0.125, 0.0, 0, 0)   # Sk > 2048 (beyond the generic kernels too)
     assert rc == -3 and b"not covered" in lib.vlni_last_error()
 
 
