@@ -441,6 +441,27 @@ def main():
                 traffic_src = f"profiles/{pmc[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
         except Exception:
             traffic = None
+        # what a large dense GEMM reaches on THIS box ("a measured large-GEMM ceiling"): the vendor library on 8192^3 in the
+        # timed dtype, random operands - a reference measurement only, the product path never calls it
+        ceiling, ceiling_at = None, None
+        try:
+            cd = torch.float32 if args.dtype == "fp32" else dtype
+            for n_ in ((2048, 4096) if args.dtype == "fp32" else (4096, 8192)):
+                xa, xb = torch.randn(n_, n_, device=dev).to(cd), torch.randn(n_, n_, device=dev).to(cd)
+                for _ in range(2):
+                    torch.matmul(xa, xb.t())
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(5):
+                    torch.matmul(xa, xb.t())
+                c1.record()
+                torch.cuda.synchronize()
+                tf = round(5 * 2.0 * n_ ** 3 / (c0.elapsed_time(c1) * 1e-3) / 1e12, 1)
+                if ceiling is None or tf > ceiling:
+                    ceiling, ceiling_at = tf, n_
+                del xa, xb
+        except Exception as e:                                  # never lets the reference measurement break the line
+            log(f"large-GEMM ceiling not measured ({type(e).__name__}: {e})")
         alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec)
         roof = {"bound": "mfma", "kernel": "gemm_nt_* / gemm_nn_* <%s>" % {"bf16": "__bf16", "fp16": "_Float16", "fp32": "float"}[args.dtype],
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
@@ -451,7 +472,11 @@ def main():
                 "avg_gflop_per_launch": round(tot_f / len(rec) / 1e9, 3),
                 "gemm_share_of_step": round(tot_ms / ms, 3),
                 "step_algorithmic_tflops": round(w.flops / sec / 1e12, 2),
-                "step_frac_of_peak": round(w.flops / sec / 1e12 / peak, 4)}
+                "step_frac_of_peak": round(w.flops / sec / 1e12 / peak, 4),
+                "measured_large_gemm_tflops": ceiling,
+                "frac_of_measured_large_gemm": round(ach / ceiling, 4) if ceiling else None,
+                "measured_large_gemm": f"torch.matmul(a, b.T) (vendor library), {ceiling_at}^3 {args.dtype}, random operands, best of 4096^3 / 8192^3 "
+                                       f"(fp32: 2048^3 / 4096^3), this box"}
 
     # ---- error of the timed path against the fp32 parity path (same model, same weights, B = 8 slice, fwd + bwd) -------------
     parity = None
