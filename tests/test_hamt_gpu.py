@@ -170,6 +170,44 @@ def test_deferred_grouped_wgrad_bf16_matches_immediate():
         ops._WQ.clear()
 
 
+def test_batched_same_shape_weight_gradients_match_per_parameter_launches():
+    """The text encoder's layers queue ONE (dY, X) pair per parameter: same-shape gradients (9 x QKV, O, FFN-in, FFN-out at the released
+    depth) are reduced by one grouped launch per shape class whose row splits fall on gradient boundaries (ops._flush_batch).
+    Batched == one launch per parameter == immediate, on a 5-layer text encoder, twice in a row (the second flush reuses the
+    workspaces and the cached choice)."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.config import HamtConfig
+    from vln_imagine_amd.train import FlatTrainer
+    cfg = HamtConfig(num_l_layers=5, num_x_layers=1, num_h_pano_layers=1)
+    ep = synth.HamtEpisode(tag="batchw", B=16, L=80, V=37, I=4, T=2, ragged=True)
+    et = EpisodeTensors(ep, "cuda")
+    saved = ops.BATCH_WGRADS
+    try:
+        grads, batched_calls = [], []
+        for defer, batch in ((False, False), (True, False), (True, True), (True, True)):
+            ops.BATCH_WGRADS = batch
+            m = build_product(cfg, torch.bfloat16)
+            tr = FlatTrainer(m)
+            tr.set_defer(defer)
+            tr.zero_grad()
+            run_episode(m, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+            n_single = sum(1 for _, _, s in ops._WQ.values() if len(s) == 1)
+            before = len(ops._TNB_BEST)
+            tr.flush()
+            batched_calls.append((n_single, len(ops._TNB_BEST) - before))
+            grads.append(tr.flat_g.clone())
+            tr.close()
+        assert batched_calls[2][0] >= 20 and batched_calls[2][1] >= 4, batched_calls       # 5 layers x 4 shapes queued; 4 shape classes tuned
+        for g in grads[1:]:
+            rel = ((grads[0] - g).norm() / grads[0].norm()).item()
+            assert rel < 1e-4, rel
+            worst = ((grads[0] - g).abs().max() / grads[0].abs().max()).item()
+            assert worst < 2e-3, worst
+    finally:
+        ops.BATCH_WGRADS = saved
+        ops._WQ.clear()
+
+
 @pytest.mark.parametrize("T", [9, 15])
 def test_deferred_wgrad_with_more_than_16_segments(T):
     """Step-by-step episodes of T >= 9 queue 2 T > 16 (dY, X) pairs for the shared cross-attention weights (the reference's

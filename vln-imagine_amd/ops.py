@@ -750,6 +750,80 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev, dtid=BF16):
     return v, sp
 
 
+BATCH_WGRADS = os.environ.get("VLNI_BATCH_WGRADS", "1") == "1"
+_TNB_BEST = {}
+
+
+def _tn_batch_choice(P, pa, pb, pm, N, K, nmt_p, dev, dtid):
+    """(kernel variant, row splits per gradient) of a BATCHED weight-gradient launch: P gradients of one shape, one (dY, X) segment of
+    nmt_p 64-row tiles each. The splits per gradient must divide nmt_p so that no block's rows cross into the next gradient."""
+    divs = [d for d in range(1, nmt_p + 1) if nmt_p % d == 0 and nmt_p // d >= 4]
+    default = (TN_VARIANT, divs[min(len(divs) - 1, 1)] if divs else 1)
+    if not AUTOTUNE:
+        return default
+    key = (N, K, nmt_p, P, dtid)
+    best = _TNB_BEST.get(key)
+    if best is not None or torch.cuda.is_current_stream_capturing():
+        return best or default
+    t128, t256 = -(-N // 128) * -(-K // 128), -(-N // 256) * -(-K // 256)
+    cands = set()
+    for v, tiles in ((TN_VARIANT, t128),) + (((6, t256), (7, t256)) if TN_BIG and N >= 256 and K >= 256 else ()):
+        want = max(1.0, (512 if v == TN_VARIANT else 250) / (P * tiles))           # splits per gradient for about one round of blocks
+        near = sorted(divs, key=lambda d: abs(d - want))[:3]
+        cands |= {(v, d) for d in near}
+    smax = max(sp for _, sp in cands) * P
+    scratch = torch.zeros((smax * (N * K + N),), dtype=torch.float32, device=dev)
+    timed = []
+    for v, sp in sorted(cands):
+        if not _parts_ok(v, P * nmt_p, P * sp):
+            continue
+        args = ("vlni_gemm_tn_h16_grouped_part", dtid, P, pa, pb, pm, N, K, scratch.data_ptr(), N * K, N, K,
+                scratch.data_ptr() + 4 * smax * N * K, P * sp, v, _st())
+        _lib.call(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call(*args); _lib.call(*args)
+        e1.record()
+        e1.synchronize()
+        timed.append((e0.elapsed_time(e1) / 2 + P * (sp + 2) * (N * K + N) * 4 / 4e9, v, sp))
+    if not timed:
+        return None
+    _, v, sp = min(timed)
+    _TNB_BEST[key] = (v, sp)
+    return v, sp
+
+
+def _flush_batch(members, entries):
+    """ONE grouped launch for several gradients of the same shape that have a single (dY, X) segment of the same length each (the
+    text encoder's layers: 9 x {QKV, O, FFN-in, FFN-out}): the launch's row-tile space is the gradients' segments back to back, its
+    P x s row splits fall on gradient boundaries, split z writes slab z, and the batched reduction adds slabs [p s, (p + 1) s) into
+    gradient p. Per gradient these launches were 108-144 tiles x 3-14 splits of 5-27 k-steps (350 TF/s over the class)."""
+    P = len(members)
+    d0, x0 = members[0][3][0]
+    N, K, M, dtid, dev = d0.shape[1], x0.shape[1], d0.shape[0], _dt(d0), d0.device
+    pa = (ctypes.c_void_p * P)(*[m[3][0][0].data_ptr() for m in members])
+    pb = (ctypes.c_void_p * P)(*[m[3][0][1].data_ptr() for m in members])
+    pm = (ctypes.c_int * P)(*[M] * P)
+    nmt_p = (M + 63) // 64
+    choice = _tn_batch_choice(P, pa, pb, pm, N, K, nmt_p, dev, dtid)
+    if choice is None or not _parts_ok(choice[0], P * nmt_p, P * choice[1]):
+        return False
+    variant, sp = choice
+    tot = P * sp
+    key = (members[0][1].data_ptr(), N, K, "batch", P)
+    buf = _PART_BUFS.get(key)
+    if buf is None or buf.numel() < tot * (N * K + N):
+        if buf is not None:
+            _KEEPALIVE.append(buf)
+        buf = _PART_BUFS[key] = torch.empty((tot * (N * K + N),), dtype=torch.float32, device=dev)
+    cpart = buf.data_ptr() + 4 * tot * N * K
+    _lib.call("vlni_gemm_tn_h16_grouped_part", dtid, P, pa, pb, pm, N, K, buf.data_ptr(), N * K, N, K, cpart, tot, variant, _st())
+    for i, (_, wv, bv, _) in enumerate(members):
+        entries.append((wv.data_ptr(), buf.data_ptr() + 4 * i * sp * N * K, N * K // 4, N * K // 4, sp))
+        entries.append((bv.data_ptr(), cpart + 4 * i * sp * N, N // 4, N // 4, sp))
+    return True
+
+
 def flush_wgrads(lo=None, hi=None):
     """Runs the queued weight/bias gradient reductions (must precede any read of the .grad arena). With (lo, hi): only the
     gradients whose address lies in [lo, hi), in address order (train.FlatTrainer's flush -> all-reduce pipeline)."""
@@ -758,8 +832,25 @@ def flush_wgrads(lo=None, hi=None):
         todo = list(_WQ)
     else:
         todo = sorted(k for k in _WQ if lo <= k < hi)
-    for key in todo:
-        wv, bv, segs = _WQ.pop(key)
+    items = [(key,) + tuple(_WQ.pop(key)) for key in todo]
+    if BATCH_WGRADS and WGRAD_PARTS and len(items) > 1:
+        groups, rest = {}, []
+        for it in items:
+            _, wv, bv, segs = it
+            d, x = segs[0]
+            if len(segs) == 1 and wv.is_contiguous() and bv.is_contiguous() and d.shape[1] % 4 == 0 and d.shape[0] >= 256:
+                groups.setdefault((d.shape[1], x.shape[1], d.shape[0], d.dtype), []).append(it)
+            else:
+                rest.append(it)
+        for members in groups.values():
+            for c in range(0, len(members), 16):
+                chunk = members[c:c + 16]
+                if len(chunk) >= 2 and _flush_batch(chunk, entries):
+                    dev = chunk[0][1].device
+                else:
+                    rest.extend(chunk)
+        items = rest
+    for key, wv, bv, segs in items:
         dev = wv.device
         N, K = segs[0][0].shape[1], segs[0][1].shape[1]
         plans, tot = [], 0                 # a gradient with more than 16 segments (an episode of > 8 steps through a shared module)
