@@ -750,18 +750,19 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev, dtid=BF16):
     return v, sp
 
 
-BATCH_WGRADS = os.environ.get("VLNI_BATCH_WGRADS", "1") == "1"
+BATCH_WGRADS = int(os.environ.get("VLNI_BATCH_WGRADS", "1"))      # 0 off, 1 on, 2 = also the wide multi-segment gradients (probe)
 _TNB_BEST = {}
 
 
-def _tn_batch_choice(P, pa, pb, pm, N, K, nmt_p, dev, dtid):
-    """(kernel variant, row splits per gradient) of a BATCHED weight-gradient launch: P gradients of one shape, one (dY, X) segment of
-    nmt_p 64-row tiles each. The splits per gradient must divide nmt_p so that no block's rows cross into the next gradient."""
+def _tn_batch_choice(P, n, pa, pb, pm, N, K, nmt_p, dev, dtid):
+    """(kernel variant, row splits per gradient) of a BATCHED weight-gradient launch: P gradients of one shape with the same (dY, X)
+    segment lengths each (n segments in all, nmt_p 64-row tiles per gradient). The splits per gradient must divide nmt_p so that no
+    block's rows cross into the next gradient."""
     divs = [d for d in range(1, nmt_p + 1) if nmt_p % d == 0 and nmt_p // d >= 4]
     default = (TN_VARIANT, divs[min(len(divs) - 1, 1)] if divs else 1)
     if not AUTOTUNE:
         return default
-    key = (N, K, nmt_p, P, dtid)
+    key = (N, K, nmt_p, P, n, dtid)
     best = _TNB_BEST.get(key)
     if best is not None or torch.cuda.is_current_stream_capturing():
         return best or default
@@ -777,7 +778,7 @@ def _tn_batch_choice(P, pa, pb, pm, N, K, nmt_p, dev, dtid):
     for v, sp in sorted(cands):
         if not _parts_ok(v, P * nmt_p, P * sp):
             continue
-        args = ("vlni_gemm_tn_h16_grouped_part", dtid, P, pa, pb, pm, N, K, scratch.data_ptr(), N * K, N, K,
+        args = ("vlni_gemm_tn_h16_grouped_part", dtid, n, pa, pb, pm, N, K, scratch.data_ptr(), N * K, N, K,
                 scratch.data_ptr() + 4 * smax * N * K, P * sp, v, _st())
         _lib.call(*args)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -793,19 +794,25 @@ def _tn_batch_choice(P, pa, pb, pm, N, K, nmt_p, dev, dtid):
     return v, sp
 
 
+TN_MAXSEG = 32          # csrc/gemm_impl.inc: row segments one grouped launch takes
+
+
 def _flush_batch(members, entries):
-    """ONE grouped launch for several gradients of the same shape that have a single (dY, X) segment of the same length each (the
-    text encoder's layers: 9 x {QKV, O, FFN-in, FFN-out}): the launch's row-tile space is the gradients' segments back to back, its
-    P x s row splits fall on gradient boundaries, split z writes slab z, and the batched reduction adds slabs [p s, (p + 1) s) into
-    gradient p. Per gradient these launches were 108-144 tiles x 3-14 splits of 5-27 k-steps (350 TF/s over the class)."""
+    """ONE grouped launch for several gradients of the same shape whose (dY, X) segments have the same lengths (the text encoder's
+    layers: 9 x {QKV, O, FFN-in, FFN-out} with one segment each; the cross-modal layers' 768 x 768 projections with one segment per
+    step): the launch's row-tile space is the gradients' segments back to back, its P x s row splits fall on gradient boundaries,
+    split z writes slab z, and the batched reduction adds slabs [p s, (p + 1) s) into gradient p. Per gradient these launches were
+    9-144 tiles x 3-21 splits (350-500 TF/s over the classes)."""
     P = len(members)
     d0, x0 = members[0][3][0]
-    N, K, M, dtid, dev = d0.shape[1], x0.shape[1], d0.shape[0], _dt(d0), d0.device
-    pa = (ctypes.c_void_p * P)(*[m[3][0][0].data_ptr() for m in members])
-    pb = (ctypes.c_void_p * P)(*[m[3][0][1].data_ptr() for m in members])
-    pm = (ctypes.c_int * P)(*[M] * P)
-    nmt_p = (M + 63) // 64
-    choice = _tn_batch_choice(P, pa, pb, pm, N, K, nmt_p, dev, dtid)
+    N, K, dtid, dev = d0.shape[1], x0.shape[1], _dt(d0), d0.device
+    pairs = [pr for m in members for pr in m[3]]             # member after member: every gradient's segments stay together
+    n = len(pairs)
+    pa = (ctypes.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    pb = (ctypes.c_void_p * n)(*[x.data_ptr() for _, x in pairs])
+    pm = (ctypes.c_int * n)(*[d.shape[0] for d, _ in pairs])
+    nmt_p = sum((d.shape[0] + 63) // 64 for d, _ in members[0][3])
+    choice = _tn_batch_choice(P, n, pa, pb, pm, N, K, nmt_p, dev, dtid)
     if choice is None or not _parts_ok(choice[0], P * nmt_p, P * choice[1]):
         return False
     variant, sp = choice
@@ -817,7 +824,7 @@ def _flush_batch(members, entries):
             _KEEPALIVE.append(buf)
         buf = _PART_BUFS[key] = torch.empty((tot * (N * K + N),), dtype=torch.float32, device=dev)
     cpart = buf.data_ptr() + 4 * tot * N * K
-    _lib.call("vlni_gemm_tn_h16_grouped_part", dtid, P, pa, pb, pm, N, K, buf.data_ptr(), N * K, N, K, cpart, tot, variant, _st())
+    _lib.call("vlni_gemm_tn_h16_grouped_part", dtid, n, pa, pb, pm, N, K, buf.data_ptr(), N * K, N, K, cpart, tot, variant, _st())
     for i, (_, wv, bv, _) in enumerate(members):
         entries.append((wv.data_ptr(), buf.data_ptr() + 4 * i * sp * N * K, N * K // 4, N * K // 4, sp))
         entries.append((bv.data_ptr(), cpart + 4 * i * sp * N, N // 4, N // 4, sp))
@@ -838,13 +845,17 @@ def flush_wgrads(lo=None, hi=None):
         for it in items:
             _, wv, bv, segs = it
             d, x = segs[0]
-            if len(segs) == 1 and wv.is_contiguous() and bv.is_contiguous() and d.shape[1] % 4 == 0 and d.shape[0] >= 256:
-                groups.setdefault((d.shape[1], x.shape[1], d.shape[0], d.dtype), []).append(it)
+            # several segments per gradient (the steps of an episode): only the small outputs, whose own launches need 14-21 row
+            # splits to fill the chip; the 2304- and 3072-wide ones already run at 1.2-1.3 PFLOP/s on their own
+            if 2 * len(segs) <= TN_MAXSEG and wv.is_contiguous() and bv.is_contiguous() and d.shape[1] % 4 == 0 \
+                    and sum(dd.shape[0] for dd, _ in segs) >= 256 and (len(segs) == 1 or d.shape[1] * x.shape[1] <= 768 * 768 or BATCH_WGRADS == 2):
+                groups.setdefault((d.shape[1], x.shape[1], tuple(dd.shape[0] for dd, _ in segs), d.dtype), []).append(it)
             else:
                 rest.append(it)
-        for members in groups.values():
-            for c in range(0, len(members), 16):
-                chunk = members[c:c + 16]
+        for (_, _, lens, _), members in groups.items():
+            per = max(2, TN_MAXSEG // len(lens))                     # gradients per launch: their segments must fit one launch
+            for c in range(0, len(members), per):
+                chunk = members[c:c + per]
                 if len(chunk) >= 2 and _flush_batch(chunk, entries):
                     dev = chunk[0][1].device
                 else:
