@@ -42,7 +42,10 @@ int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, vo
                  const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32, void* stream);
 
 /* Same with an explicit kernel variant: 0 auto, 1 register-staged 32 KiB, 2 / 3 LDS-DMA 2- / 3-stage, 4 / 5 the same with 8 waves,
-   6 / 7 / 8 LDS-DMA large tiles 256x128 / 256x256 / 128x256, 9 / 10 / 11 small tiles 64x128 / 128x64 / 64x64, 12 / 13 tiles 192x128 / 128x192 (two blocks per CU); results identical.
+   6 / 7 / 8 LDS-DMA large tiles 256x128 / 256x256 / 128x256, 9 / 10 / 11 small tiles 64x128 / 128x64 / 64x64, 12 / 13 tiles 192x128 / 128x192
+   (two blocks per CU), 14 persistent 128x128 (register epilogue): results identical bit for bit. 15 = persistent 256x256 "8-phase"
+   kernel on v_mfma_f32_16x16x32 for long launches (16-bit types, K % 128 == 0; other cases run variant 14): same products summed in
+   another tree, i.e. equal to the others within float32 rounding of the accumulator.
    variant + 16: B is given as [K,N] row-major with ldb >= N, i.e. the forward weight W[out,in] itself as the dgrad operand
    (dX = dY * W) - no transposed weight copy; bf16 only, K % 64 == 0, K >= 192, N % 8 == 0, pipelines 2..5. */
 int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
@@ -51,9 +54,12 @@ int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, 
                    float drop_p, unsigned drop_seed /* dropout after act, before residual; mask = f(seed, row*N+col) */,
                    void* stream);
 
-/* Diagnostic only: per-block cycle sums (8 x uint64 x <= 768 blocks: DMA wait, barrier, DMA issue, reads + MFMA, epilogue, k-steps,
-   kernel, cold start) of the last launch of the persistent GEMM's stamped build (environment VLNI_PK_HACK=4), tools/gemm_stamps.py */
+#ifdef VLNI_DIAG
+/* Diagnostic builds only (VLNI_DIAG=1 python -m vln_imagine_amd.build; not in the default library): per-block cycle sums (8 x uint64 x
+   <= 768 blocks: DMA wait, barrier, DMA issue, reads + MFMA, epilogue, k-steps, kernel, cold start) of the last launch of the persistent
+   GEMM's stamped build (environment VLNI_PK_HACK=4), tools/gemm_stamps.py */
 int vlni_debug_pk_stamps(void* host_dst, int bytes);
+#endif
 
 /* Two problems (same N, K, epilogue kind; arrays of 2) in ONE launch: the language / vision streams of a cross-modal layer. */
 int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* lda, const void* const* B, const long* ldb, void* const* C,

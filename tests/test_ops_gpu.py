@@ -477,10 +477,22 @@ def test_wgrad_partials_reject_register_staged_kernel(ops):
                   2, 5, torch.cuda.current_stream().cuda_stream)
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32, 33])
+def _same(x, y, variant):
+    """Every pipeline on v_mfma_32x32x16 sums the same products in the same tree: equal bit for bit. Variant 15 (the 256 x 256 8-phase
+    kernel on v_mfma_16x16x32) sums them in another tree: equal to float32 rounding of the accumulator, i.e. <= 1 ulp of the 16-bit output
+    on a small fraction of the elements (float32 operands never reach it, they run variant 14)."""
+    if variant != 15 or x.dtype == torch.float32:
+        return torch.equal(x, y)
+    xf, yf = x.float(), y.float()
+    ulp = 2.0 ** -7 if x.dtype == torch.bfloat16 else 2.0 ** -10
+    close = bool(((xf - yf).abs() <= ulp * torch.maximum(xf.abs(), yf.abs()) + 1e-6).all())
+    return close and float((xf != yf).float().mean()) < 0.05
+
+
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_gemm_variants_identical(ops, variant):
-    """All GEMM pipelines (register-staged, LDS-DMA 2/3-stage with 4 or 8 waves, large tiles 256x128 / 256x256 / 128x256) give
-    bit-identical results, incl. epilogues and ragged tile edges."""
+    """All GEMM pipelines (register-staged, LDS-DMA 2/3-stage with 4 or 8 waves, large tiles 256x128 / 256x256 / 128x256, persistent)
+    give bit-identical results, incl. epilogues and ragged tile edges; the 8-phase kernel (15) agrees to accumulator rounding."""
     for dtype in (torch.bfloat16, torch.float32):
         for (M, N, K) in ((333, 768, 768), (700, 640, 384)):
             a, b = _rand((M, K), dtype, 31, 0.5), _rand((N, K), dtype, 32, 0.05)
@@ -490,10 +502,10 @@ def test_gemm_variants_identical(ops, variant):
                 out, z = torch.empty((M, N), dtype=dtype, device="cuda"), torch.empty((M, N), dtype=dtype, device="cuda")
                 ops._gemm_call(v, a, b, out, bias, 1, res, z, None, 0, 1.0, 1, False, M, N, K)
                 outs.append((out, z))
-            assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (variant, dtype, M, N, K)
+            assert _same(outs[0][0], outs[1][0], variant) and _same(outs[0][1], outs[1][1], variant), (variant, dtype, M, N, K)
 
 
-@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32, 33])
+@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
 def test_gemm_dual_launch_variants(ops, variant):
     """Two problems in one launch (language + vision stream) == two single launches, for every tile geometry."""
     saved = (ops.AUTOTUNE, ops.GEMM_VARIANTS)
@@ -510,13 +522,13 @@ def test_gemm_dual_launch_variants(ops, variant):
             r0 = torch.empty_like(o0); r1 = torch.empty_like(o1)
             ops._gemm_call(1, a0, b0, r0, bias[0], 0, res[0], None, None, 0, 1.0, 1, False, a0.shape[0], N, K)
             ops._gemm_call(1, a1, b1, r1, bias[1], 0, res[1], None, None, 0, 1.0, 1, False, a1.shape[0], N, K)
-            assert torch.equal(o0, r0) and torch.equal(o1, r1), (variant, dtype)
+            assert _same(o0, r0, variant) and _same(o1, r1, variant), (variant, dtype)
     finally:
         ops.AUTOTUNE, ops.GEMM_VARIANTS = saved
         ops._GEMM_BEST.clear()
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 32, 33])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
 def test_gemm_nn_weight_layout_matches_transposed_copy(ops, variant):
     """dgrad straight from W[out, in] (transposing LDS reads, variant + 16) == the NT kernel on an explicit W^T copy, bit for bit,
     incl. GELU' / residual epilogues, ragged rows and a partial column tile (zero page)."""
@@ -539,11 +551,12 @@ def test_gemm_nn_weight_layout_matches_transposed_copy(ops, variant):
     assert torch.equal(o0, ops.gemm_nt(a0, w0.t().contiguous())) and torch.equal(o1, ops.gemm_nt(a1, ops.KN(w1)))
 
 
-@pytest.mark.parametrize("nn,pk", [(False, 14), (True, 6), (False, 15), (True, 7), (False, 32), (True, 32), (False, 33), (True, 33)])
+@pytest.mark.parametrize("nn,pk", [(False, 14), (True, 6), (False, 15)])
 def test_gemm_persistent_kernel_streams_many_tiles(ops, nn, pk):
     """The persistent kernel (variant 14; 16 + 6 with the weight as [K, N]) at the bench's row counts: > 512 tiles, so every block walks
     several tiles through its two LDS stages (next tile's first k-tile prefetched under the epilogue), two problems per launch, every
-    epilogue kind (bias + GELU + stored pre-activation, GELU' + residual, dropout), ragged last row tile. Bit-identical to variant 1 / 5."""
+    epilogue kind (bias + GELU + stored pre-activation, GELU' + residual, dropout), ragged last row tile. Bit-identical to variant 1 / 5
+    (15, the 256 x 256 8-phase kernel: to accumulator rounding; its k-tile stream runs on across output tiles of BOTH problems)."""
     base = 16 if nn else 0
     ref_v, pk_v = (16 + 5, 16 + pk) if nn else (1, pk)
     K = 768
@@ -579,7 +592,7 @@ def test_gemm_persistent_kernel_streams_many_tiles(ops, nn, pk):
                     ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.NN_VARIANTS = saved
                     ops._GEMM_BEST.clear()
             for x, y in zip(outs[0], outs[1]):
-                assert torch.equal(x, y), (nn, N, kind)
+                assert _same(x, y, pk), (nn, N, kind)
 
 
 @pytest.mark.parametrize("with_bias,p_drop", [(False, 0.0), (True, 0.0), (False, 0.1), (True, 0.1)])

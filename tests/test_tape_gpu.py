@@ -1,0 +1,127 @@
+"""Episode tape (vln_imagine_amd.ops.EpisodeTape, hamt/episode.py:run_episode_taped): step-by-step forward into episode-wide buffers,
+a ghost pass that records the batched autograd graph without kernels, ONE episode-batched backward. Held to the plain step-by-step
+rollout (what the reference agent runs, r2r/agent_cmt.py:498-606 + :814-827) and, with dropout, to the batched pass computed for real
+with the same seeds."""
+import pytest
+import torch
+
+from tests.golden.variants import hamt_variant_setup
+from tests.test_hamt_gpu import build_product
+from vln_imagine_amd import synth
+from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode, run_episode_taped
+
+pytestmark = pytest.mark.gpu
+
+
+def _grads_close(m1, m2, rel, what):
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p.grad is None:
+            assert q.grad is None or float(q.grad.abs().max()) == 0, n
+            continue
+        assert q.grad is not None, n
+        d = (p.grad.float() - q.grad.float()).abs().max().item()
+        assert d <= rel * max(1.0, p.grad.abs().max().item()), (what, n, d)
+
+
+@pytest.mark.parametrize("variant", ["c1_T3_dense", "c1_shipped", "c1_encoder"])
+def test_taped_episode_equals_stepwise_fp32(variant):
+    """float32: logits of every step, loss and every gradient of the taped episode == the step-by-step autograd rollout; the steps'
+    own logits (what a sampling agent reads during the rollout) are the ghost pass's rows."""
+    from vln_imagine_amd import ops
+    cfg, ep = hamt_variant_setup(variant)
+    et = EpisodeTensors(ep, "cuda")
+    m1, m2 = build_product(cfg), build_product(cfg)
+    o1 = run_episode(m1, et, bypass=cfg.bypass_imag_encoder, criterion=ops.cross_entropy_sum)
+    o1["loss"].backward()
+    seen = []
+    o2 = run_episode_taped(m2, et, bypass=cfg.bypass_imag_encoder, criterion=ops.cross_entropy_sum,
+                           on_step=lambda t, lg, st: seen.append((t, lg.clone(), st.clone())))
+    o2["loss"].backward()
+    assert abs(o1["loss"].item() - o2["loss"].item()) < 1e-5
+    assert [t for t, _, _ in seen] == list(range(ep.T))
+    for t in range(ep.T):
+        a, b = o1["logits"][t], o2["logits"][t]
+        fin = torch.isfinite(a)
+        assert (torch.isfinite(b) == fin).all() and (a[fin] - b[fin]).abs().max().item() < 2e-5
+        assert torch.equal(seen[t][1], o2["logits"][t]), t                     # the step's logits ARE the batched tensor's rows
+        assert (seen[t][2] - o1["states"][t]).abs().max().item() < 2e-5         # states = txt[:, 0] * hist[:, 0] (model_HAMT.py:86)
+        assert (o1["hist"][t] - o2["hist"][t]).abs().max().item() < 1e-5
+    _grads_close(m1, m2, 3e-5, variant)
+
+
+def test_tape_is_reused_across_episodes_and_rejects_other_shapes():
+    """A second episode on the same tape writes the same buffers (what a captured step graph replays into); an episode of another
+    shape through the same tape re-allocates at step 0 instead of silently mixing shapes."""
+    from vln_imagine_amd import ops
+    cfg, ep = hamt_variant_setup("c1_T3_dense")
+    et = EpisodeTensors(ep, "cuda")
+    m = build_product(cfg)
+    tape = ops.EpisodeTape(ep.T)
+    o = run_episode_taped(m, et, tape=tape)
+    o["loss"].backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    ptrs = [b.data_ptr() for b in tape.bufs["visual"]]
+    m.zero_grad()
+    o = run_episode_taped(m, et, tape=tape)
+    o["loss"].backward()
+    assert ptrs == [b.data_ptr() for b in tape.bufs["visual"]]
+    for n, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.allclose(p.grad, g1[n], rtol=1e-5, atol=1e-7), n           # (embedding / bias gradients are float atomics: order varies)
+    ep2 = synth.HamtEpisode(tag="other", B=ep.B + 1, L=ep.L, V=ep.V, I=ep.I, T=ep.T)
+    rows0 = tape.bufs["visual"][0].shape[0]
+    o = run_episode_taped(m, EpisodeTensors(ep2, "cuda"), tape=tape)
+    assert torch.isfinite(o["loss"]).item() and tape.bufs["visual"][0].shape[0] == rows0 // ep.B * (ep.B + 1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_taped_episode_with_dropout_equals_the_batched_pass_computed_with_its_seeds(dtype):
+    """train(): every step's launch draws the window of the episode-wide mask that belongs to its rows (seed shifted by t x elements x
+    hash multiplier), so (a) the batched call COMPUTED with the unshifted seeds reproduces the steps' logits, and (b) the ghost pass's
+    backward - which regenerates masks from the unshifted seeds over T x B samples - gives that computed pass's gradients."""
+    from vln_imagine_amd import ops
+    cfg, ep = hamt_variant_setup("c1_T3_dense")
+    et = EpisodeTensors(ep, "cuda")
+    m1, m2 = build_product(cfg, dtype).train(), build_product(cfg, dtype).train()
+    torch.manual_seed(7); ops.reseed(1234)            # torch's generator: the dropouts outside the tape (language / imagine / aux head)
+    o1 = run_episode_taped(m1, et, criterion=ops.cross_entropy_sum)
+    o1["loss"].backward()
+    torch.manual_seed(7); ops.reseed(1234)
+    o2 = run_episode_taped(m2, et, criterion=ops.cross_entropy_sum, ghost_compute=True)
+    o2["loss"].backward()
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for t in range(ep.T):
+        a, b, c = o1["logits"][t], o2["logits"][t], o2["step_logits"][t]
+        fin = torch.isfinite(a)
+        assert (a[fin] - b[fin]).abs().max().item() < tol, t
+        assert (c[fin] - b[fin]).abs().max().item() < tol, t            # recorded step (shifted seed) vs computed batch (unshifted seed)
+    assert abs(o1["loss"].item() - o2["loss"].item()) < (1e-5 if dtype == torch.float32 else 2e-3)
+    if dtype == torch.float32:
+        _grads_close(m1, m2, 5e-5, "dropout")
+    # and dropout is really on: an eval() run differs
+    m3 = build_product(cfg, dtype)
+    torch.manual_seed(7); ops.reseed(1234)
+    o3 = run_episode_taped(m3, et, criterion=ops.cross_entropy_sum)
+    assert abs(o3["loss"].item() - o1["loss"].item()) > 1e-3
+
+
+def test_taped_bf16_full_width_tracks_the_stepwise_bf16_run():
+    """bfloat16 at the bench's layer width: the taped episode and the step-by-step autograd rollout differ by kernel choice and by
+    the padded history keys only."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.config import HamtConfig
+    cfg = HamtConfig(num_l_layers=2, num_x_layers=2, num_h_pano_layers=1)
+    ep = synth.HamtEpisode(tag="tape16", B=16, L=80, V=37, I=6, T=4)
+    et = EpisodeTensors(ep, "cuda")
+    m1, m2 = build_product(cfg, torch.bfloat16), build_product(cfg, torch.bfloat16)
+    o1 = run_episode(m1, et, criterion=ops.cross_entropy_sum)
+    o1["loss"].backward()
+    o2 = run_episode_taped(m2, et, criterion=ops.cross_entropy_sum)
+    o2["loss"].backward()
+    assert abs(o1["loss"].item() - o2["loss"].item()) < 5e-3
+    num = den = 0.0
+    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
+        if p.grad is not None:
+            num += float((p.grad.double() - q.grad.double()).pow(2).sum())
+            den += float(p.grad.double().pow(2).sum())
+    assert (num / den) ** 0.5 < 0.03, (num / den) ** 0.5

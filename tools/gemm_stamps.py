@@ -1,6 +1,7 @@
 """Where a k-step of the persistent GEMM spends its cycles: runs the stamped diagnostic build (VLNI_PK_HACK=4, s_memtime around the
 phases of wave 0 of every block; cdna_hip_programming.md section 7 'In-kernel stamps') on the dual-problem launches of a step and prints
 per-phase cycles per k-step (median over blocks). The stamped build's own run time is not a measurement (its fences forbid overlaps).
+Needs the diagnostic library: VLNI_DIAG=1 python -m vln_imagine_amd.build --force
 usage: VLNI_PK_HACK=4 python tools/gemm_stamps.py"""
 import ctypes
 import os

@@ -11,8 +11,9 @@ import torch  # noqa: E402
 from vln_imagine_amd import ops  # noqa: E402
 
 dt = torch.bfloat16
-M0, M1 = 64 * 86, 64 * 40
-NT_VARIANTS = tuple(int(v) for v in os.environ.get("NT_VARIANTS", "4,5,12,13,14").split(","))
+T = int(os.environ.get("T", "1"))                       # T > 1: the row counts of T time-batched / episode-batched steps
+M0, M1 = T * 64 * 86, T * 64 * 40
+NT_VARIANTS = tuple(int(v) for v in os.environ.get("NT_VARIANTS", "4,5,12,13,14,15").split(","))
 NN_VARIANTS = tuple(int(v) for v in os.environ.get("NN_VARIANTS", "4,5,6").split(","))
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
 
@@ -59,12 +60,24 @@ def run(nn, N, K, kind):
         ops.GEMM_VARIANTS, ops.NN_VARIANTS = saved
         ops._GEMM_BEST.clear()
     fl = 2.0 * (M0 + M1) * N * K
+    extra = ""
+    if nn:                                   # the same dgrad through the NT kernels on a W^T copy (what launches of >= NT_LONG_ROWS rows use)
+        wt = (w[0].t().contiguous(), w[1].t().contiguous())
+        try:
+            for v in (14, 15):
+                ops.GEMM_VARIANTS = (v,)
+                ops._GEMM_BEST.clear()
+                t = min(time_call(lambda: ops.gemm_nt2(a, wt, **kw)) for _ in range(ROUNDS))
+                extra += f" | W^T v{v}:{t:6.1f}us/{fl / t / 1e6:4.0f}TF"
+        finally:
+            ops.GEMM_VARIANTS = saved[0]
+            ops._GEMM_BEST.clear()
     acat = torch.cat(a, 0)
     wm = w[0] if nn else w[0].t()
     us_lib = time_call(lambda: torch.matmul(acat, wm))
     tag = "NN" if nn else "NT"
     print(f"{tag} rows {M0}+{M1} N={N:4d} K={K:4d} {kind:5s} " + " ".join(f"v{v}:{best[v]:6.1f}us/{fl / best[v] / 1e6:4.0f}TF" for v in variants)
-          + f" | hipblaslt(plain) {us_lib:6.1f}us/{fl / us_lib / 1e6:4.0f}TF", flush=True)
+          + extra + f" | hipblaslt(plain) {us_lib:6.1f}us/{fl / us_lib / 1e6:4.0f}TF", flush=True)
     return fl, min(best.values()), {v: best[v] for v in variants}
 
 

@@ -11,6 +11,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvlni.so")
 SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "attention.hip", "graphmap.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+if os.environ.get("VLNI_DIAG") == "1":       # stamped / timing-only kernel builds + vlni_debug_pk_stamps (tools/gemm_stamps.py); never the default
+    FLAGS.append("-DVLNI_DIAG")
 
 
 def _stale(target, deps):

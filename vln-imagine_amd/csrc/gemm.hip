@@ -36,20 +36,24 @@
 #define VLNI_H16 __bf16
 #define VLNI_H16_ID VLNI_BF16
 #define VLNI_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define VLNI_MFMA16S(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #include "gemm_impl.inc"
 #undef VLNI_NS
 #undef VLNI_H16
 #undef VLNI_H16_ID
 #undef VLNI_MFMA16
+#undef VLNI_MFMA16S
 #define VLNI_NS k_f16
 #define VLNI_H16 _Float16
 #define VLNI_H16_ID VLNI_F16
 #define VLNI_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define VLNI_MFMA16S(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 #include "gemm_impl.inc"
 #undef VLNI_NS
 #undef VLNI_H16
 #undef VLNI_H16_ID
 #undef VLNI_MFMA16
+#undef VLNI_MFMA16S
 
 // ---- C-ABI: dtype 0 (float32) and 1 (bfloat16) go to the bfloat16 instance, 2 (float16) to the float16 instance -----------------
 extern "C" int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
@@ -76,7 +80,9 @@ extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, l
   return vlni_gemm_nt_v(dtype, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, preact, ldp, dact_src, ldd, dact, alpha, split_k,
                         atomic_f32, 0, 0.f, 0u, stream);
 }
+#ifdef VLNI_DIAG
 extern "C" int vlni_debug_pk_stamps(void* host_dst, int bytes) { return k_bf16::vlni_debug_pk_stamps(host_dst, bytes); }
+#endif
 extern "C" int vlni_reduce_parts(const void* table, int n_entries, int n_blocks, void* stream) {
   return k_bf16::vlni_reduce_parts(table, n_entries, n_blocks, stream);
 }

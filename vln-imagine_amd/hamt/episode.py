@@ -33,6 +33,14 @@ class EpisodeTensors:
             n = max(lens)
             m = torch.arange(n)[None, :] < torch.tensor(lens)[:, None]
             self.hist_masks.append(m.to(dev))
+        self._full = {}
+
+    def full(self, k):
+        """Step inputs `k` of all T steps as ONE [T*B, ...] tensor (step t = rows [t B, (t + 1) B)), built once."""
+        v = self._full.get(k)
+        if v is None:
+            v = self._full[k] = torch.cat([s[k] for s in self.steps], 0).contiguous()
+        return v
 
 
 def ce_sum(logits, target):
@@ -122,3 +130,79 @@ def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2,
         loss = loss + cosine_weight * aux
     return {"loss": loss, "ml_loss": ml_loss, "aux": aux, "logits": list(logits.view(T, B, -1)), "txt_embeds": txt,
             "imagine_embeds": img, "hist": list(hist_steps)}
+
+
+def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
+                      ghost_compute=False):
+    """Step-by-step FORWARD - the call pattern a sampled rollout needs: step t + 1's observation may depend on the action chosen from step
+    t's logits (`on_step(t, logits, states)`, r2r/agent_cmt.py:498-606) - and ONE episode-batched BACKWARD (vln_imagine_amd.ops.EpisodeTape):
+    the T `visual` / `history` calls write their activations into slices of episode-wide buffers, a ghost pass of the same model code
+    over the T x B samples records the autograd graph without launching a kernel, and loss.backward() then runs on T x longer launches.
+    Valid because no transformer output of step t enters step t + 1's input: history tokens are re-encoded from features
+    (vilmodel_cmt.py:576-618, 1056-1205). Every step sees the history padded to T entries ([CLS, h_0 .. h_{t-1}, 0 ..] with the mask of
+    model_HAMT.py:62-63); logits, loss and gradients equal run_episode's to rounding (tests/test_tape_gpu.py).
+    ghost_compute=True (tests): the batched pass COMPUTES with the recorded dropout seeds instead of reusing the steps' buffers."""
+    from vln_imagine_amd import ops
+    ep, B, T = et.ep, et.B, et.T
+    dev = et.txt_ids.device
+    tape = tape if tape is not None else ops.EpisodeTape(T)
+    assert tape.T >= T
+    tape.reset()
+    txt = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
+    img = model("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None if bypass else et.imagine_masks)
+    aux = None
+    if use_aux:
+        aux, img = model("align_with_contrastive_loss", align_txt_embeds=txt, txt_masks=et.txt_masks, align_imagine_embeds=img,
+                         imagine_masks=et.imagine_masks, sub_instr_segs=ep.sub_instr_segs,
+                         sub_instr_imag_flag=ep.sub_instr_imag_flag, noun_phrase_segs=ep.noun_phrase_segs)
+    cls = model("history").expand(B, -1)                                                   # [B, H]
+    H, dt = cls.shape[-1], cls.dtype
+    ar = torch.arange(T, device=dev)
+    lens = torch.tensor(ep.hist_lens[:T], device=dev)                                       # [T, B] history length before step t (model_HAMT.py:62-63)
+    valid = ar[None, None, :] < lens[:, :, None]                                            # [step t, sample b, entry j]
+    hm_full = valid.reshape(T * B, T).contiguous()
+    # history inputs of all steps: sample (t, b) holds [CLS, h_0 .. h_{t-1}, 0 ...]. Entries beyond t are never written, so the buffer is
+    # zeroed once per tape; the recorded steps read slices of it, the ghost pass an autograd expression with the same values
+    hb = getattr(tape, "_hist_buf", None)
+    if hb is None or hb.shape != (T, B, T, H) or hb.dtype != dt:
+        hb = tape._hist_buf = torch.zeros((T, B, T, H), dtype=dt, device=dev)
+    with torch.no_grad():
+        hb[:, :, 0] = cls
+    f = et.full
+    step_logits = []
+    for t in range(T):
+        sl = slice(t * B, (t + 1) * B)
+        with tape.record("visual", t):
+            lg, txt_o, hist_o, ob_o = model(
+                "visual", txt_embeds=txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm_full[sl],
+                ob_img_feats=f("ob_img_feats")[sl], ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
+                ob_masks=f("ob_masks")[sl], imagine_embeds=img, imagine_masks=et.imagine_masks)
+        step_logits.append(lg)
+        if on_step is not None:
+            on_step(t, lg, txt_o[:, 0] * hist_o[:, 0])
+        with tape.record("history", t):
+            h = model("history", hist_img_feats=f("hist_img_feats")[sl], hist_ang_feats=f("hist_ang_feats")[sl],
+                      ob_step_ids=et.step_ids[t], hist_pano_img_feats=f("hist_pano_img_feats")[sl],
+                      hist_pano_ang_feats=f("hist_pano_ang_feats")[sl])
+        if t + 1 < T:
+            with torch.no_grad():
+                hb[t + 1:, :, t + 1] = h * valid[t + 1:, :, t + 1, None].to(h.dtype)
+    # ---- ghost pass: the same two calls on the T x B samples; no kernels, only the autograd graph over the filled buffers ----
+    with tape.ghost("history", compute=ghost_compute):
+        h_all = model("history", hist_img_feats=f("hist_img_feats"), hist_ang_feats=f("hist_ang_feats"),
+                      ob_step_ids=ar.repeat_interleave(B), hist_pano_img_feats=f("hist_pano_img_feats"),
+                      hist_pano_ang_feats=f("hist_pano_ang_feats"))
+    prefix = torch.cat([cls.to(h_all.dtype).unsqueeze(0), h_all.view(T, B, H)[:T - 1]], 0)    # entries 0 .. T-1 as [entry, B, H]
+    hist = prefix.permute(1, 0, 2).unsqueeze(0) * valid.to(h_all.dtype)[:, :, :, None]        # [T, B, T, H], zeros beyond the valid entries
+    rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+    with tape.ghost("visual", compute=ghost_compute):
+        logits, txt_o, hist_o, ob_o = model(
+            "visual", txt_embeds=rep(txt), txt_masks=rep(et.txt_masks), hist_embeds=hist.reshape(T * B, T, H), hist_masks=hm_full,
+            ob_img_feats=f("ob_img_feats"), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
+            ob_masks=f("ob_masks"), imagine_embeds=rep(img), imagine_masks=rep(et.imagine_masks))
+    ml_loss = criterion(logits, f("target"))
+    loss = ml_loss * train_ml / B
+    if use_aux and torch.is_tensor(aux):
+        loss = loss + cosine_weight * aux
+    return {"loss": loss, "ml_loss": ml_loss, "aux": aux, "logits": list(logits.view(T, B, -1)), "step_logits": step_logits,
+            "txt_embeds": txt, "imagine_embeds": img, "hist": list(h_all.view(T, B, H)), "tape": tape}

@@ -236,7 +236,7 @@ class ImageEmbeddings(_FeatEmbed):
         if nav_types is not None:
             srcs.append((self.nav_type_embedding.weight, "gather", nav_types.reshape(-1).contiguous()))
         y = ops.sum_layer_norm(srcs, self.layer_norm.weight, self.layer_norm.bias, B * S, dt, HID_EPS)
-        return F.dropout(y.view(B, S, -1), self.p_drop, self.training)
+        return ops.dropout(y.view(B, S, -1), self.p_drop, self.training)
 
 
 class HistoryEmbeddings(_FeatEmbed):
@@ -278,13 +278,13 @@ class HistoryEmbeddings(_FeatEmbed):
         if self.pano_encoder is not None:                 # :603-614, pano mask is all ones -> no key mask
             Bp, P, _ = pano_img.shape
             pi, pa = self._feat(pano_img, pano_ang, "pano_", dt)
-            pe = F.dropout((pi + pa).view(Bp, P, -1), self.p_drop, self.training)
+            pe = ops.dropout((pi + pa).view(Bp, P, -1), self.p_drop, self.training)
             pm = ops.seq_mean(self.pano_encoder(pe, None))
             if len(srcs) == 4:                            # the sum kernel takes 4 sources: fold the type row into the pano mean
                 pm = pm + self.type_embedding.weight.to(pm.dtype)
                 srcs = [srcs[0], srcs[1], srcs[3]]
             srcs.append((pm, "dense", None))
-        return F.dropout(ops.sum_layer_norm(srcs, g, b, B, dt, HID_EPS), self.p_drop, self.training)
+        return ops.dropout(ops.sum_layer_norm(srcs, g, b, B, dt, HID_EPS), self.p_drop, self.training)
 
 
 class BypassImagineEmbeddings(nn.Module):
@@ -455,7 +455,7 @@ class NextActionPrediction(nn.Module):
     def forward(self, x, neg_inf_mask):
         n = self.net
         h = ops.layer_norm(ops.linear(x, n[0].weight, n[0].bias, act=2), n[2].weight, n[2].bias, HID_EPS)
-        return ops.row_dot(n[3](h), n[4].weight, n[4].bias, neg_inf_mask)
+        return ops.row_dot(ops.dropout(h, n[3].p, n[3].training), n[4].weight, n[4].bias, neg_inf_mask)
 
 
 def _cfg(config):

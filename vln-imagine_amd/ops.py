@@ -58,6 +58,138 @@ def _rows(t):
 
 
 # =====================================================================================
+#  episode tape: step-by-step forward, ONE episode-batched backward
+# =====================================================================================
+# The reference agent rolls an episode out step by step (the action taken at step t decides the observation of step t + 1) and runs ONE
+# backward at the end (r2r/agent_cmt.py:814-827). No output of a `visual` / `history` call feeds a later call's transformer input (history
+# tokens are re-encoded from features, vilmodel_cmt.py:1056-1205), so the T calls are the T batch slices of one call on T x B samples:
+#   * record(key, t):  the step's forward runs under no_grad; every activation an operator allocates is slice t of an episode-wide
+#                      buffer (rows [t B S, (t + 1) B S) of the tensor the batched call would have produced);
+#   * ghost(key):      the SAME model code is called once on the T x B inputs; the operators launch nothing and hand out the filled
+#                      buffers, so autograd records the batched graph at no kernel cost;
+#   * backward:        runs on 6 x longer launches (M ~ 48 k rows: the 256 x 256 GEMM kernel's shapes, one attention / LayerNorm launch per
+#                      layer instead of T).
+# Dropout: masks are hash(seed, element index) with the sample outermost in every index, and the hash starts with idx * K + seed, so the
+# step-t launch of a tensor of E elements per step uses seed + t E K: exactly the window of the batched tensor's mask that the batched
+# backward regenerates from the unshifted seed. Seeds are drawn once per operator call and replayed for the later steps and the ghost pass.
+_TAPE = None
+_HASH_MUL = 0x9E3779B1
+
+
+class EpisodeTape:
+    def __init__(self, T):
+        self.T = T
+        self.bufs, self.seeds, self.steps = {}, {}, {}
+        self.key = self.mode = None
+        self.t = self.i = self.si = 0
+
+    def reset(self):
+        """New episode: fresh dropout seeds; the buffers are kept (a captured step graph replays into the same addresses)."""
+        self.seeds, self.steps = {}, {}
+
+    def _enter(self, key, mode, t):
+        global _TAPE
+        assert _TAPE is None, "episode tapes do not nest"
+        self.key, self.mode, self.t, self.i, self.si = key, mode, t, 0, 0
+        self.bufs.setdefault(key, [])
+        self.seeds.setdefault(key, [])
+        _TAPE = self
+
+    def _exit(self):
+        global _TAPE
+        if self.mode == "record":
+            self.steps[self.key] = max(self.steps.get(self.key, 0), self.t + 1)
+        n_alloc, n_seed = self.i, self.si
+        _TAPE = None
+        self.key = self.mode = None
+        return n_alloc, n_seed
+
+    def record(self, key, t):
+        return _TapeCtx(self, key, "record", t)
+
+    def ghost(self, key, compute=False):
+        """compute=True: the batched call computes for real with the recorded dropout seeds (the reference the tests hold the tape to)."""
+        return _TapeCtx(self, key, "compute" if compute else "ghost", 0)
+
+    def take(self, shape, dtype, device):
+        if self.mode == "compute":
+            return torch.empty(shape, dtype=dtype, device=device)
+        bufs, i = self.bufs[self.key], self.i
+        self.i += 1
+        if self.mode == "record":
+            full = (self.T * shape[0],) + tuple(shape[1:])
+            if i == len(bufs):
+                assert self.t == 0, f"tape {self.key!r}: step {self.t} allocates more activations than step 0"
+                bufs.append(torch.empty(full, dtype=dtype, device=device))
+            b = bufs[i]
+            if tuple(b.shape) != full or b.dtype != dtype:
+                if self.t != 0:
+                    raise RuntimeError(f"tape {self.key!r}: allocation {i} of step {self.t} is {tuple(shape)} {dtype}, step 0 had "
+                                       f"{(b.shape[0] // self.T,) + tuple(b.shape[1:])} {b.dtype} (the steps of a tape must have one shape)")
+                _KEEPALIVE.append(b)                    # an older capture may still write here
+                b = bufs[i] = torch.empty(full, dtype=dtype, device=device)
+            return b[self.t * shape[0]:(self.t + 1) * shape[0]]
+        n = self.steps.get(self.key, 0)
+        assert i < len(bufs) and n > 0, f"tape {self.key!r}: the ghost pass allocates activation {i}, the steps recorded {len(bufs)}"
+        b = bufs[i]
+        per = b.shape[0] // self.T
+        if tuple(shape) != (n * per,) + tuple(b.shape[1:]) or b.dtype != dtype:
+            raise RuntimeError(f"tape {self.key!r}: ghost allocation {i} is {tuple(shape)} {dtype}, the {n} recorded steps hold "
+                               f"{(n * per,) + tuple(b.shape[1:])} {b.dtype}")
+        return b[:n * per]
+
+    def seed(self, n):
+        seeds, si = self.seeds[self.key], self.si
+        self.si += 1
+        if self.mode == "record" and self.t == 0:
+            assert si == len(seeds)
+            seeds.append(next_seeds(n))
+        return seeds[si]
+
+
+class _TapeCtx:
+    def __init__(self, tape, key, mode, t):
+        self.a = (tape, key, mode, t)
+        self.ng = torch.no_grad() if mode == "record" else None
+
+    def __enter__(self):
+        tape, key, mode, t = self.a
+        tape._enter(key, mode, t)
+        if self.ng is not None:
+            self.ng.__enter__()
+        return tape
+
+    def __exit__(self, *exc):
+        tape = self.a[0]
+        if self.ng is not None:
+            self.ng.__exit__(*exc)
+        n_alloc, n_seed = tape._exit()
+        if exc[0] is None and self.a[2] != "compute":
+            assert n_alloc == len(tape.bufs[self.a[1]]) and n_seed == len(tape.seeds[self.a[1]]), \
+                f"tape {self.a[1]!r}: {self.a[2]} pass made {n_alloc} allocations / {n_seed} seed draws, step 0 made " \
+                f"{len(tape.bufs[self.a[1]])} / {len(tape.seeds[self.a[1]])}"
+        return False
+
+
+def _new(shape, dtype, device):
+    """Activation buffer of a FORWARD operator: plain torch.empty, or the episode tape's slice / whole buffer."""
+    if _TAPE is None:
+        return torch.empty(shape, dtype=dtype, device=device)
+    return _TAPE.take(tuple(shape), dtype, device)
+
+
+def _ghost():
+    return _TAPE is not None and _TAPE.mode == "ghost"
+
+
+def _shift(seed, step_elems):
+    """Dropout seed of a step's launch inside a recording tape (see above); step_elems = elements of the masked tensor per step."""
+    if _TAPE is None or _TAPE.mode != "record" or _TAPE.t == 0:
+        return seed
+    return (seed + _TAPE.t * step_elems * _HASH_MUL) & 0xFFFFFFFF
+
+
+# =====================================================================================
 #  raw kernel wrappers (no autograd)
 # =====================================================================================
 # Per-shape kernel choice: the GEMM pipelines (register-staged 4 blocks/CU, LDS-DMA 2-/3-stage with 4 or 8 waves on 128x128
@@ -65,9 +197,16 @@ def _rows(t):
 # count fills 256 CUs and on how many operand bytes each CU pulls per output. The first call of a shape
 # times each once with HIP events (a few hundred microseconds) and the winner is cached for the life of the process.
 AUTOTUNE = True
-GEMM_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)   # 15 / 32 (persistent ring of 32-deep half-steps, 4 / 5 slots) exist and
-#                 are tested bit-identical, but lost 8-12 % to 14 on every step shape (tools/gemm_step_probe.py): not tried by the autotune
+GEMM_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)
+P8_VARIANT = 15          # 256 x 256 "8-phase" persistent kernel (v_mfma_16x16x32, one block per CU): tried for long launches only
+P8_MIN_ROWS = int(os.environ.get("VLNI_P8_MIN_ROWS", "6144"))
 _GEMM_BEST = {}
+
+
+def _nt_variants(rows, K, dtype):
+    if dtype in H16 and rows >= P8_MIN_ROWS and K % 128 == 0 and P8_VARIANT not in GEMM_VARIANTS and len(GEMM_VARIANTS) > 1:
+        return GEMM_VARIANTS + (P8_VARIANT,)
+    return GEMM_VARIANTS
 
 
 class KN:
@@ -83,14 +222,19 @@ NN_DGRAD = os.environ.get("VLNI_NN_DGRAD", "1") == "1"    # bf16 dgrad straight 
                          # shadows to rebuild after every optimizer step and half the shadow memory. Same-box A/B on the bench step
                          # (3 pairs): 37.5-37.8 ms vs 38.1 ms with NT kernels on W^T copies. (Before the LDS-DMA of that kernel was
                          # issued as asm it was the slower choice: the compiler serialised its copies with the reads.)
-NN_VARIANTS = (2, 3, 4, 5, 6)          # 7 / 32: the ring forms of the [K,N] kernel (see GEMM_VARIANTS)
+NN_VARIANTS = (2, 3, 4, 5, 6)
 NN_MIN_ROWS = int(os.environ.get("VLNI_NN_MIN_ROWS", "4096"))   # below this the small-tile NT pipelines on a W^T copy win (DUET's map / viewpoint
                                                                 # streams: 25.0 vs 26.0 ms per step with every dgrad on the NN kernel)
 
 
+NT_LONG_ROWS = int(os.environ.get("VLNI_NT_LONG_ROWS", "16384"))   # episode-batched dgrad launches (30-50 k rows): the 256 x 256 8-phase NT kernel
+                                                                   # on the W^T copy beats the transposing-read kernels there
+
+
 class WT:
     """The dgrad operand of a (possibly row-packed) weight, resolved by gemm_nt / gemm_nt2 once the row count of the launch is known:
-    the weight itself as [K, N] (KN, transposing-read kernel) for long launches, the maintained W^T copy for short ones."""
+    the weight itself as [K, N] (KN, transposing-read kernel) for step-long launches, the maintained W^T copy for short ones and for
+    episode-long ones (NT_LONG_ROWS)."""
     __slots__ = ("params", "dtype")
 
     def __init__(self, params, dtype):
@@ -101,7 +245,7 @@ class WT:
         return self.params[0].shape[1]
 
     def resolve(self, rows):
-        if rows >= NN_MIN_ROWS:
+        if NN_MIN_ROWS <= rows < NT_LONG_ROWS:
             return KN(SHADOWS.get(self.params, self.dtype, False))
         return SHADOWS.get(self.params, self.dtype, True)
 
@@ -129,9 +273,13 @@ def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_s
         N = b.shape[0]
         assert b.shape[1] == K and a.dtype == b.dtype and a.stride(1) == 1 and b.stride(1) == 1
     if out is None:
-        out = torch.empty((M, N), dtype=torch.float32 if atomic else a.dtype, device=a.device)
+        out = _new((M, N), torch.float32 if atomic else a.dtype, a.device)
+    if _ghost():
+        return out
     if drop is not None and drop[0] <= 0.0:
         drop = None
+    if drop is not None:
+        drop = (drop[0], _shift(drop[1], M * N))
     args = (a, b, out, bias, act, residual, preact, dact_src, dact, alpha, split_k, atomic, M, N, K, drop)
     variant = 21 if kn else 0
     if AUTOTUNE and not atomic and M >= 512:
@@ -141,7 +289,7 @@ def gemm_nt(a, b, out=None, bias=None, act=0, residual=None, preact=None, dact_s
             variant = 21 if kn else 0                                       # no timing trials inside a graph capture
         elif variant is None:
             best = (float("inf"), 0)
-            for v in ([16 + u for u in NN_VARIANTS] if kn else GEMM_VARIANTS):
+            for v in ([16 + u for u in NN_VARIANTS] if kn else _nt_variants(M, K, a.dtype)):
                 _gemm_call(v, *args)                                    # warm
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -177,13 +325,15 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
     else:
         N = b0.shape[0]
     assert b1.shape == b0.shape and a1.shape[1] == K and a0.dtype == a1.dtype == b0.dtype == b1.dtype
-    outs = (torch.empty((M0, N), dtype=a0.dtype, device=a0.device), torch.empty((M1, N), dtype=a0.dtype, device=a0.device))
+    outs = (_new((M0, N), a0.dtype, a0.device), _new((M1, N), a0.dtype, a0.device))
+    if _ghost():
+        return outs
     vp, lg = ctypes.c_void_p, ctypes.c_long
     ptr2 = lambda ts: _arr(vp, [_p(t) for t in ts])
     ld2 = lambda ts: _arr(lg, [t.stride(0) if t is not None else 0 for t in ts])
     if drop is not None and drop[0] <= 0.0:
         drop = None
-    seeds = _arr(ctypes.c_uint, drop[1] if drop else (0, 0))
+    seeds = _arr(ctypes.c_uint, (_shift(drop[1][0], M0 * N), _shift(drop[1][1], M1 * N)) if drop else (0, 0))
     cargs = (_dt(a0), ptr2(a), ld2(a), ptr2(b), ld2(b), ptr2(outs), ld2(outs), _arr(ctypes.c_int, (M0, M1)), N, K,
              ptr2(bias), act, ptr2(residual), ld2(residual), ptr2(preact), ld2(preact), ptr2(dact_src), ld2(dact_src), dact)
     variant = 21 if kn else 0
@@ -194,7 +344,7 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
             variant = 21 if kn else 0
         elif variant is None:
             best = (float("inf"), 0)
-            for v in ([16 + u for u in NN_VARIANTS] if kn else GEMM_VARIANTS):
+            for v in ([16 + u for u in NN_VARIANTS] if kn else _nt_variants(M0 + M1, K, a0.dtype)):
                 _lib.call("vlni_gemm_nt_dual", *cargs, v, drop[0] if drop else 0.0, seeds, _st())
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -256,9 +406,11 @@ def colsum(x, out=None):
 
 def ln_fwd(x, gamma, beta, eps):
     rows, H = x.shape
-    y = torch.empty((rows, H), dtype=x.dtype, device=x.device)
-    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
-    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    y = _new((rows, H), x.dtype, x.device)
+    mean = _new((rows,), torch.float32, x.device)
+    rstd = _new((rows,), torch.float32, x.device)
+    if _ghost():
+        return y, mean, rstd
     _lib.call("vlni_layernorm_fwd", _dt(x), x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), eps,
               y.data_ptr(), y.stride(0), mean.data_ptr(), rstd.data_ptr(), rows, H, _st())
     return y, mean, rstd
@@ -290,9 +442,11 @@ def ln_fwd2(xs, gs, bs, eps):
     H = xs[0].shape[1]
     if xs[0].dtype != xs[1].dtype or xs[1].shape[1] != H:
         return ln_fwd(xs[0], gs[0], bs[0], eps), ln_fwd(xs[1], gs[1], bs[1], eps)
-    ys = tuple(torch.empty((x.shape[0], H), dtype=x.dtype, device=x.device) for x in xs)
-    ms = tuple(torch.empty((x.shape[0],), dtype=torch.float32, device=x.device) for x in xs)
-    rs = tuple(torch.empty((x.shape[0],), dtype=torch.float32, device=x.device) for x in xs)
+    ys = tuple(_new((x.shape[0], H), x.dtype, x.device) for x in xs)
+    ms = tuple(_new((x.shape[0],), torch.float32, x.device) for x in xs)
+    rs = tuple(_new((x.shape[0],), torch.float32, x.device) for x in xs)
+    if _ghost():
+        return (ys[0], ms[0], rs[0]), (ys[1], ms[1], rs[1])
     _lib.call("vlni_layernorm_fwd_dual", _dt(xs[0]), _p2(xs), _l2(xs), _p2(gs), _p2(bs), eps, _p2(ys), _l2(ys), _p2(ms), _p2(rs),
               _i2(xs[0].shape[0], xs[1].shape[0]), H, _st())
     return (ys[0], ms[0], rs[0]), (ys[1], ms[1], rs[1])
@@ -332,11 +486,13 @@ def _ln_bwd_to2(dys, xs, gs, bs, means, rstds, wants, drop=None):
 
 def attn_fwd(q, k, v, B, Sq, Sk, kmask=None, bias=None, nh=12, drop=None):
     """q [B*Sq, >=nh*64] (strided view), k/v [B*Sk, ...]; returns ctx [B*Sq, nh*64], lse [B,nh,Sq]."""
-    out = torch.empty((B * Sq, nh * 64), dtype=q.dtype, device=q.device)
-    lse = torch.empty((B, nh, Sq), dtype=torch.float32, device=q.device)
+    out = _new((B * Sq, nh * 64), q.dtype, q.device)
+    lse = _new((B, nh, Sq), torch.float32, q.device)
+    if _ghost():
+        return out, lse
     _lib.call("vlni_attn_fwd", _dt(q), q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
               _p(kmask), _p(bias), out.data_ptr(), out.stride(0), lse.data_ptr(), B, nh, Sq, Sk, 1.0 / 8.0,
-              drop[0] if drop else 0.0, drop[1] if drop else 0, _st())
+              drop[0] if drop else 0.0, _shift(drop[1], B * nh * Sq * Sk) if drop else 0, _st())
     return out, lse
 
 
@@ -375,8 +531,11 @@ def attn_fwd2(q, k, v, B, Sq, Sk, kmask=(None, None), bias0=None, nh=12, drop=No
     if not _dual_attn_ok(*q, *k, *v) or max(Sk) > 256:
         return (attn_fwd(q[0], k[0], v[0], B, Sq[0], Sk[0], kmask[0], bias0, nh, drop=(p_, seeds[0])),
                 attn_fwd(q[1], k[1], v[1], B, Sq[1], Sk[1], kmask[1], None, nh, drop=(p_, seeds[1])))
-    outs = tuple(torch.empty((B * Sq[i], nh * 64), dtype=q[i].dtype, device=q[i].device) for i in range(2))
-    lses = tuple(torch.empty((B, nh, Sq[i]), dtype=torch.float32, device=q[i].device) for i in range(2))
+    outs = tuple(_new((B * Sq[i], nh * 64), q[i].dtype, q[i].device) for i in range(2))
+    lses = tuple(_new((B, nh, Sq[i]), torch.float32, q[i].device) for i in range(2))
+    if _ghost():
+        return (outs[0], lses[0]), (outs[1], lses[1])
+    seeds = tuple(_shift(seeds[i], B * nh * Sq[i] * Sk[i]) for i in range(2))
     _lib.call("vlni_attn_fwd_dual", _dt(q[0]), _p2(q), _l2(q), _p2(k), _l2(k), _p2(v), _l2(v), _p2(kmask), _p2((bias0, None)), _p2(outs), _l2(outs),
               _p2(lses), B, nh, (ctypes.c_int * 2)(*Sq), (ctypes.c_int * 2)(*Sk), 1.0 / 8.0, p_, (ctypes.c_uint * 2)(*seeds), _st())
     return (outs[0], lses[0]), (outs[1], lses[1])
@@ -431,11 +590,14 @@ def set_seed_base(t):
     _SEED_BASE[0] = t
 
 
-def cast(x, dtype):
+def cast(x, dtype, tape=False):
+    """tape=True: an ACTIVATION cast inside a forward operator (episode-tape aware); weights and gradients are never taped."""
     if x.dtype == dtype:
         return x
     x = x.contiguous()
-    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    out = _new(x.shape, dtype, x.device) if tape else torch.empty(x.shape, dtype=dtype, device=x.device)
+    if tape and _ghost():
+        return out
     _lib.call("vlni_cast", _dt(x), _DT[dtype], x.data_ptr(), out.data_ptr(), x.numel(), _st())
     return out
 
@@ -1000,7 +1162,7 @@ class _FfnBlock(torch.autograd.Function):
         shp = x.shape
         x2 = _rows(_chk(x, "x"))
         dt = x.dtype
-        z = torch.empty((x2.shape[0], w1.shape[0]), dtype=dt, device=x.device)
+        z = _new((x2.shape[0], w1.shape[0]), dt, x.device)
         a = gemm_nt(x2, _w((w1,), dt), bias=b1, act=1, preact=z)
         pre = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2, drop=(drop[1], drop[2]))
         y, mean, rstd = ln_fwd(pre, g, b, eps)
@@ -1211,8 +1373,8 @@ class _DualFfnBlock(torch.autograd.Function):
         a0, a1 = _rows(_chk(x0, "x0")), _rows(_chk(x1, "x1"))
         dt = x0.dtype
         FF = P0[0].shape[0]
-        z0 = torch.empty((a0.shape[0], FF), dtype=dt, device=x0.device)
-        z1 = torch.empty((a1.shape[0], FF), dtype=dt, device=x0.device)
+        z0 = _new((a0.shape[0], FF), dt, x0.device)
+        z1 = _new((a1.shape[0], FF), dt, x0.device)
         h0, h1 = gemm_nt2((a0, a1), (_w((P0[0],), dt), _w((P1[0],), dt)), bias=(P0[1], P1[1]), act=1, preact=(z0, z1))
         ph = max(drop0[1], drop1[1])
         pre0, pre1 = gemm_nt2((h0, h1), (_w((P0[2],), dt), _w((P1[2],), dt)), bias=(P0[3], P1[3]), residual=(a0, a1),
@@ -1450,8 +1612,8 @@ class _Linear(torch.autograd.Function):
         dt = out_dtype
         x2 = _rows(_chk(x, "x"))
         if x2.dtype != dt:
-            x2 = cast(x2, dt)
-        z = torch.empty((x2.shape[0], w.shape[0]), dtype=dt, device=x.device) if act else None
+            x2 = cast(x2, dt, tape=True)
+        z = _new((x2.shape[0], w.shape[0]), dt, x.device) if act else None
         y = gemm_nt(x2, _w((w,), dt), bias=b, act=act, preact=z)
         ctx.save_for_backward(x2, z, w)
         ctx.act, ctx.shp, ctx.in_dtype, ctx.b = act, shp, x.dtype, b
@@ -1509,9 +1671,10 @@ class _SmallKLinear(torch.autograd.Function):
         shp = x.shape
         x2 = _rows(_chk(x, "x")).float()
         N, K = w.shape
-        y = torch.empty((x2.shape[0], N), dtype=out_dtype, device=x.device)
-        _lib.call("vlni_smallk_linear_fwd", _DT[out_dtype], x2.data_ptr(), x2.stride(0), w.data_ptr(), _p(b), y.data_ptr(),
-                  y.stride(0), x2.shape[0], N, K, _st())
+        y = _new((x2.shape[0], N), out_dtype, x.device)
+        if not _ghost():
+            _lib.call("vlni_smallk_linear_fwd", _DT[out_dtype], x2.data_ptr(), x2.stride(0), w.data_ptr(), _p(b), y.data_ptr(),
+                      y.stride(0), x2.shape[0], N, K, _st())
         ctx.save_for_backward(x2, w)
         ctx.has_b, ctx.b = b is not None, b
         return y.view(shp[:-1] + (N,))
@@ -1557,12 +1720,13 @@ class _SumLayerNorm(torch.autograd.Function):
             f32[k] = 1 if s2.dtype == torch.float32 else 0
             if s2.dtype != torch.float32 and s2.dtype != out_dtype:
                 raise TypeError("sum_layernorm: activation sources must have the compute dtype")
-        y = torch.empty((rows, H), dtype=out_dtype, device=dev)
-        xs = torch.empty((rows, H), dtype=out_dtype, device=dev)
-        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
-        rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
-        _lib.call("vlni_sum_layernorm_fwd", _DT[out_dtype], n, ptrs, lds, ips, f32, g.data_ptr(), b.data_ptr(), eps,
-                  y.data_ptr(), H, xs.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), rows, H, _st())
+        y = _new((rows, H), out_dtype, dev)
+        xs = _new((rows, H), out_dtype, dev)
+        mean = _new((rows,), torch.float32, dev)
+        rstd = _new((rows,), torch.float32, dev)
+        if not _ghost():
+            _lib.call("vlni_sum_layernorm_fwd", _DT[out_dtype], n, ptrs, lds, ips, f32, g.data_ptr(), b.data_ptr(), eps,
+                      y.data_ptr(), H, xs.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), rows, H, _st())
         ctx.save_for_backward(xs, g, mean, rstd, *[i for i in idxs if i is not None])
         ctx.spec, ctx.idx_pos = spec, [k for k, i in enumerate(idxs) if i is not None]
         ctx.shapes = [(s.shape, s.dtype) for s in srcs]
@@ -1603,8 +1767,9 @@ class _SeqMean(torch.autograd.Function):
     def forward(ctx, x):
         B, S, H = x.shape
         x = _chk(x, "x").contiguous()
-        out = torch.empty((B, H), dtype=x.dtype, device=x.device)
-        _lib.call("vlni_seqmean_fwd", _dt(x), x.data_ptr(), out.data_ptr(), B, S, H, _st())
+        out = _new((B, H), x.dtype, x.device)
+        if not _ghost():
+            _lib.call("vlni_seqmean_fwd", _dt(x), x.data_ptr(), out.data_ptr(), B, S, H, _st())
         ctx.dims = (B, S, H)
         return out
 
@@ -1626,9 +1791,10 @@ class _RowDot(torch.autograd.Function):
         h2 = _rows(_chk(h, "h"))
         rows, H = h2.shape
         m8 = mask.reshape(-1).to(torch.uint8).contiguous() if mask is not None else None
-        out = torch.empty((rows,), dtype=torch.float32, device=h.device)
-        _lib.call("vlni_rowdot_fwd", _dt(h2), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(bias), _p(m8), out.data_ptr(),
-                  rows, H, _st())
+        out = _new((rows,), torch.float32, h.device)
+        if not _ghost():
+            _lib.call("vlni_rowdot_fwd", _dt(h2), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(bias), _p(m8), out.data_ptr(),
+                      rows, H, _st())
         ctx.save_for_backward(h2, w, m8)
         ctx.shp, ctx.has_b, ctx.bias = shp, bias is not None, bias
         return out.view(shp[:-1])
@@ -1758,8 +1924,9 @@ class _GateRows(torch.autograd.Function):
     def forward(ctx, visn, lang, r0, n):
         visn, lang = _chk(visn, "visn").contiguous(), _chk(lang, "lang").contiguous()
         (B, Sv, H), Sl = visn.shape, lang.shape[1]
-        f = torch.empty((B, n, H), dtype=visn.dtype, device=visn.device)
-        _lib.call("vlni_gate_rows_fwd", _dt(visn), visn.data_ptr(), lang.data_ptr(), f.data_ptr(), B, Sv, Sl, r0, n, H, _st())
+        f = _new((B, n, H), visn.dtype, visn.device)
+        if not _ghost():
+            _lib.call("vlni_gate_rows_fwd", _dt(visn), visn.data_ptr(), lang.data_ptr(), f.data_ptr(), B, Sv, Sl, r0, n, H, _st())
         ctx.save_for_backward(visn, lang)
         ctx.meta = (r0, n)
         return f
@@ -1789,7 +1956,35 @@ def drop_cfg(p_attn, p_hidden, training):
     """(p_attn, p_hidden, seed) for one fused block call; zeros outside training."""
     if not training or (p_attn <= 0.0 and p_hidden <= 0.0):
         return NO_DROP
-    return (float(p_attn), float(p_hidden), next_seeds(4))
+    return (float(p_attn), float(p_hidden), _TAPE.seed(4) if _TAPE is not None else next_seeds(4))
+
+
+class _TapeDropout(torch.autograd.Function):
+    """Counter-based dropout (vlni_dropout) as an autograd node: what `dropout` uses inside an episode tape, where torch's own generator
+    would draw one mask in the step's forward and another one in the ghost pass."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _chk(x, "x").contiguous()
+        y = _new(x.shape, x.dtype, x.device)
+        if not _ghost():
+            _lib.call("vlni_dropout", _dt(x), x.data_ptr(), y.data_ptr(), x.numel(), p, _shift(seed, x.numel()), _st())
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dropout_apply(dy, ctx.p, ctx.seed), None, None
+
+
+def dropout(x, p, training):
+    """F.dropout for the small tensors the models drop outside the fused kernels (embedding outputs, action heads); inside an episode
+    tape the mask comes from the library's counter-based hash so that the ghost pass and the batched backward see the step's mask."""
+    if not training or p <= 0.0:
+        return x
+    if _TAPE is None:
+        return torch.nn.functional.dropout(x, p, True)
+    return _TapeDropout.apply(x, float(p), _TAPE.seed(1))
 
 
 def self_att_block(x, kmask, p, eps=1e-12, bias=None, drop=NO_DROP):
