@@ -17,7 +17,8 @@ starts the N rank processes itself - from a parent that never touches the GPU - 
 Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel = the MFMA GEMM family, timed with HIP events on the
 launch stream in an instrumented pass after the timed region), `cpu_baseline` (the CPU oracle on a bounded sample, N = 1),
 `bf16_vs_fp32` (error of the timed bf16 path against the fp32 parity path of the same model on a B = 8 slice) and, at N = 1,
-`extras`: the same episodes time-batched, in train mode (in-kernel dropout p = 0.1), with the shipped freeze, at T = 1 and in fp32.
+`extras`: the same episodes through the other two drivers (one autograd graph per call; time-batched), in eval mode (dropout off), with the
+shipped freeze, at T = 1, in fp16 and in fp32. Default = the reference's training mode (model.train(), dropout p = 0.1 inside the kernels).
 """
 import argparse
 import json
@@ -153,11 +154,20 @@ class Workload:
         m.load_state_dict({k: torch.from_numpy(v) for k, v in self.weights.items()})
         return m.to(device).eval().set_compute_dtype(dtype)      # eval(): dropout p = 0 (the survey's CPU probe); `train_mode` extra: p = 0.1
 
-    def run(self, criterion=None, keep=False, model=None, et=None, time_batched=False):
+    def run(self, criterion=None, keep=False, model=None, et=None, mode="stepwise"):
+        """mode: 'stepwise' = T autograd graphs, one per call (the reference agent's own pattern); 'taped' (HAMT) = the same
+        step-by-step forward calls recorded on an episode tape + ONE episode-batched backward (valid for sampled rollouts too);
+        'time_batched' (HAMT) = forward AND backward on T x B samples (teacher forcing only)."""
         kw = {} if criterion is None else {"criterion": criterion}
-        if time_batched:
+        if mode == "time_batched":
             from vln_imagine_amd.hamt.episode import run_episode_time_batched
             return run_episode_time_batched(model or self.model, et or self.et, **kw)
+        if mode == "taped":
+            from vln_imagine_amd import ops
+            from vln_imagine_amd.hamt.episode import run_episode_taped
+            if getattr(self, "tape", None) is None:
+                self.tape = ops.EpisodeTape(self.T)
+            return run_episode_taped(model or self.model, et or self.et, tape=self.tape, **kw)
         return self._run(model or self.model, et or self.et, keep=keep, **kw)
 
 
@@ -221,9 +231,14 @@ def main():
     ap.add_argument("--lang-rows", default="all", choices=["all", "cls"],
                     help="HAMT: 'all' = every language row through the last cross-modal layer like the reference's NavCMT (the headline); "
                          "'cls' = only the row the agent reads (what the VLNBertCMT wrapper selects; identical results)")
-    ap.add_argument("--time-batched", action="store_true",
-                    help="HAMT: run the T teacher-forced steps as one [T*B] batch (same results, SURVEY 8f rank 1)")
-    ap.add_argument("--train-mode", action="store_true", help="model.train(): in-kernel dropout p = 0.1 (the reference's training mode)")
+    ap.add_argument("--mode", default=None, choices=["taped", "stepwise", "time_batched"],
+                    help="HAMT episode driver (default taped): taped = step-by-step forward calls + ONE episode-batched backward (episode tape; "
+                         "what a sampled rollout can use); stepwise = one autograd graph per call; time_batched = forward and backward on "
+                         "T x B samples (teacher forcing only). DUET runs stepwise.")
+    ap.add_argument("--time-batched", action="store_true", help="same as --mode time_batched")
+    ap.add_argument("--train-mode", dest="train_mode", action="store_true", default=True,
+                    help="model.train(): in-kernel dropout p = 0.1 - the reference's training mode (default)")
+    ap.add_argument("--eval-mode", dest="train_mode", action="store_false", help="model.eval(): dropout p = 0 (rounds 1-2 quoted this)")
     ap.add_argument("--grad-comm", default="bf16", choices=["bf16", "fp32"],
                     help="dtype of the gradient all-reduce payload for N > 1 (arena stays fp32)")
     ap.add_argument("--graph", dest="graph", action="store_true", default=True,
@@ -242,8 +257,13 @@ def main():
         args.batch = 32 if args.model == "duet" else 64
     if args.cpu_batch is None:
         args.cpu_batch = args.batch
+    if args.time_batched:
+        args.mode = "time_batched"
     if args.model == "duet":
-        args.time_batched = False                 # DUET's maps grow with the agent's moves: there is no time-batched form
+        args.mode = "stepwise"                    # DUET's maps grow with the agent's moves: no batched form yet
+    elif args.mode is None:
+        args.mode = "taped"
+    args.time_batched = args.mode == "time_batched"
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
@@ -301,11 +321,11 @@ def main():
             return bool(f.item() > 0)
         return flag
 
-    def measure(w, trainer, steps, warmup, time_batched=False, graph=True, what="step"):
+    def measure(w, trainer, steps, warmup, mode="stepwise", graph=True, what="step"):
         """W untimed warm-up steps, capture, then EXACTLY `steps` steps between fences; max over ranks. Returns (seconds per step,
         launch description, last loss, eager step callable)."""
         def fwd_bwd():
-            loss = w.run(criterion=ops.cross_entropy_sum, time_batched=time_batched)["loss"]
+            loss = w.run(criterion=ops.cross_entropy_sum, mode=mode)["loss"]
             if w.model.compute_dtype == torch.float16:
                 (loss * trainer.loss_scale).backward()           # the fused step divides the scale out again (and skips on overflow)
             else:
@@ -331,7 +351,7 @@ def main():
             import gc
             loss = None                                 # drop the last eager autograd graph (its AccumulateGrad nodes) before capturing
             gc.collect()
-            slow, captured = True, None
+            slow, captured, failed = True, None, None
             try:
                 captured = trainer.capture(fwd_bwd, warmup=1)
                 captured()
@@ -343,8 +363,13 @@ def main():
                 tg = (time.perf_counter() - tg) / 2
                 log(f"{what}: captured into hipGraphs; replay {1e3 * tg:.1f} ms vs eager {1e3 * eager_s:.1f} ms")
                 slow = tg > 1.3 * eager_s             # never seen on a dedicated GPU; two processes SHARING one GPU replay pathologically slowly
-            except Exception as e:                      # keep measuring: fall back to the eager step and say so
-                log(f"{what}: graph capture failed ({type(e).__name__}: {e})")
+            except Exception as e:                      # one GPU: keep measuring with the eager step and say so
+                failed = f"{type(e).__name__}: {e}"
+                log(f"{what}: graph capture failed ({failed})")
+            if world > 1 and agree(failed is not None):
+                # several ranks: a silent fall-back would time a different program (44 instead of 33 ms) under the same headline - stop
+                # instead (--no-graph asks for the eager step explicitly). Every rank reaches this decision before any replay runs.
+                raise SystemExit(f"bench.py: hipGraph capture failed on a rank of {world} ({failed}); rerun with --no-graph to time the eager step")
             if agree(slow):
                 log(f"{what}: no usable graph replay on this box: timing the eager step")
             else:
@@ -372,7 +397,7 @@ def main():
         w.model.train()
     trainer = FlatTrainer(w.model, lr=1e-5, grad_comm_dtype=comm, **scaler)
     log(f"model + episode ready on {dev}; warmup {args.warmup}, steps {args.steps}, dtype {args.dtype}, world {world}")
-    sec, launch, last_loss, eager_step = measure(w, trainer, args.steps, args.warmup, time_batched=args.time_batched, graph=args.graph)
+    sec, launch, last_loss, eager_step = measure(w, trainer, args.steps, args.warmup, mode=args.mode, graph=args.graph)
     ms = sec * 1e3
     eps = args.batch * world / sec
 
@@ -395,6 +420,8 @@ def main():
             return b.n if isinstance(b, ops.WT) else b.t.shape[1] if isinstance(b, ops.KN) else b.shape[0]      # WT / KN: dgrad operand handles
 
         def timed(a, b, *p, **k):
+            if ops._ghost():                           # the tape's ghost pass launches nothing: not a GEMM launch
+                return orig(a, b, *p, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig(a, b, *p, **k)
@@ -404,6 +431,8 @@ def main():
             return r
 
         def timed2(a, b, *p, **k):                     # dual-problem launches (language + vision stream in one launch)
+            if ops._ghost():
+                return orig2(a, b, *p, **k)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = orig2(a, b, *p, **k)
@@ -436,7 +465,7 @@ def main():
         traffic, traffic_src = None, None
         try:      # HBM bytes per launch: separate rocprofv3 --pmc passes of this command (never collected inside a timed run)
             pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-            if pmc and args.dtype == "bf16" and args.model == "hamt" and not args.time_batched:      # collected on the default workload only
+            if pmc and args.dtype == "bf16" and args.model == "hamt" and args.mode == "taped" and args.train_mode:      # collected on the default workload only
                 traffic = round(json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["bytes_per_launch"])
                 traffic_src = f"profiles/{pmc[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
         except Exception:
@@ -482,6 +511,7 @@ def main():
     parity = None
     if rank == 0 and not args.no_parity and args.dtype in ("bf16", "fp16"):
         ws = Workload(args.model, args, shipped, dev, dtype, batch=8, tag="slice", model=w.model)
+        w.model.eval()                                            # p = 0 on both sides: the distance of the arithmetic, not of two mask draws
         w32 = ws.build(dev, torch.float32)
         w32.load_state_dict(w.model.state_dict())                 # the timed model has taken optimizer steps: compare at ITS weights
         trainer.zero_grad()
@@ -501,6 +531,8 @@ def main():
                             "reference goldens at 1e-4")
         log(f"bf16 vs fp32: {parity}")
         del w32, o16, o32, ws
+        if args.train_mode:
+            w.model.train()
     if world > 1:
         dist.barrier()
 
@@ -513,33 +545,38 @@ def main():
             return {"value": round(args.batch / sec_, 2), "unit": "episodes/s", "ms_per_step": round(sec_ * 1e3, 3),
                     "step_algorithmic_tflops": round(flops_ / sec_ / 1e12, 2), "note": note}
 
-        if args.model == "hamt" and not args.time_batched:
-            s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=True, graph=args.graph, what="time-batched")
-            extras["time_batched"] = line(s_, w.flops, "T steps as one [T*B] batch under teacher forcing; same results as the step-by-step calls")
+        if args.model == "hamt":
+            for md, note in (("stepwise", "one autograd graph per `visual` / `history` call (rounds 1-2's headline path): T x shorter backward launches"),
+                             ("time_batched", "forward AND backward on T x B samples (teacher forcing only); same results"),
+                             ("taped", "step-by-step forward calls on an episode tape + ONE episode-batched backward")):
+                if md != args.mode:
+                    s_, _, _, _ = measure(w, trainer, k_extra, 2, mode=md, graph=args.graph, what=md)
+                    extras[md] = line(s_, w.flops, note)
         if args.model == "hamt" and args.lang_rows == "all":
             w.model.visual_lang_rows = "cls"
-            s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="cls-rows")
-            if not args.time_batched:
-                s2_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=True, graph=args.graph, what="cls-rows, time-batched")
+            s_, _, _, _ = measure(w, trainer, k_extra, 2, mode=args.mode, graph=args.graph, what="cls-rows")
             w.model.visual_lang_rows = "all"
             extras["cls_rows"] = line(s_, w.flops, "what the VLNBertCMT wrapper runs: the last cross-modal layer computes only the language [CLS] row it "
                                                    "reads (NavCMT.visual_lang_rows = 'cls'); logits, loss and gradients identical "
                                                    "(tests/test_hamt_gpu.py), step_algorithmic_tflops still counts the reference's full rows")
-            if not args.time_batched:
-                extras["cls_rows"]["time_batched_ms_per_step"] = round(s2_ * 1e3, 3)
-        if not args.train_mode:
+        if args.train_mode:
+            w.model.eval()
+            s_, _, _, _ = measure(w, trainer, k_extra, 2, mode=args.mode, graph=args.graph, what="eval-mode")
             w.model.train()
-            s_, _, _, _ = measure(w, trainer, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="train-mode")
+            extras["eval_mode"] = line(s_, w.flops, "model.eval(): dropout p = 0 (what rounds 1-2 quoted as the headline)")
+        else:
+            w.model.train()
+            s_, _, _, _ = measure(w, trainer, k_extra, 2, mode=args.mode, graph=args.graph, what="train-mode")
             w.model.eval()
             extras["train_mode"] = line(s_, w.flops, "model.train(): attention-probability and hidden dropout p = 0.1 inside the fused kernels "
                                                      "(masks regenerated in backward), the reference's training mode")
         if args.model == "hamt":
             w1 = Workload("hamt", args, shipped, dev, dtype, T=1, tag="benchT1", model=w.model)
-            s_, _, _, _ = measure(w1, trainer, k_extra, 2, graph=args.graph, what="T=1")
+            s_, _, _, _ = measure(w1, trainer, k_extra, 2, mode=args.mode, graph=args.graph, what="T=1")
             extras["T1"] = line(s_, w1.flops, "one navigation step per episode (SURVEY 8d's second episode length)")
         if args.dtype == "bf16":
             w.model.set_compute_dtype(torch.float32)
-            s_, _, _, _ = measure(w, trainer, 3, 1, time_batched=args.time_batched, graph=False, what="fp32")
+            s_, _, _, _ = measure(w, trainer, 3, 1, mode=args.mode, graph=False, what="fp32")
             w.model.set_compute_dtype(dtype)
             e_ = line(s_, w.flops, "the parity path: every contraction on v_mfma_f32_32x32x2_f32 (exact fp32), eager launches")
             e_["step_frac_of_fp32_mfma_peak"] = round(w.flops / s_ / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)
@@ -551,7 +588,9 @@ def main():
             w16 = Workload(args.model, args, shipped, dev, torch.float16, tag=f"bench{rank}")
             tr16 = FlatTrainer(w16.model, lr=1e-5, grad_comm_dtype=comm, loss_scale=16384.0, growth_interval=2000)
             trainer = tr16                                   # measure()'s closures read `trainer`
-            s_, _, _, _ = measure(w16, tr16, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="fp16")
+            if args.train_mode:
+                w16.model.train()
+            s_, _, _, _ = measure(w16, tr16, k_extra, 2, mode=args.mode, graph=args.graph, what="fp16")
             e_ = line(s_, w16.flops, "float16 compute + GradScaler-style dynamic loss scaling in the fused step (float32 masters, f16 mirror)")
             e_["skipped_steps"] = int(float(tr16.state[5]))
             e_["loss_scale"] = float(tr16.state[4])
@@ -563,7 +602,9 @@ def main():
             del trainer
             ws_ = Workload(args.model, args, True, dev, dtype, tag=f"bench{rank}")
             tr2 = FlatTrainer(ws_.model, lr=1e-5, grad_comm_dtype=comm)
-            s_, _, _, _ = measure(ws_, tr2, k_extra, 2, time_batched=args.time_batched, graph=args.graph, what="freeze=shipped")
+            if args.train_mode:
+                ws_.model.train()
+            s_, _, _, _ = measure(ws_, tr2, k_extra, 2, mode=args.mode, graph=args.graph, what="freeze=shipped")
             extras["freeze_shipped"] = line(s_, ws_.flops, "the released run's freeze: language stack (and HAMT history encoder) forward only")
             tr2.close()
 
@@ -580,7 +621,8 @@ def main():
             "config": {"workload": f"{w.label}, batch {args.batch}/GPU, {args.L} text, {args.V} obs tokens, "
                                    f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, "
                                    + ("train mode: in-kernel dropout p=0.1" if args.train_mode else "dropout p=0 (eval)")
-                                   + (", steps time-batched (teacher forcing)" if args.time_batched else ", step-by-step calls")
+                                   + {"time_batched": ", steps time-batched (teacher forcing)", "stepwise": ", step-by-step calls (one autograd graph each)",
+                                      "taped": ", step-by-step forward calls, ONE episode-batched backward (episode tape)"}[args.mode]
                                    + (", last X-layer: language [CLS] row only" if args.model == "hamt" and args.lang_rows == "cls" else ""),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "launch": launch, "rccl": rccl,

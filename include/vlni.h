@@ -45,7 +45,9 @@ int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, vo
    6 / 7 / 8 LDS-DMA large tiles 256x128 / 256x256 / 128x256, 9 / 10 / 11 small tiles 64x128 / 128x64 / 64x64, 12 / 13 tiles 192x128 / 128x192
    (two blocks per CU), 14 persistent 128x128 (register epilogue): results identical bit for bit. 15 = persistent 256x256 "8-phase"
    kernel on v_mfma_f32_16x16x32 for long launches (16-bit types, K % 128 == 0; other cases run variant 14): same products summed in
-   another tree, i.e. equal to the others within float32 rounding of the accumulator.
+   another tree, i.e. equal to the others within float32 rounding of the accumulator. 32 (= id 16; ids above 15 are passed as 32 + id - 16
+   because "+ 16" is the layout flag below) = 256x128 tiles, three LDS buffers, four dedicated loader waves, same MFMA as 15: step-long
+   launches and N = 768 projections (16-bit types, K % 64 == 0, K >= 128).
    variant + 16: B is given as [K,N] row-major with ldb >= N, i.e. the forward weight W[out,in] itself as the dgrad operand
    (dX = dY * W) - no transposed weight copy; bf16 only, K % 64 == 0, K >= 192, N % 8 == 0, pipelines 2..5. */
 int vlni_gemm_nt_v(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,

@@ -13,7 +13,7 @@ from vln_imagine_amd import ops  # noqa: E402
 dt = torch.bfloat16
 T = int(os.environ.get("T", "1"))                       # T > 1: the row counts of T time-batched / episode-batched steps
 M0, M1 = T * 64 * 86, T * 64 * 40
-NT_VARIANTS = tuple(int(v) for v in os.environ.get("NT_VARIANTS", "4,5,12,13,14,15").split(","))
+NT_VARIANTS = tuple(int(v) for v in os.environ.get("NT_VARIANTS", "5,12,13,14,15,32").split(","))
 NN_VARIANTS = tuple(int(v) for v in os.environ.get("NN_VARIANTS", "4,5,6").split(","))
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
 
@@ -64,7 +64,7 @@ def run(nn, N, K, kind):
     if nn:                                   # the same dgrad through the NT kernels on a W^T copy (what launches of >= NT_LONG_ROWS rows use)
         wt = (w[0].t().contiguous(), w[1].t().contiguous())
         try:
-            for v in (14, 15):
+            for v in (14, 15, 32):
                 ops.GEMM_VARIANTS = (v,)
                 ops._GEMM_BEST.clear()
                 t = min(time_call(lambda: ops.gemm_nt2(a, wt, **kw)) for _ in range(ROUNDS))

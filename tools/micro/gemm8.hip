@@ -229,6 +229,236 @@ __global__ __launch_bounds__(512) void gemm8_kernel(P8 p, unsigned long long* st
   }
 }
 
+
+// ======================================================================================================================
+// 256 x 128 x 64 tile, THREE 48-KiB LDS buffers (k-tile s in buffer s % 3): 8 waves as 4 (M) x 2 (N), a wave owns 64 x 64 = acc[4][4];
+// a k-tile is 2 phases of 16 MFMAs (rows 0-31 / 32-63 of the wave's tile); the two wave groups (waves 0-3 / 4-7) run one barrier apart.
+// k-tile s + 2 is requested during k-tile s (3 + 3 LDS-DMA instructions per wave); s_waitcnt vmcnt(6) in phase 2 certifies k-tile s + 1.
+// The buffer of s + 2 was last read in k-tile s - 1: no ordering subtleties beyond retiring phase 2's reads before its first barrier.
+template <int STAMP, int NL>      // NL: dedicated loader waves (0 = the 8 computing waves request their own data)
+__global__ __launch_bounds__(512 + 64 * NL) void gemm8h_kernel(P8 p, unsigned long long* stamps) {
+  extern __shared__ __attribute__((aligned(16))) char dsmem[];
+  constexpr int TM = 256, TN = 128, BUF = (TM + TN) * 128;     // 49152
+  constexpr int NI = NL ? 48 / NL : 6;                         // LDS-DMA instructions per requesting wave and k-tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = NL > 0 && wave >= 8;
+  const int wr = (wave & 7) >> 1, wc = wave & 1, grp = (wave & 7) >> 2, fr = lane & 15, fq = lane >> 4;
+  const int bid = blockIdx.x, xcd = bid & 7, gx = gridDim.x >> 3;
+  const int q8 = p.ntiles >> 3, rr = p.ntiles & 7;
+  const int c0 = xcd < rr ? xcd * (q8 + 1) : rr * (q8 + 1) + (xcd - rr) * q8;
+  const int c1 = c0 + q8 + (xcd < rr ? 1 : 0);
+  int tile = c0 + (bid >> 3);
+  if (tile >= c1) return;
+  const int nk = p.K / 64;
+
+  auto locate = [&](int w, Side& s) __attribute__((always_inline)) {
+    const int ntn = (p.N + TN - 1) / TN;
+    if (p.group_m <= 1) { s.m0 = (w / ntn) * TM; s.n0 = (w % ntn) * TN; return; }
+    const int ntm = (p.M + TM - 1) / TM;
+    const int per = p.group_m * ntn;
+    const int g = w / per, idx = w - g * per;
+    const int first = g * p.group_m, gsz = min(ntm - first, p.group_m);
+    s.m0 = (first + idx % gsz) * TM;
+    s.n0 = (idx / gsz) * TN;
+  };
+  // request side. The k-tile's 48 KiB are 48 pieces of 1 KiB = 8 LDS rows: piece q (0..31 A, 32..47 B) = rows (q % 32 or q - 32) * 8 ...
+  // Requesting wave v (0..NV-1, NV = 8 or NL) owns pieces v + NV * j, j = 0 .. NI-1.
+  constexpr int NV = NL ? NL : 8;
+  const int v = NL ? (wave - 8) : wave;
+  const unsigned lds0 = lds_u32(dsmem);
+  const char* pg[NI];
+  auto point = [&](const Side& s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int q = v + NV * j;
+      const int rho = (q & 31) * 8 + (lane >> 3);                 // (B pieces: q - 32 < 16, so q & 31 = q - 32)
+      const int c = (lane & 7) ^ ((rho >> 1) & 7);
+      if (NV * j < 32 && q < 32) pg[j] = p.A + (long)min(s.m0 + rho, p.M - 1) * p.lda * 2 + c * 16;
+      else pg[j] = p.B + (long)min(s.n0 + rho, p.N - 1) * p.ldb * 2 + c * 16;
+    }
+  };
+#define H_DMA(j, boff)                                                                                          \
+  do {                                                                                                          \
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"                           \
+                 : : "v"(pg[j]), "s"(lds0 + (boff) + v * 1024), "n"(NV * (j) * 1024) : "memory", "scc");        \
+    pg[j] += 128;                                                                                               \
+  } while (0)
+
+  unsigned long long t_begin = 0, t_loop = 0, t_epi = 0;
+  if constexpr (STAMP) t_begin = __builtin_amdgcn_s_memtime();
+  Side cur, nxt;
+  locate(tile, cur);
+  unsigned rbuf = 0, wbuf = 2 * BUF;
+  int left = nk - 2;
+
+  if (loader || NL == 0) {
+    point(cur);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) H_DMA(j, 0);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) H_DMA(j, BUF);
+    if constexpr (NI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  }
+  BAR();
+
+  if (loader) {
+    // ---- loader waves: the request stream only, in step with wave group 0's barriers ----
+    while (true) {
+      const int ntile = tile + gx;
+      const bool more = ntile < c1;
+      for (int kt = 0; kt < nk; ++kt) {
+        if (left == 0) {
+          int nt_ = more ? ntile : tile;
+          asm volatile("" : "+s"(nt_));
+          locate(nt_, nxt);
+          point(nxt);
+          left = nk;
+        }
+        --left;
+#pragma unroll
+        for (int j = 0; j < NI / 2; ++j) H_DMA(j, wbuf);
+        BAR(); BAR();
+#pragma unroll
+        for (int j = NI / 2; j < NI; ++j) H_DMA(j, wbuf);
+        if constexpr (NI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        BAR(); BAR();
+        wbuf = wbuf == 2 * BUF ? 0 : wbuf + BUF;
+      }
+      BAR();                                                   // (group 0's line-up barrier)
+      if (!more) break;
+      tile = ntile;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  const int sw = (fr >> 1) & 7;
+  const unsigned aoff = (wr * 64 + fr) * 128 + ((fq ^ sw) << 4);             // + mb * 2048, ^ 64 for the second k32
+  const unsigned boffr = 32768 + (wc * 64 + fr) * 128 + ((fq ^ sw) << 4);    // + nb * 2048
+  h16x8 a[2][2], b[4][2];
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  while (true) {
+    const int ntile = tile + gx;
+    const bool more = ntile < c1;
+    unsigned long long tl = 0;
+    if constexpr (STAMP) tl = __builtin_amdgcn_s_memtime();
+    if (grp == 1) BAR();
+    for (int kt = 0; kt < nk; ++kt) {
+      if constexpr (NL == 0) {
+        if (left == 0) {
+          int nt_ = more ? ntile : tile;
+          asm volatile("" : "+s"(nt_));
+          locate(nt_, nxt);
+          point(nxt);
+          left = nk;
+        }
+        --left;
+      }
+      const char* rb = dsmem + rbuf;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) b[nb][kk] = *(const h16x8*)(rb + nb * 2048 + (boffr ^ (kk * 64)));
+      SB();
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) a[mb][kk] = *(const h16x8*)(rb + mb * 2048 + (aoff ^ (kk * 64)));
+      SB();
+      if constexpr (NL == 0) { H_DMA(0, wbuf); H_DMA(1, wbuf); H_DMA(2, wbuf); }
+      BAR(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SB();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nb][kk], a[mb][kk], acc[mb][nb], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      BAR();
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) a[mb][kk] = *(const h16x8*)(rb + (mb + 2) * 2048 + (aoff ^ (kk * 64)));
+      SB();
+      if constexpr (NL == 0) {
+        H_DMA(3, wbuf); H_DMA(4, wbuf); H_DMA(5, wbuf);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      BAR(); SB();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) acc[mb + 2][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nb][kk], a[mb][kk], acc[mb + 2][nb], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      BAR();
+      rbuf = rbuf == 2 * BUF ? 0 : rbuf + BUF;
+      wbuf = wbuf == 2 * BUF ? 0 : wbuf + BUF;
+    }
+    if (grp == 0) BAR();
+    unsigned long long te = 0;
+    if constexpr (STAMP) { te = __builtin_amdgcn_s_memtime(); t_loop += te - tl; }
+    {
+      __bf16* C = (__bf16*)p.C;
+      f32x4 bv[2][2];
+      int colj[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        colj[j] = cur.n0 + wc * 64 + j * 32 + (fq & 1) * 16 + (fq >> 1) * 8;
+        const int cc = min(colj[j], p.N - 8);
+        bv[j][0] = p.bias ? *(const f32x4*)(p.bias + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        bv[j][1] = p.bias ? *(const f32x4*)(p.bias + cc + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int im = 0; im < 4; ++im) {
+        const int row = cur.m0 + wr * 64 + im * 16 + fr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int col = colj[j];
+          float v8[8];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float x = acc[im][j * 2][u], y = acc[im][j * 2 + 1][u];
+            const auto s2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+            v8[u] = __uint_as_float(s2[0]) + bv[j][0][u];
+            v8[4 + u] = __uint_as_float(s2[1]) + bv[j][1][u];
+          }
+          h16x8 o;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) o[u] = (__bf16)v8[u];
+          if (col < p.N && row < p.M) *(h16x8*)(C + (long)row * p.ldc + col) = o;
+          acc[im][j * 2] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[im][j * 2 + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+    if constexpr (STAMP) t_epi += __builtin_amdgcn_s_memtime() - te;
+    if (!more) break;
+    tile = ntile;
+    if constexpr (NL == 0) cur = nxt;
+    else locate(tile, cur);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (STAMP) {
+    if (lane == 0) {
+      unsigned long long* o = stamps + ((long)blockIdx.x * 8 + wave) * 4;
+      o[0] = __builtin_amdgcn_s_memtime() - t_begin; o[1] = t_loop; o[2] = t_epi; o[3] = 0;
+    }
+  }
+}
+
 // ---- reference: one thread per output, float accumulation in k order ----
 __global__ void ref_kernel(const __bf16* A, const __bf16* B, float* C, int M, int N, int K, const float* bias) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -246,13 +476,29 @@ __global__ void fill_kernel(__bf16* x, long n, unsigned seed) {
   x[i] = (__bf16)(((float)(h & 0xFFFF) / 32768.0f) - 1.0f);
 }
 
+static int g_kind = 0;          // 0: 256 x 256, 1: 256 x 128
+static int tiles_of(int M, int N) { return ((M + 255) / 256) * ((N + (g_kind ? 127 : 255)) / (g_kind ? 128 : 256)); }
 static void launch(const P8& p0, hipStream_t st, bool stamp, unsigned long long* stamps) {
   P8 p = p0;
-  const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
-  p.ntiles = ntm * ntn;
+  p.ntiles = tiles_of(p.M, p.N);
   static const int gm = getenv("GROUP_M") ? atoi(getenv("GROUP_M")) : 4;
   p.group_m = gm;
   const int G = 8 * std::min(32, (p.ntiles + 7) / 8);
+  if (g_kind == 1) {
+    if (stamp) hipLaunchKernelGGL((gemm8h_kernel<1, 0>), dim3(G), dim3(512), 147456, st, p, stamps);
+    else hipLaunchKernelGGL((gemm8h_kernel<0, 0>), dim3(G), dim3(512), 147456, st, p, stamps);
+    return;
+  }
+  if (g_kind == 2) {
+    if (stamp) hipLaunchKernelGGL((gemm8h_kernel<1, 4>), dim3(G), dim3(768), 147456, st, p, stamps);
+    else hipLaunchKernelGGL((gemm8h_kernel<0, 4>), dim3(G), dim3(768), 147456, st, p, stamps);
+    return;
+  }
+  if (g_kind == 3) {
+    if (stamp) hipLaunchKernelGGL((gemm8h_kernel<1, 8>), dim3(G), dim3(1024), 147456, st, p, stamps);
+    else hipLaunchKernelGGL((gemm8h_kernel<0, 8>), dim3(G), dim3(1024), 147456, st, p, stamps);
+    return;
+  }
   if (stamp) hipLaunchKernelGGL(gemm8_kernel<1>, dim3(G), dim3(512), 131072, st, p, stamps);
   else hipLaunchKernelGGL(gemm8_kernel<0>, dim3(G), dim3(512), 131072, st, p, stamps);
 }
@@ -260,11 +506,22 @@ static void launch(const P8& p0, hipStream_t st, bool stamp, unsigned long long*
 int main(int argc, char** argv) {
   hipFuncSetAttribute((const void*)gemm8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   hipFuncSetAttribute((const void*)gemm8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  hipFuncSetAttribute((const void*)gemm8h_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  hipFuncSetAttribute((const void*)gemm8h_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  hipFuncSetAttribute((const void*)gemm8h_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  hipFuncSetAttribute((const void*)gemm8h_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  hipFuncSetAttribute((const void*)gemm8h_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  hipFuncSetAttribute((const void*)gemm8h_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  g_kind = argc > 1 ? atoi(argv[1]) : 0;
+  const char* names[] = {"256 x 256, 2 buffers", "256 x 128, 3 buffers", "256 x 128, 3 buffers, 4 loader waves", "256 x 128, 3 buffers, 8 loader waves"};
+  printf("kernel: %s\n", names[g_kind]);
   struct Shape { int M, N, K; bool check; };
   std::vector<Shape> shapes = {
-      {1000, 520, 256, true}, {256, 256, 128, true}, {4096, 4096, 4096, true}, {8192, 8192, 8192, false},
+      {1000, 520, 256, true}, {256, 256, 192, true}, {4096, 4096, 4096, true}, {8192, 8192, 8192, false},
       {48384, 768, 768, true}, {48384, 2304, 768, false}, {48384, 3072, 768, false}, {48384, 768, 3072, false},
-      {8064, 768, 768, false}, {8064, 2304, 768, false}, {8064, 3072, 768, false}, {8064, 768, 3072, false}};
+      {8256, 768, 768, true}, {8256, 2304, 768, false}, {8256, 3072, 768, false}, {8256, 768, 3072, false},
+      {5120, 768, 768, false}, {5120, 2304, 768, false}, {5120, 3072, 768, false}, {5120, 768, 3072, false},
+      {2304, 768, 768, false}, {2304, 2304, 768, false}, {2304, 3072, 768, false}, {2304, 768, 3072, false}};
   unsigned long long* stamps;
   hipMalloc(&stamps, 256 * 8 * 4 * 8);
   for (const Shape& s : shapes) {
@@ -317,7 +574,7 @@ int main(int argc, char** argv) {
     hipDeviceSynchronize();
     std::vector<unsigned long long> hs(256 * 8 * 4);
     hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost);
-    const int ntiles = ((s.M + 255) / 256) * ((s.N + 255) / 256), G = 8 * std::min(32, (ntiles + 7) / 8);
+    const int ntiles = tiles_of(s.M, s.N), G = 8 * std::min(32, (ntiles + 7) / 8);
     double tot = 0, lp = 0, ep = 0;
     for (int b = 0; b < G; ++b) { tot += hs[(b * 8) * 4]; lp += hs[(b * 8) * 4 + 1]; ep += hs[(b * 8) * 4 + 2]; }
     const double tiles_per_block = (double)ntiles / G;

@@ -1,12 +1,12 @@
 """Per-kernel-family time per step from a rocprofv3 kernel_trace.csv of bench.py (steps delimited by the AdamW launches)."""
 import csv, glob, collections, sys
-f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv") + glob.glob(sys.argv[1] + "/*_kernel_trace.csv"))[0]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 rows = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f)))
 idx = [i for i, r in enumerate(rows) if "adamw" in r[2]]
 a, b = idx[-nsteps - 1], idx[-1]
 seg = rows[a + 1:b + 1]
-FAM = ("gemm_nt", "gemm_nn", "gemm_tn", "reduce_parts", "attn_bwd", "attn_fwd", "ln_bwd", "ln_fwd", "adamw", "transpose", "cast_kernel", "scatter_add",
+FAM = ("gemm_p8h", "gemm_p8", "gemm_pk", "gemm_nt", "gemm_nn", "gemm_tn", "reduce_parts", "attn_bwd", "attn_fwd", "ln_bwd", "ln_fwd", "adamw", "transpose", "cast_kernel", "scatter_add",
        "smallk", "FillFunctor", "CatArray", "CUDAFunctor_add", "direct_copy", "MulFunctor", "reduce_kernel", "copyBuffer")
 agg = collections.defaultdict(lambda: [0, 0])
 for s, e, k in seg:

@@ -34,6 +34,8 @@ class EpisodeTensors:
             m = torch.arange(n)[None, :] < torch.tensor(lens)[:, None]
             self.hist_masks.append(m.to(dev))
         self._full = {}
+        # history length before each step, [T, B] (model_HAMT.py:62-63), resident: a captured step must not copy host data
+        self.hist_lens_dev = torch.tensor(ep.hist_lens, device=dev)
 
     def full(self, k):
         """Step inputs `k` of all T steps as ONE [T*B, ...] tensor (step t = rows [t B, (t + 1) B)), built once."""
@@ -158,7 +160,7 @@ def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=
     cls = model("history").expand(B, -1)                                                   # [B, H]
     H, dt = cls.shape[-1], cls.dtype
     ar = torch.arange(T, device=dev)
-    lens = torch.tensor(ep.hist_lens[:T], device=dev)                                       # [T, B] history length before step t (model_HAMT.py:62-63)
+    lens = et.hist_lens_dev[:T]                                                            # [T, B] history length before step t
     valid = ar[None, None, :] < lens[:, :, None]                                            # [step t, sample b, entry j]
     hm_full = valid.reshape(T * B, T).contiguous()
     # history inputs of all steps: sample (t, b) holds [CLS, h_0 .. h_{t-1}, 0 ...]. Entries beyond t are never written, so the buffer is

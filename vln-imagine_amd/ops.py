@@ -98,7 +98,10 @@ class EpisodeTape:
     def _exit(self):
         global _TAPE
         if self.mode == "record":
-            self.steps[self.key] = max(self.steps.get(self.key, 0), self.t + 1)
+            self.steps[self.key] = self.t + 1 if self.t == 0 else max(self.steps.get(self.key, 0), self.t + 1)
+            if self.t == 0 and self.i < len(self.bufs[self.key]):        # another program than the last episode's (e.g. NavCMT.visual_lang_rows
+                _KEEPALIVE.extend(self.bufs[self.key][self.i:])          # switched): step 0 defines it; an older capture may still use the rest
+                del self.bufs[self.key][self.i:]
         n_alloc, n_seed = self.i, self.si
         _TAPE = None
         self.key = self.mode = None
@@ -200,13 +203,19 @@ AUTOTUNE = True
 GEMM_VARIANTS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14)
 P8_VARIANT = 15          # 256 x 256 "8-phase" persistent kernel (v_mfma_16x16x32, one block per CU): tried for long launches only
 P8_MIN_ROWS = int(os.environ.get("VLNI_P8_MIN_ROWS", "6144"))
+P8H_VARIANT = 32         # (id 16) 256 x 128 tiles, three LDS buffers, four loader waves: step-long launches and narrow projections
+P8H_MIN_ROWS = int(os.environ.get("VLNI_P8H_MIN_ROWS", "1024"))
 _GEMM_BEST = {}
 
 
 def _nt_variants(rows, K, dtype):
-    if dtype in H16 and rows >= P8_MIN_ROWS and K % 128 == 0 and P8_VARIANT not in GEMM_VARIANTS and len(GEMM_VARIANTS) > 1:
-        return GEMM_VARIANTS + (P8_VARIANT,)
-    return GEMM_VARIANTS
+    v = GEMM_VARIANTS
+    if dtype in H16 and len(v) > 1:
+        if rows >= P8H_MIN_ROWS and K % 64 == 0 and K >= 128 and P8H_VARIANT not in v:
+            v = v + (P8H_VARIANT,)
+        if rows >= P8_MIN_ROWS and K % 128 == 0 and P8_VARIANT not in v:
+            v = v + (P8_VARIANT,)
+    return v
 
 
 class KN:
@@ -218,7 +227,9 @@ class KN:
         self.t = t
 
 
-NN_DGRAD = os.environ.get("VLNI_NN_DGRAD", "1") == "1"    # bf16 dgrad straight from W[out, in] through the transposing-read kernel: no W^T
+NN_DGRAD = os.environ.get("VLNI_NN_DGRAD", "0") == "1"    # (round 3: off. The 256-wide NT kernels on the W^T copy beat the transposing-read kernels on
+                         # every launch of >= 1 k rows: 885-909 vs 670-690 TF/s at K = 2304 / 3072 on a step's rows, tools/gemm_step_probe.py; the
+                         # copies cost one batched transpose per optimizer step.) bf16 dgrad straight from W[out, in] through the transposing-read kernel: no W^T
                          # shadows to rebuild after every optimizer step and half the shadow memory. Same-box A/B on the bench step
                          # (3 pairs): 37.5-37.8 ms vs 38.1 ms with NT kernels on W^T copies. (Before the LDS-DMA of that kernel was
                          # issued as asm it was the slower choice: the compiler serialised its copies with the reads.)
