@@ -44,12 +44,26 @@ def pytest_sessionstart(session):
         e = dict(env, **extra) if extra else {k: v for k, v in env.items() if k not in ("WORLD_SIZE",)}
         cmd = [sys.executable, "-m", "tests.dp_worker", out, "rank" if extra else "single"]
         DP["procs"].append((name, subprocess.Popen(cmd, cwd=ROOT, env=e, stdout=log, stderr=subprocess.STDOUT), log))
+    # bench.py's own multi-rank jobs run AFTER those workers (at most 6 processes may hold the GPU): tests/bench_runner.py waits for
+    # their result files, then starts the ranks itself - from a process that never touches the GPU (tests/test_bench_gpu.py)
+    log = open(os.path.join(out, "bench_runner.log"), "w")
+    benv = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    DP["bench"] = (subprocess.Popen([sys.executable, "-m", "tests.bench_runner", out], cwd=ROOT, env=benv, stdout=log, stderr=subprocess.STDOUT), log)
 
 
 def pytest_sessionfinish(session, exitstatus):
     for _, p, log in DP["procs"]:
         if p.poll() is None:
             p.kill()
+        log.close()
+    if DP.get("bench"):
+        p, log = DP["bench"]
+        if p.poll() is None:
+            open(os.path.join(DP["dir"], "stop"), "w").close()
+            try:
+                p.wait(timeout=5)
+            except subprocess.TimeoutExpired:
+                p.kill()                      # (its bench children finish on their own; they are bounded by --steps 2)
         log.close()
 
 

@@ -32,8 +32,9 @@ def imag_arrays():
     return {f"{100 + i}_{i % 3}": synth.det_uniform(f"h5/imag{i}", (1 + i % 4, 768), -0.5, 0.5).astype(np.float32) for i in range(5)}
 
 
-def h5import(path, arrays, chunks=None, gzip=None):
-    """One `h5import` call: every array as a raw little-endian file plus its configuration file (h5import's documented keywords)."""
+def h5import(path, arrays, chunks=None, gzip=None, append=False):
+    """One `h5import` call: every array as a raw little-endian file plus its configuration file (h5import's documented keywords).
+    append=True adds the datasets to an existing file (h5import takes at most 30 inputs per call)."""
     with tempfile.TemporaryDirectory() as tmp:
         cmd = [os.path.join(H5TOOLS, "h5import")]
         for i, (k, a) in enumerate(arrays.items()):
@@ -49,7 +50,7 @@ def h5import(path, arrays, chunks=None, gzip=None):
             with open(os.path.join(tmp, f"{i}.cfg"), "w") as f:
                 f.write("\n".join(cfg) + "\n")
             cmd += [os.path.join(tmp, f"{i}.bin"), "-c", os.path.join(tmp, f"{i}.cfg")]
-        if os.path.exists(path):
+        if os.path.exists(path) and not append:
             os.remove(path)
         subprocess.run(cmd + ["-o", path], check=True, capture_output=True)
 

@@ -192,7 +192,8 @@ def test_bf16_trainer_step_with_odd_sized_parameters():
         assert ops.SHADOWS._tr and ops.SHADOWS._tr_table is not None
         for lyr in m.global_encoder.encoder.x_layers:
             for w2 in (lyr.visn_inter.dense.weight, lyr.visn_output.dense.weight):
-                wt = ops._w((w2,), torch.bfloat16, True).resolve(64)            # a short launch: the maintained W^T copy
+                wt = ops._w((w2,), torch.bfloat16, True)                        # the maintained W^T copy (a WT handle with VLNI_NN_DGRAD=1)
+                wt = wt.resolve(64) if isinstance(wt, ops.WT) else wt
                 assert torch.equal(wt, w2.detach().bfloat16().t())
     finally:
         ops._WQ.clear()

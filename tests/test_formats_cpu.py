@@ -123,3 +123,22 @@ def test_library_reads_what_the_fixture_writer_writes(tmp_path, chunks, compress
         out = str(tmp_path / "d.bin")
         subprocess.run([os.path.join(H5TOOLS, "h5dump"), "-d", "/" + k, "-b", "LE", "-o", out, path], check=True, capture_output=True)
         assert np.array_equal(np.fromfile(out, a.dtype.newbyteorder("<")).reshape(a.shape), a), k
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(H5TOOLS, "h5import")), reason="HDF5 command-line tools not installed")
+def test_reader_walks_a_multi_level_group_btree_written_by_the_library(tmp_path):
+    """The real view-feature stores hold ~10 k keys: the root group's B-tree then has internal nodes above its symbol-table leaves and the
+    local heap has grown. 300 datasets written by the library's own h5import (> 2 * 16 * 8 + 1 keys force a level-1 tree)."""
+    import numpy as np
+    from tests.golden.make_hdf5_fixture import h5import
+    from vln_imagine_amd.hdf5_lite import Hdf5File
+    arrays = {f"scan{(i * 7) % 11:02d}_vp{i:04d}": np.full((2, 3), float(i), np.float32) + np.arange(6, dtype=np.float32).reshape(2, 3) / 8
+              for i in range(300)}
+    path = str(tmp_path / "many.hdf5")
+    keys = list(arrays)
+    for c in range(0, len(keys), 25):
+        h5import(path, {k: arrays[k] for k in keys[c:c + 25]}, append=c > 0)
+    f = Hdf5File(path)
+    assert sorted(f.keys()) == sorted(arrays)
+    for k in list(arrays)[::37] + [list(arrays)[-1]]:
+        assert np.array_equal(f.dataset(k), arrays[k]), k

@@ -108,7 +108,8 @@ def test_product_bf16_tracks_fp32():
             continue
         num += float((p16.grad.double() - p32.grad.double()).pow(2).sum())
         den += float(p32.grad.double().pow(2).sum())
-    assert (num / den) ** 0.5 < 0.1, (num / den) ** 0.5
+    # (what bf16 gives here: the CPU oracle under torch.autocast(bfloat16) is 0.11 from its float32 self on the full-depth model, tools/bf16_error_study.py)
+    assert (num / den) ** 0.5 < 0.13, (num / den) ** 0.5
 
 
 def test_flat_trainer_direct_grads_match_autograd():

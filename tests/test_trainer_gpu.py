@@ -101,7 +101,7 @@ def test_optimizer_state_dict_round_trip():
         # Adam's amplification of atomics-order noise on ~zero gradients
         assert d.max().item() < 5e-4 and d.mean().item() < 1e-6, (d.max().item(), d.mean().item())
         # and the layout is what torch.optim.AdamW loads
-        plist = [p for p in m2.parameters() if p.requires_grad]
+        plist = list(m2.parameters())
         opt = torch.optim.AdamW(plist, lr=LR)
         tmpl = opt.state_dict()
         tmpl["state"] = sd_opt["state"]
@@ -109,6 +109,64 @@ def test_optimizer_state_dict_round_trip():
         assert torch.equal(opt.state[plist[3]]["exp_avg"].cpu(), sd_opt["state"][3]["exp_avg"].cpu())
     finally:
         t2.close()
+
+
+def test_optimizer_checkpoints_of_a_model_with_frozen_parameters_travel_both_ways():
+    """The shipped run passes --fix_lang_embedding (update_lang_bert=False): the reference builds AdamW from ALL vln_bert.parameters()
+    (r2r/agent_cmt.py:98), so indices count the frozen tensors too and only the optimised ones have state. FlatTrainer(groups=None) keeps
+    that index space: a torch.optim.AdamW state_dict loads into it, and its own state_dict loads into torch.optim.AdamW."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_shipped")
+    et = EpisodeTensors(ep, "cuda")
+    ref, m = build_product(cfg), build_product(cfg)
+    frozen = [i for i, p in enumerate(ref.parameters()) if not p.requires_grad]
+    assert frozen and len(frozen) < len(list(ref.parameters()))
+    opt = torch.optim.AdamW(ref.parameters(), lr=LR, weight_decay=0.01)
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        run_episode(ref, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+        torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.grad is not None], 40.0)
+        opt.step()
+    sr = opt.state_dict()
+    assert not any(i in sr["state"] for i in frozen)                       # torch skips parameters without a gradient
+    m.load_state_dict(ref.state_dict())
+    flags = [p.requires_grad for p in m.parameters()]
+    tr = FlatTrainer(m, lr=LR)
+    try:
+        assert [p.requires_grad for p in m.parameters()] == flags           # the constructor unfreezes nothing
+        assert all(id(p) not in tr._off for p, f in zip(m.parameters(), flags) if not f)
+        tr.load_state_dict(sr)
+        plist = list(m.parameters())
+        live = [i for i, f in enumerate(flags) if f and i in sr["state"]]
+        for i in (live[0], live[len(live) // 2], live[-1]):
+            o, nel = tr._off[id(plist[i])], plist[i].numel()
+            assert torch.equal(tr.m[o:o + nel].view(plist[i].shape), sr["state"][i]["exp_avg"])
+            assert torch.equal(tr.v[o:o + nel].view(plist[i].shape), sr["state"][i]["exp_avg_sq"])
+        assert tr.step_no == 2
+        # one more step on both sides from the loaded state: the replicas stay together
+        opt.zero_grad(set_to_none=True)
+        run_episode(ref, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+        torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.grad is not None], 40.0)
+        opt.step()
+        tr.zero_grad()
+        run_episode(m, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+        tr.step()
+        worst = max((p - q).abs().max().item() for p, q in zip(m.parameters(), ref.parameters()))
+        assert worst < 4 * LR, worst
+        for i in frozen:
+            assert torch.equal(plist[i], list(ref.parameters())[i])           # frozen tensors: untouched on both sides
+        # and back: this trainer's state_dict is what torch.optim.AdamW(model.parameters()) loads
+        sd = tr.state_dict()
+        assert sd["param_groups"][0]["params"] == sr["param_groups"][0]["params"]
+        assert set(sd["state"]) == set(opt.state_dict()["state"])
+        opt2 = torch.optim.AdamW(ref.parameters(), lr=LR, weight_decay=0.01)
+        opt2.load_state_dict({"state": sd["state"], "param_groups": sd["param_groups"]})
+        rp = list(ref.parameters())
+        assert torch.allclose(opt2.state[rp[live[0]]]["exp_avg"], opt.state[rp[live[0]]]["exp_avg"], rtol=0, atol=2e-5)
+        assert float(opt2.state[rp[live[0]]]["step"]) == 3.0
+    finally:
+        tr.close()
 
 
 def test_marks_are_scoped_to_the_trainers_parameters():

@@ -530,28 +530,60 @@ __global__ __launch_bounds__(256) void adamw_groups_kernel(float* __restrict__ p
                                                            float eps, float wd, const float* __restrict__ state) {
   if (state[5] != 0.f) return;                                   // skipped step: parameters, moments and mirror stay
   const float cc = state[0];
-  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  const long stride = (long)gridDim.x * blockDim.x * 4;
-  for (; i < n; i += stride) {
-    int k = 0;
-    while (k + 1 < ngrp && i >= grp_end[k]) ++k;                 // groups start on 8-element boundaries: a float4 never straddles
-    if (grp_lr[ngrp + k] == 0.f) continue;
-    const float lr = grp_lr[k], bc1 = gstate[4 * k + 1], rbc2 = 1.f / sqrtf(gstate[4 * k + 2]);
-    f32x4 pv = *(f32x4*)(p + i), gv = *(const f32x4*)(g + i), mv = *(f32x4*)(m + i), vv = *(f32x4*)(v + i);
+  // Two float4 groups per thread and iteration, every load of both issued before the first use (8 x 16 B per lane in flight), streaming
+  // (non-temporal) accesses: the four arrays are 4 x 430 MB per step and nothing is re-read before the next step (the mirror is: plain store).
+  const long T = (long)gridDim.x * blockDim.x * 4;
+  long i0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  for (; i0 < n; i0 += 2 * T) {
+    long idx[2] = {i0, i0 + T};
+    bool on[2];
+    float lr[2], bc1[2], rbc2[2];
+    f32x4 pv[2], gv[2], mv[2], vv[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float gg = gv[j] * cc;
-      pv[j] *= (1.f - lr * wd);
-      mv[j] = b1 * mv[j] + (1.f - b1) * gg;
-      vv[j] = b2 * vv[j] + (1.f - b2) * gg * gg;
-      const float denom = sqrtf(vv[j]) * rbc2 + eps;
-      pv[j] -= (lr / bc1) * mv[j] / denom;
+    for (int u = 0; u < 2; ++u) {
+      const long i = idx[u];
+      on[u] = i < n;
+      if (!on[u]) continue;
+      int k = 0;
+      while (k + 1 < ngrp && i >= grp_end[k]) ++k;               // groups start on 8-element boundaries: a float4 never straddles
+      on[u] = grp_lr[ngrp + k] != 0.f;
+      if (!on[u]) continue;
+      lr[u] = grp_lr[k]; bc1[u] = gstate[4 * k + 1]; rbc2[u] = 1.f / sqrtf(gstate[4 * k + 2]);
+      pv[u] = __builtin_nontemporal_load((const f32x4*)(p + i));
+      gv[u] = __builtin_nontemporal_load((const f32x4*)(g + i));
+      mv[u] = __builtin_nontemporal_load((const f32x4*)(m + i));
+      vv[u] = __builtin_nontemporal_load((const f32x4*)(v + i));
     }
-    *(f32x4*)(p + i) = pv; *(f32x4*)(m + i) = mv; *(f32x4*)(v + i) = vv;
-    if (shadow) {
-      typedef SH sh4 __attribute__((ext_vector_type(4)));
-      sh4 s = {(SH)pv[0], (SH)pv[1], (SH)pv[2], (SH)pv[3]};
-      *(sh4*)(shadow + i) = s;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!on[u]) continue;
+      const long i = idx[u];
+      // An element that has never received a gradient (g, m and v all exactly zero: a parameter behind a detach() - the embeddings under
+      // --fix_lang_embedding - or an unused head) is left alone, weight decay included: torch.optim.AdamW skips parameters whose
+      // .grad is None the same way (r2r/agent_cmt.py:98 builds it over ALL parameters). A float4 of such elements is not even stored.
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool live = gv[u][j] != 0.f || mv[u][j] != 0.f || vv[u][j] != 0.f;
+        any |= live;
+        const float gg = gv[u][j] * cc;
+        const float p0 = pv[u][j] * (1.f - lr[u] * wd);
+        const float m1 = b1 * mv[u][j] + (1.f - b1) * gg;
+        const float v1 = b2 * vv[u][j] + (1.f - b2) * gg * gg;
+        const float denom = sqrtf(v1) * rbc2[u] + eps;
+        pv[u][j] = live ? p0 - (lr[u] / bc1[u]) * m1 / denom : pv[u][j];
+        mv[u][j] = m1;                                        // (0 where nothing was ever added)
+        vv[u][j] = v1;
+      }
+      if (!any) continue;
+      __builtin_nontemporal_store(pv[u], (f32x4*)(p + i));
+      __builtin_nontemporal_store(mv[u], (f32x4*)(m + i));
+      __builtin_nontemporal_store(vv[u], (f32x4*)(v + i));
+      if (shadow) {
+        typedef SH sh4 __attribute__((ext_vector_type(4)));
+        sh4 s = {(SH)pv[u][0], (SH)pv[u][1], (SH)pv[u][2], (SH)pv[u][3]};
+        *(sh4*)(shadow + i) = s;
+      }
     }
   }
 }

@@ -104,8 +104,11 @@ class HamtGraphBuckets:
         self.head = getattr(model, "contrastive_alignment_model", None)
 
     def key_for(self, ep):
-        L = next(x for x in self.l_buckets if x >= ep.L)
-        V = next(x for x in self.v_buckets if x >= ep.V)
+        L = next((x for x in self.l_buckets if x >= ep.L), None)
+        V = next((x for x in self.v_buckets if x >= ep.V), None)
+        if L is None or V is None:
+            raise ValueError(f"episode with {ep.L} text tokens / {ep.V} observation tokens exceeds the largest bucket "
+                             f"(l_buckets {self.l_buckets}, v_buckets {self.v_buckets})")
         return (L, V, ep.T)
 
     def _fwd_bwd(self, key):
@@ -120,7 +123,10 @@ class HamtGraphBuckets:
             finally:
                 if self.head is not None:
                     self.head.set_static_plan(None)
-            out["loss"].backward()
+            if self.model.compute_dtype == torch.float16:          # the fused step divides the trainer's loss scale out again
+                (out["loss"] * self.trainer.loss_scale).backward()
+            else:
+                out["loss"].backward()
             outs["logits"] = [t.detach() for t in out["logits"]]
             return out["loss"].detach()
         return fwd_bwd

@@ -8,6 +8,8 @@ ignore_index -100) and :746-752 (loss = ml * train_ml / B + cosine_weight * aux)
 (models/vilmodel_cmt.py:999-1205): the reference itself, the CPU oracle, or the HIP
 product model, so all three are driven by the very same code.
 """
+import contextlib
+
 import torch
 import torch.nn.functional as F
 
@@ -135,7 +137,7 @@ def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2,
 
 
 def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
-                      ghost_compute=False):
+                      ghost_compute=False, overlap_history=True):
     """Step-by-step FORWARD - the call pattern a sampled rollout needs: step t + 1's observation may depend on the action chosen from step
     t's logits (`on_step(t, logits, states)`, r2r/agent_cmt.py:498-606) - and ONE episode-batched BACKWARD (vln_imagine_amd.ops.EpisodeTape):
     the T `visual` / `history` calls write their activations into slices of episode-wide buffers, a ghost pass of the same model code
@@ -143,7 +145,10 @@ def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=
     Valid because no transformer output of step t enters step t + 1's input: history tokens are re-encoded from features
     (vilmodel_cmt.py:576-618, 1056-1205). Every step sees the history padded to T entries ([CLS, h_0 .. h_{t-1}, 0 ..] with the mask of
     model_HAMT.py:62-63); logits, loss and gradients equal run_episode's to rounding (tests/test_tape_gpu.py).
-    ghost_compute=True (tests): the batched pass COMPUTES with the recorded dropout seeds instead of reusing the steps' buffers."""
+    ghost_compute=True (tests): the batched pass COMPUTES with the recorded dropout seeds instead of reusing the steps' buffers.
+    overlap_history: step t's `history` call (the panorama encoder: 2.3 k-row launches that fill a fifth of the chip) runs on a second
+    stream beside step t's `visual` call - both read features and h_0 .. h_{t-1} only - and its ghost pass is recorded on that stream, so
+    autograd runs the history encoder's batched backward there too, beside the text encoder's."""
     from vln_imagine_amd import ops
     ep, B, T = et.ep, et.B, et.T
     dev = et.txt_ids.device
@@ -171,9 +176,29 @@ def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=
     with torch.no_grad():
         hb[:, :, 0] = cls
     f = et.full
+    for k in ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats", "ob_img_feats", "ob_ang_feats",
+              "ob_nav_types", "ob_masks", "target"):
+        f(k)                                                   # built (once) on the main stream before any side-stream reader
+    main = torch.cuda.current_stream() if dev.type == "cuda" else None
+    side = None
+    if overlap_history and main is not None:
+        side = getattr(tape, "_side", None)
+        if side is None:
+            side = tape._side = torch.cuda.Stream()
+
+    def history_step(t, sl):
+        with tape.record("history", t):
+            return model("history", hist_img_feats=f("hist_img_feats")[sl], hist_ang_feats=f("hist_ang_feats")[sl],
+                         ob_step_ids=et.step_ids[t], hist_pano_img_feats=f("hist_pano_img_feats")[sl],
+                         hist_pano_ang_feats=f("hist_pano_ang_feats")[sl])
+
     step_logits = []
     for t in range(T):
         sl = slice(t * B, (t + 1) * B)
+        if side is not None:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                h = history_step(t, sl)
         with tape.record("visual", t):
             lg, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm_full[sl],
@@ -182,18 +207,23 @@ def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=
         step_logits.append(lg)
         if on_step is not None:
             on_step(t, lg, txt_o[:, 0] * hist_o[:, 0])
-        with tape.record("history", t):
-            h = model("history", hist_img_feats=f("hist_img_feats")[sl], hist_ang_feats=f("hist_ang_feats")[sl],
-                      ob_step_ids=et.step_ids[t], hist_pano_img_feats=f("hist_pano_img_feats")[sl],
-                      hist_pano_ang_feats=f("hist_pano_ang_feats")[sl])
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            h = history_step(t, sl)
         if t + 1 < T:
             with torch.no_grad():
                 hb[t + 1:, :, t + 1] = h * valid[t + 1:, :, t + 1, None].to(h.dtype)
     # ---- ghost pass: the same two calls on the T x B samples; no kernels, only the autograd graph over the filled buffers ----
-    with tape.ghost("history", compute=ghost_compute):
-        h_all = model("history", hist_img_feats=f("hist_img_feats"), hist_ang_feats=f("hist_ang_feats"),
-                      ob_step_ids=ar.repeat_interleave(B), hist_pano_img_feats=f("hist_pano_img_feats"),
-                      hist_pano_ang_feats=f("hist_pano_ang_feats"))
+    if side is not None:
+        side.wait_stream(main)
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        with tape.ghost("history", compute=ghost_compute):
+            h_all = model("history", hist_img_feats=f("hist_img_feats"), hist_ang_feats=f("hist_ang_feats"),
+                          ob_step_ids=ar.repeat_interleave(B), hist_pano_img_feats=f("hist_pano_img_feats"),
+                          hist_pano_ang_feats=f("hist_pano_ang_feats"))
+    if side is not None:
+        main.wait_stream(side)
     prefix = torch.cat([cls.to(h_all.dtype).unsqueeze(0), h_all.view(T, B, H)[:T - 1]], 0)    # entries 0 .. T-1 as [entry, B, H]
     hist = prefix.permute(1, 0, 2).unsqueeze(0) * valid.to(h_all.dtype)[:, :, :, None]        # [T, B, T, H], zeros beyond the valid entries
     rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))

@@ -26,8 +26,9 @@ class Hdf5File:
     """Read-only view of a classic HDF5 file: keys() of the root group and dataset(key) -> numpy array."""
 
     def __init__(self, path):
-        with open(path, "rb") as f:
-            self.buf = f.read()
+        import mmap
+        with open(path, "rb") as f:                             # mapped, not read: the view-feature stores are > 1 GB and every rank opens them
+            self.buf = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
         b = self.buf
         if b[:8] != SIG:
             raise ValueError(f"{path}: not an HDF5 file")
@@ -64,7 +65,7 @@ class Hdf5File:
         return self.base + self._u64(a + 24)
 
     def _name(self, heap_data, off):
-        e = self.buf.index(b"\0", heap_data + off)
+        e = self.buf.find(b"\0", heap_data + off)
         return self.buf[heap_data + off:e].decode()
 
     def _walk_group(self, addr, heap_data):

@@ -849,6 +849,7 @@ def _bgrad_to(params, dy):
 # Deferred weight gradients (parameters marked `_vlni_defer` by train.FlatTrainer): the (dY, X) pairs of a parameter are
 # queued during backward and reduced by ONE grouped transposing-read GEMM per parameter at flush time, i.e. one launch
 # with a T-times longer reduction instead of T short split-K launches. 288 GB of HBM make keeping dY alive free.
+RESERVE_CUS = 0          # > 0 (train.FlatTrainer with a gradient exchange): one-round weight-gradient launches leave this many CUs free
 TN_BIG = True            # 256 x 256 tiles for episode-long reductions (+10..26 % there, tools/tn_probe.py)
 TN_VARIANT = 5          # LDS-DMA 2-stage, 8 waves: fastest of the five on every episode-level shape (tools/tn_probe.py)
 _WQ = {}
@@ -893,10 +894,10 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev, dtid=BF16):
     if best is not None or torch.cuda.is_current_stream_capturing():
         return best or default
     t128 = ((N + 127) // 128) * ((K + 127) // 128)
-    cands = {(TN_VARIANT, max(1, min(s, nmt // 3))) for s in (2, 3, 4, 6, 8, 12, 16, max(1, round(512 / t128)))}
+    cands = {(TN_VARIANT, max(1, min(s, nmt // 3))) for s in (2, 3, 4, 6, 8, 12, 16, max(1, round((512 - 2 * RESERVE_CUS) / t128)))}
     if TN_BIG and N >= 256 and K >= 256 and nmt >= 32:
         t256 = ((N + 255) // 256) * ((K + 255) // 256)
-        s6 = max(1, min(nmt // 4, round(252 / t256)))
+        s6 = max(1, min(nmt // 4, round((252 - RESERVE_CUS) / t256)))
         cands |= {(v, sp) for v in (6, 7) for sp in (s6, max(1, s6 // 2), max(1, (3 * s6) // 4), min(nmt // 4, 2 * s6))}
     smax = max(_eff_split(nmt, sp)[0] for _, sp in cands)
     scratch = torch.zeros((smax * (N * K + N),), dtype=torch.float32, device=dev)
@@ -942,7 +943,7 @@ def _tn_batch_choice(P, n, pa, pb, pm, N, K, nmt_p, dev, dtid):
     t128, t256 = -(-N // 128) * -(-K // 128), -(-N // 256) * -(-K // 256)
     cands = set()
     for v, tiles in ((TN_VARIANT, t128),) + (((6, t256), (7, t256)) if TN_BIG and N >= 256 and K >= 256 else ()):
-        want = max(1.0, (512 if v == TN_VARIANT else 250) / (P * tiles))           # splits per gradient for about one round of blocks
+        want = max(1.0, ((512 if v == TN_VARIANT else 250) - (2 if v == TN_VARIANT else 1) * RESERVE_CUS) / (P * tiles))   # ~ one round of blocks
         near = sorted(divs, key=lambda d: abs(d - want))[:3]
         cands |= {(v, d) for d in near}
     smax = max(sp for _, sp in cands) * P

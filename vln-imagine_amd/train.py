@@ -6,6 +6,8 @@ Restates the tail of Seq2SeqCMTAgent.train (VLN-HAMT/finetune_src/r2r/agent_cmt.
 zero_grad, backward, clip_grad_norm_(40.), AdamW step; DDP's constructor broadcast and gradient
 averaging (:61-63); the three optimizer parameter groups of the shipped "variant4" warm-up
 (:82-96, r2r/main.py:202-255); and the optimizer part of the checkpoints (:837-870)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -14,6 +16,28 @@ from . import _lib, ops
 
 def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def _exchange():
+    """True when the gradient exchange runs: several ranks - or ONE rank with VLNI_FORCE_COLLECTIVES=1, which sends the whole flush ->
+    side-stream all-reduce -> graph pipeline through the process group on a one-GPU box (a 1-rank RCCL communicator still launches its
+    kernels, keeps its watchdog thread alive beside the graph captures, and completes work objects asynchronously)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("VLNI_FORCE_COLLECTIVES") == "1"
+
+
+def sync_autotune(src=0):
+    """Every rank adopts rank `src`'s kernel choices (GEMM pipelines per shape, weight-gradient variant x split): the ranks time their
+    candidates independently, and a different winner on one rank is a different step time under a max-over-ranks clock."""
+    if _world() == 1:
+        return
+    box = [(dict(ops._GEMM_BEST), dict(ops._TN_BEST), dict(ops._TNB_BEST))] if dist.get_rank() == src else [None]
+    dist.broadcast_object_list(box, src=src)
+    if dist.get_rank() != src:
+        for mine, theirs in zip((ops._GEMM_BEST, ops._TN_BEST, ops._TNB_BEST), box[0]):
+            mine.clear()
+            mine.update(theirs)
 
 
 def _all_reduce_sum(t, async_op=False):
@@ -106,22 +130,35 @@ def reduce_range_(flat, lo, hi, ws, chunk_elems, comm_dtype=None):
 class FlatTrainer:
     """clip_grad_norm_ + AdamW over flat arenas, with torch.optim-style parameter groups.
 
-    groups=None: one group of every parameter that requires a gradient (lr). Otherwise a list of dicts like torch.optim's
-    param_groups - {"params": iterable, "lr": float (default lr), "trainable": bool (default True), "name": str} - and EVERY
-    listed parameter goes into the arena whether or not it currently requires a gradient, so that a later stage can switch a
-    group on (`set_group`). Per group the learning rate and the trainable flag live in device memory: changing them is a small
-    device write that a captured step picks up on its next replay (switching `trainable` also flips requires_grad, which changes
-    the autograd graph: capture again after it).
+    groups=None: ONE group of ALL model.parameters(), like the reference's `optimizer(self.vln_bert.parameters(), lr)` (r2r/agent_cmt.py:98).
+    Otherwise a list of dicts like torch.optim's param_groups - {"params": iterable, "lr": float (default lr), "trainable": bool (default
+    True), "name": str}. The position of a parameter in its group's list is its index in state_dict() / load_state_dict(), exactly as in
+    torch.optim, so checkpoints travel both ways whether or not some parameters are frozen.
+
+    What goes into the arena: every listed parameter that requires a gradient, plus every parameter of a group declared trainable=False
+    (a later stage switches it on with `set_group`; declaring it off also clears requires_grad, like set_group(trainable=False)). A
+    parameter the MODEL froze (requires_grad False inside a trainable group: --fix_lang_embedding, update_lang_bert=False) keeps its flag and
+    stays outside the arena: it has an index, never a state entry - torch.optim.AdamW skips parameters without a gradient the same way.
+    requires_grad is only ever set by set_group() (and by declaring a group off), never switched ON here.
+
+    Per group the learning rate and the trainable flag live in device memory: changing them is a small device write that a captured step
+    picks up on its next replay (switching `trainable` also flips requires_grad, which changes the autograd graph: capture again after it).
 
     Only the parameters of THIS trainer are marked for direct gradient accumulation / deferred weight gradients (ops._direct,
-    ops._wb_grad_to look at the marks): other models in the process keep plain autograd accumulation."""
+    ops._wb_grad_to look at the marks): other models in the process keep plain autograd accumulation.
+
+    Parameters that never receive a gradient (behind a detach(): the embeddings under --fix_lang_embedding; unused heads) are left alone
+    by the step kernel, weight decay included, and have no state entry - like torch.optim.AdamW's grad-None parameters. The rule is per
+    ELEMENT (g, m, v all exactly zero), so a row of an embedding table that no batch has touched yet does not decay either, where torch
+    decays the whole tensor once any row has a gradient; and a parameter that did receive gradients keeps being updated (its moments
+    decay) in a later step in which its gradient happens to be missing, where torch would skip that step for it."""
 
     def __init__(self, model, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=40.0,
                  chunk_mb=128, grad_comm_dtype=None, groups=None, broadcast=True, overlap_chunks=4,
                  loss_scale=None, growth_interval=0):
         self.model = model
         if groups is None:
-            groups = [{"params": [p for p in model.parameters() if p.requires_grad], "lr": lr, "name": "all"}]
+            groups = [{"params": list(model.parameters()), "lr": lr, "name": "all"}]
         assert 1 <= len(groups) <= 8, "1..8 parameter groups"
         # arena order, group by group: inside a group the q/k/v projections of every attention module sit back to back (weights,
         # then biases), so the packed [2304,768] QKV gradient is ONE wgrad GEMM into a contiguous view (ops._packed_grad)
@@ -136,10 +173,14 @@ class FlatTrainer:
         self._units = []                    # (first offset, elements) of what a flush chunk / all-reduce chunk must not split
         offs, n = {}, 0
         for gi, g in enumerate(groups):
-            plist = list(g["params"])
-            assert plist, f"parameter group {gi} is empty"
+            listed = list(g["params"])
+            assert listed, f"parameter group {gi} is empty"
+            assert not ({id(p) for p in listed} & seen), "a parameter appears in two groups"
+            seen |= {id(p) for p in listed}
+            on = bool(g.get("trainable", True))
+            plist = [p for p in listed if p.requires_grad or not on]      # the rest: frozen by the model, index only (class docstring)
+            assert plist, f"parameter group {gi} ({g.get('name', gi)}) has no parameter that requires a gradient"
             ids = {id(p) for p in plist}
-            assert not (ids & seen), "a parameter appears in two groups"
             order, placed = [], set()
             for unit in qkv_units:
                 if all(id(p) in ids for p in unit) and not any(id(p) in placed for p in unit):
@@ -153,9 +194,8 @@ class FlatTrainer:
                     self.params.append(p)
                     n += (p.numel() + 7) // 8 * 8     # slots aligned to 16 bytes in the 16-bit mirror too (32 B in float32)
                 self._units.append((u0, n - u0))
-            seen |= ids
-            self.groups.append({"name": g.get("name", f"group{gi}"), "params": plist, "lr": float(g.get("lr", lr)),
-                                "trainable": bool(g.get("trainable", True)), "end": n})
+            self.groups.append({"name": g.get("name", f"group{gi}"), "params": plist, "listed": listed, "lr": float(g.get("lr", lr)),
+                                "trainable": on, "end": n})
         self._off = offs
         self.n = n
         dev = self.params[0].device
@@ -187,12 +227,14 @@ class FlatTrainer:
         self.growth_interval = int(growth_interval)
         self.state[4] = float(loss_scale) if loss_scale else 1.0
         for g in self.groups:
-            for p in g["params"]:
-                p.requires_grad_(g["trainable"])
+            if not g["trainable"]:              # a group declared off: as set_group(trainable=False). Nothing is ever switched ON here.
+                for p in g["params"]:
+                    p.requires_grad_(False)
         self.chunk = chunk_mb * (1 << 20) // 4
         self.grad_comm_dtype = grad_comm_dtype
         self.overlap_chunks = max(1, int(overlap_chunks))
         self._side = None
+        self.time_exchange = False          # True: allreduce_grads records HIP events for exchange_report()
         self.graph_epoch = 0
         # compute-dtype mirror of the parameter arena, kept current by the AdamW kernel (ops.ShadowCache hands out views of it):
         # bfloat16, or float16 when the model computes in float16 (then pair it with loss_scale / growth_interval)
@@ -200,6 +242,10 @@ class FlatTrainer:
         self.flat_b = torch.empty(n, dtype=cd if cd in ops.H16 else torch.bfloat16, device=dev)
         if broadcast and _world() > 1:
             self.broadcast_from(0)
+        if _exchange():
+            # leave a few CUs' worth of every one-round weight-gradient launch to the collective's own kernels: a launch sized for all 256
+            # CUs gives RCCL no CU until one of its (100+ us) tiles retires. Costs the flush ~3 % where a launch is exactly one round.
+            ops.RESERVE_CUS = int(os.environ.get("VLNI_RESERVE_CUS", "8"))
         ops.SHADOWS.set_arena(self.flat_p, self.flat_b)
 
     # ---- replicas ---------------------------------------------------------------------------------------------------
@@ -274,7 +320,7 @@ class FlatTrainer:
         (DDP overlaps its buckets with backward the same way, r2r/agent_cmt.py:61-63,827). flushers: per-range callables
         (captured graphs) instead of eager launches."""
         ws = _world()
-        if ws == 1:
+        if not _exchange():
             if flushers is None:
                 self.flush()
             else:
@@ -285,6 +331,9 @@ class FlatTrainer:
             self._side = torch.cuda.Stream()
         main = torch.cuda.current_stream()
         ranges = self.comm_ranges()
+        timed = self.time_exchange
+        if timed:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         for k, (lo, hi) in enumerate(ranges):
             if flushers is None:
                 self.flush(lo, hi)
@@ -292,8 +341,26 @@ class FlatTrainer:
                 flushers[k]()
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
+                if timed and k == 0:
+                    ev[0].record()
                 self._reduce_range(lo, hi, ws)
+        if timed:
+            ev[1].record(main)                 # the last flush is done: from here on the main stream only waits for the exchange
+            ev[2].record(self._side)
+            self._exchange_events = ev
         main.wait_stream(self._side)
+
+    def exchange_report(self):
+        """After a step with time_exchange = True: what the gradient exchange cost (HIP events; call after a synchronize)."""
+        ev = getattr(self, "_exchange_events", None)
+        if ev is None:
+            return None
+        ranges = self.comm_ranges()
+        es = 2 if self.grad_comm_dtype in (torch.bfloat16, torch.float16) else 4
+        return {"exposed_ms": round(max(0.0, ev[1].elapsed_time(ev[2])), 3),      # exchange still running after the last flush kernel
+                "exchange_span_ms": round(ev[0].elapsed_time(ev[2]), 3),           # first range's pack -> last range's unpack
+                "ranges": len(ranges), "payload_bytes_per_range": [(hi - lo) * es for lo, hi in ranges],
+                "payload_dtype": str(self.grad_comm_dtype or torch.float32).replace("torch.", "")}
 
     def step(self):
         self.flush()
@@ -316,16 +383,17 @@ class FlatTrainer:
 
     # ---- checkpoints (the 'optimizer' entry of r2r/agent_cmt.py:837-870) -------------------------------------------------
     def state_dict(self):
-        """torch.optim.AdamW's layout: state[i] = {step, exp_avg, exp_avg_sq} with i counting the parameters group by group in
-        the order they were given, param_groups[k] = {lr, betas, eps, weight_decay, params: [i...]}."""
+        """torch.optim.AdamW's layout: param_groups[k]["params"] = the indices of the group's parameters in the order they were given
+        (parameters the model froze included), state[i] = {step, exp_avg, exp_avg_sq} for the parameters that are optimised."""
         _, b1, b2, eps, wd = self.hp
         steps = self.gstate.view(-1, 4)[:, 0].tolist()
         state, pgs, i = {}, [], 0
         for k, g in enumerate(self.groups):
             ids = []
-            for p in g["params"]:
-                o = self._off[id(p)]
-                if steps[k] > 0:
+            for p in g["listed"]:
+                o = self._off.get(id(p))
+                # no entry for a parameter that never received a gradient (all-zero moments: the step kernel left it alone), as in torch
+                if o is not None and steps[k] > 0 and bool(self.v[o:o + p.numel()].any()):
                     state[i] = {"step": torch.tensor(float(steps[k])), "exp_avg": self.m[o:o + p.numel()].view(p.shape).clone(),
                                 "exp_avg_sq": self.v[o:o + p.numel()].view(p.shape).clone()}
                 ids.append(i)
@@ -336,19 +404,24 @@ class FlatTrainer:
                 "vlni": {"step_no": self.step_no, "loss_scale": float(self.state[4]), "good_steps": float(self.state[6])}}
 
     def load_state_dict(self, sd):
+        """Takes this class's own state_dict() and torch.optim.AdamW's (e.g. the 'optimizer' entry of a reference checkpoint, r2r/agent_cmt.py:
+        837-870): indices count the parameters of a group in the order they were given; entries of parameters outside the arena (frozen by
+        the model) are ignored, missing entries start from zero moments."""
         G = len(self.groups)
         assert len(sd["param_groups"]) == G, "optimizer state has a different number of parameter groups"
         gs = torch.zeros(G, 4)
         _, b1, b2, _, _ = self.hp
         with torch.no_grad():
-            i = 0
             for k, (g, pg) in enumerate(zip(self.groups, sd["param_groups"])):
-                assert len(pg["params"]) == len(g["params"]), f"group {k}: parameter count differs"
+                assert len(pg["params"]) == len(g["listed"]), \
+                    f"group {k}: the state lists {len(pg['params'])} parameters, this trainer's group has {len(g['listed'])}"
                 self.set_group(k, lr=pg["lr"], trainable=pg.get("trainable", g["trainable"]))
                 t = 0.0
-                for p in g["params"]:
+                for p, i in zip(g["listed"], pg["params"]):
+                    o = self._off.get(id(p))
+                    if o is None:
+                        continue
                     st = sd["state"].get(i)
-                    o = self._off[id(p)]
                     if st is not None:
                         self.m[o:o + p.numel()].copy_(st["exp_avg"].reshape(-1))
                         self.v[o:o + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
@@ -356,7 +429,6 @@ class FlatTrainer:
                     else:
                         self.m[o:o + p.numel()].zero_()
                         self.v[o:o + p.numel()].zero_()
-                    i += 1
                 gs[k] = torch.tensor([t, 1.0 - b1 ** t, 1.0 - b2 ** t, 0.0])
             self.gstate.copy_(gs.reshape(-1))
             extra = sd.get("vlni", {})
@@ -417,9 +489,12 @@ class GraphedStep:
         # dropout: the seeds recorded in the graph are constants, their device-resident base moves on every replay
         self.seed_base = torch.zeros(1, dtype=torch.int32, device=trainer.flat_p.device)
         ops.set_seed_base(self.seed_base)
-        split = _world() > 1
+        split = _exchange()
+        # With a process group alive its watchdog thread may make HIP calls while this thread captures: capture in thread-local error
+        # mode so that those calls neither fail nor invalidate the capture (torch's default "global" mode would do both)
+        mode = dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
         self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
+        with torch.cuda.graph(self.g_fb, **mode):
             self.seed_base.add_(7919)
             trainer.zero_grad()
             self.loss = fwd_bwd()
@@ -433,12 +508,12 @@ class GraphedStep:
                     self.g_flush.append(None)              # nothing deferred in this range (small parameters only)
                     continue
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.g_fb.pool()):
+                with torch.cuda.graph(g, pool=self.g_fb.pool(), **mode):
                     trainer.flush(lo, hi)
                 self.g_flush.append(g)
             assert not ops._WQ, "a queued weight gradient lies outside every flush range"
         self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool()):
+        with torch.cuda.graph(self.g_opt, pool=self.g_fb.pool(), **mode):
             trainer.step()
         trainer.step_no -= 1                   # recorded, not executed
 
