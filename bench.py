@@ -297,7 +297,19 @@ def main():
         # "nccl" IS RCCL on ROCm; VLNI_DIST_BACKEND=gloo + VLNI_ONE_GPU=1 rehearse the multi-rank path on a 1-GPU box
         backend = os.environ.get("VLNI_DIST_BACKEND", "nccl")
         kw = {"device_id": dev} if backend == "nccl" else {}       # bind the communicator to this rank's GPU up front
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        # RCCL prints a version banner on STDOUT when its first communicator comes up; stdout carries rank 0's ONE JSON line, so the
+        # communicator is brought up (init + a first collective) with fd 1 pointing at stderr
+        sys.stdout.flush()
+        keep_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep_fd, 1)
+            os.close(keep_fd)
         rccl = {"backend": backend, "world_size": dist.get_world_size(),
                 "forced_single_rank": True if forced else None}
 

@@ -204,6 +204,11 @@ int vlni_cosine_fwd(int dtype, const void* x, const void* y, float eps, float* c
                     void* stream);
 int vlni_cosine_bwd(int dtype, const void* x, const void* y, const float* gcos, const float* cosv, const float* nx,
                     const float* ny, void* dx, void* dy, int rows, int H, void* stream);
+
+/* Pairwise dot products of two small float32 row sets: out[na, nb] = a[na, H] b[nb, H]^T (similarity matrix of the InfoNCE / margin
+   alignment losses against in-batch negatives, vilmodel_cmt.py:793-856) and its backward (da / db may be NULL). */
+int vlni_pairdot_fwd(const float* a, const float* b, float* out, int na, int nb, int H, void* stream);
+int vlni_pairdot_bwd(const float* g, const float* a, const float* b, float* da, float* db, int na, int nb, int H, void* stream);
 /* y = x * mask/(1-p), counter-based mask f(seed, linear index); x NULL writes the scaled mask */
 int vlni_dropout(int dtype, const void* x, void* y, long n, float p, unsigned seed, void* stream);
 /* dz = da * act'(z), act 1 gelu-erf / 2 relu (n multiple of 4) */

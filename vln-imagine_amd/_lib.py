@@ -55,6 +55,8 @@ SIGNATURES = {
     "vlni_segment_mean_bwd": [I, P, P, P, P, I, I, P],
     "vlni_cosine_fwd": [I, P, P, F, P, P, P, I, I, P],
     "vlni_cosine_bwd": [I, P, P, P, P, P, P, P, P, I, I, P],
+    "vlni_pairdot_fwd": [P, P, P, I, I, I, P],
+    "vlni_pairdot_bwd": [P, P, P, P, P, I, I, I, P],
     "vlni_dropout": [I, P, P, L, F, U, P],
     "vlni_act_bwd": [I, I, P, P, P, L, P],
     "vlni_adamw_step": [P, P, P, P, P, L, F, F, F, F, F, I, P, P],

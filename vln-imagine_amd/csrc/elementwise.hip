@@ -905,6 +905,41 @@ extern "C" int vlni_cosine_bwd(int dtype, const void* x, const void* y, const fl
   return VLNI_OK;
 }
 
+// Pairwise dot products of two small float32 row sets (the in-batch-negatives similarity matrix of the InfoNCE / margin alignment losses,
+// vilmodel_cmt.py:793-856: a few hundred projected imaginations x every other sample's noun phrases): out[i, j] = <a_i, b_j>.
+// One wave per output; the backward kernels give dA[i] = sum_j g[i, j] b_j and dB[j] = sum_i g[i, j] a_i with one wave per row.
+__global__ __launch_bounds__(64) void pairdot_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                         int nb, int H) {
+  const int i = blockIdx.y, j = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int c = lane; c < H; c += 64) s += a[(long)i * H + c] * b[(long)j * H + c];
+  s = wave_sum(s);
+  if (lane == 0) out[(long)i * nb + j] = s;
+}
+// d_rows[r, :] = sum_q g(r, q) * other[q, :]; g is [na, nb] row-major, `trans` selects g[q, r] (the dB side)
+__global__ __launch_bounds__(256) void pairdot_bwd_kernel(const float* __restrict__ g, const float* __restrict__ other, float* __restrict__ d,
+                                                          int nr, int nq, int H, int trans) {
+  const int r = blockIdx.x;
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float s = 0.f;
+    for (int q = 0; q < nq; ++q) s += (trans ? g[(long)q * nr + r] : g[(long)r * nq + q]) * other[(long)q * H + c];
+    d[(long)r * H + c] = s;
+  }
+}
+extern "C" int vlni_pairdot_fwd(const float* a, const float* b, float* out, int na, int nb, int H, void* stream) {
+  VLNI_CHECK(na > 0 && nb > 0 && H > 0 && na <= 65535, VLNI_EINVAL, "pairdot_fwd: na=%d nb=%d H=%d", na, nb, H);
+  hipLaunchKernelGGL(pairdot_fwd_kernel, dim3(nb, na), dim3(64), 0, (hipStream_t)stream, a, b, out, nb, H);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_pairdot_bwd(const float* g, const float* a, const float* b, float* da, float* db, int na, int nb, int H, void* stream) {
+  VLNI_CHECK(na > 0 && nb > 0 && H > 0, VLNI_EINVAL, "pairdot_bwd: na=%d nb=%d H=%d", na, nb, H);
+  if (da) hipLaunchKernelGGL(pairdot_bwd_kernel, dim3(na), dim3(256), 0, (hipStream_t)stream, g, b, da, na, nb, H, 0);
+  if (db) hipLaunchKernelGGL(pairdot_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, a, db, nb, na, H, 1);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
 extern "C" int vlni_act_bwd(int dtype, int act, const void* da, const void* z, void* dz, long n, void* stream) {
   VLNI_CHECK(n > 0 && n % 4 == 0 && (act == 1 || act == 2), VLNI_EINVAL, "act_bwd: n=%ld act=%d", n, act);
   dim3 grid((unsigned)std::min<long>(2048, (n / 4 + 255) / 256)), block(256);

@@ -428,7 +428,7 @@ class AlignWithContrastiveLoss(nn.Module):
             pf, mf = proj_s.float(), means.float()
             unit = lambda v: v / v.norm(dim=-1, keepdim=True).clamp_min(1e-8)
             pos = (unit(pf) * unit(mf)).sum(-1)
-            sims = unit(pf) @ unit(np_means).t()
+            sims = ops.pairdot(unit(pf), unit(np_means))
             own_b = torch.div(rows_t.index_select(0, sc), I, rounding_mode="floor")
             is_neg = owner[None, :] != own_b[:, None]
             if typ == "contrastive-InfoNCE":

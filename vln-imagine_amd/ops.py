@@ -1584,7 +1584,7 @@ class _PreNormFfnBlock(torch.autograd.Function):
         dt = x.dtype
         _, ph, sd = drop
         xn, mean, rstd = ln_fwd(x2, g, b, eps)
-        z = torch.empty((x2.shape[0], w1.shape[0]), dtype=dt, device=x.device)
+        z = _new((x2.shape[0], w1.shape[0]), dt, x.device)
         a = gemm_nt(xn, _w((w1,), dt), bias=b1, act=1, preact=z, drop=(ph, sd))
         y = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2, drop=(ph, sd + 1))
         ctx.save_for_backward(x2, xn, z, a, mean, rstd)
@@ -1837,8 +1837,9 @@ class _DuetFuse(torch.autograd.Function):
         gl, ll = _chk(gl, "global_logits").float().contiguous(), ll.float().contiguous()
         (B, G), V = gl.shape, ll.shape[1]
         assert src.shape == (B, G) and bw.shape == (B, V) and src.dtype == torch.int32 and bw.dtype == torch.uint8
-        out = torch.empty_like(gl)
-        _lib.call("vlni_duet_fuse_fwd", gl.data_ptr(), ll.data_ptr(), src.data_ptr(), bw.data_ptr(), out.data_ptr(), B, G, V, _st())
+        out = _new(gl.shape, gl.dtype, gl.device)
+        if not _ghost():
+            _lib.call("vlni_duet_fuse_fwd", gl.data_ptr(), ll.data_ptr(), src.data_ptr(), bw.data_ptr(), out.data_ptr(), B, G, V, _st())
         ctx.save_for_backward(src, bw)
         return out
 
@@ -1925,6 +1926,33 @@ class _Cosine(torch.autograd.Function):
         _lib.call("vlni_cosine_bwd", _dt(x), x.data_ptr(), y.data_ptr(), g.data_ptr(), cosv.data_ptr(), nx.data_ptr(),
                   ny.data_ptr(), _p(dx), _p(dy), rows, H, _st())
         return dx, dy
+
+
+class _PairDot(torch.autograd.Function):
+    """out[i, j] = <a_i, b_j> for two small float32 row sets (vlni_pairdot_*): the similarity matrix of the alignment head's
+    in-batch-negatives losses (vilmodel_cmt.py:793-856)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _chk(a, "a").float().contiguous(), _chk(b, "b").float().contiguous()
+        (na, H), nb = a.shape, b.shape[0]
+        out = torch.empty((na, nb), dtype=torch.float32, device=a.device)
+        _lib.call("vlni_pairdot_fwd", a.data_ptr(), b.data_ptr(), out.data_ptr(), na, nb, H, _st())
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.float().contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        _lib.call("vlni_pairdot_bwd", g.data_ptr(), a.data_ptr(), b.data_ptr(), _p(da), _p(db), a.shape[0], b.shape[0], a.shape[1], _st())
+        return da, db
+
+
+def pairdot(a, b):
+    return _PairDot.apply(a, b)
 
 
 class _GateRows(torch.autograd.Function):
