@@ -164,7 +164,10 @@ class Workload:
             return run_episode_time_batched(model or self.model, et or self.et, **kw)
         if mode == "taped":
             from vln_imagine_amd import ops
-            from vln_imagine_amd.hamt.episode import run_episode_taped
+            if self.family == "duet":
+                from vln_imagine_amd.duet.episode import run_episode_taped
+            else:
+                from vln_imagine_amd.hamt.episode import run_episode_taped
             if getattr(self, "tape", None) is None:
                 self.tape = ops.EpisodeTape(self.T)
             return run_episode_taped(model or self.model, et or self.et, tape=self.tape, **kw)
@@ -234,7 +237,7 @@ def main():
     ap.add_argument("--mode", default=None, choices=["taped", "stepwise", "time_batched"],
                     help="HAMT episode driver (default taped): taped = step-by-step forward calls + ONE episode-batched backward (episode tape; "
                          "what a sampled rollout can use); stepwise = one autograd graph per call; time_batched = forward and backward on "
-                         "T x B samples (teacher forcing only). DUET runs stepwise.")
+                         "T x B samples (teacher forcing only; HAMT). DUET: taped (maps padded to the episode's largest) or stepwise.")
     ap.add_argument("--time-batched", action="store_true", help="same as --mode time_batched")
     ap.add_argument("--train-mode", dest="train_mode", action="store_true", default=True,
                     help="model.train(): in-kernel dropout p = 0.1 - the reference's training mode (default)")
@@ -259,9 +262,9 @@ def main():
         args.cpu_batch = args.batch
     if args.time_batched:
         args.mode = "time_batched"
-    if args.model == "duet":
-        args.mode = "stepwise"                    # DUET's maps grow with the agent's moves: no batched form yet
-    elif args.mode is None:
+    if args.model == "duet" and args.mode == "time_batched":
+        raise SystemExit("bench.py: DUET has no time-batched driver (its map grows with the agent's moves); use --mode taped or stepwise")
+    if args.mode is None:
         args.mode = "taped"
     args.time_batched = args.mode == "time_batched"
 
@@ -575,6 +578,9 @@ def main():
             return {"value": round(args.batch / sec_, 2), "unit": "episodes/s", "ms_per_step": round(sec_ * 1e3, 3),
                     "step_algorithmic_tflops": round(flops_ / sec_ / 1e12, 2), "note": note}
 
+        if args.model == "duet" and args.mode != "stepwise":
+            s_, _, _, _ = measure(w, trainer, k_extra, 2, mode="stepwise", graph=args.graph, what="stepwise")
+            extras["stepwise"] = line(s_, w.flops, "one autograd graph per `panorama` / `navigation` call (rounds 1-2's path)")
         if args.model == "hamt":
             for md, note in (("stepwise", "one autograd graph per `visual` / `history` call (rounds 1-2's headline path): T x shorter backward launches"),
                              ("time_batched", "forward AND backward on T x B samples (teacher forcing only); same results"),

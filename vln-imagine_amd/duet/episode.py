@@ -92,3 +92,126 @@ def run_episode(model, et, use_aux=True, train_ml=0.2, cosine_weight=0.5, criter
         loss = loss + cosine_weight * aux
     out.update(loss=loss, ml_loss=ml_loss, og_loss=og_loss, aux=aux, txt_embeds=txt, imagine_embeds=img)
     return out
+
+
+def _taped_inputs(et):
+    """Step inputs of a non-REVERIE episode padded to ONE map size Gmax and concatenated over the T steps (built once per episode):
+    padded map nodes are masked out exactly like a smaller map's padding in a ragged batch (agent.py:98-134 pads to the batch maximum)."""
+    hit = getattr(et, "_taped", None)
+    if hit is not None:
+        return hit
+    import numpy as np
+    ep, B, T, dev = et.ep, et.B, et.T, et.device
+    assert all("obj_img_fts" not in s for s in et.steps), "the DUET episode tape covers R2R-style episodes (no object tokens)"
+    Gs = [s["gmap_masks"].shape[1] for s in et.steps]
+    Gmax, P = max(Gs), et.pano_widths[0]
+    assert all(w == P for w in et.pano_widths)
+    S_T = 1 + T * (P + 1)                                   # bank rows per sample: zero row, then (avg_t, pano_t) per step
+    base = 1 + np.arange(T) * (P + 1)
+    pad2 = lambda x, G: torch.cat([x, x.new_zeros((B, Gmax - G) + tuple(x.shape[2:]))], 1) if G < Gmax else x
+    steps, off = [], np.zeros((T, B, Gmax), np.int64)
+    for t, s in enumerate(et.steps):
+        G = Gs[t]
+        for b, srcs in enumerate(ep.steps[t]["node_src"]):
+            for j, src in enumerate(srcs):
+                off[t, b, j + 1] = base[src[1]] + (0 if src[0] == "avg" else 1 + src[2])
+        pd = s["gmap_pair_dists"]
+        pdp = pd.new_zeros((B, Gmax, Gmax))
+        pdp[:, :G, :G] = pd
+        ones = torch.ones(B, 1, dtype=torch.bool, device=dev)
+        plen = s["view_lens"]
+        steps.append(dict(
+            view_img_fts=s["view_img_fts"], loc_fts=s["loc_fts"], nav_types=s["nav_types"], view_lens=plen,
+            gmap_step_ids=pad2(s["gmap_step_ids"], G), gmap_pos_fts=pad2(s["gmap_pos_fts"], G), gmap_masks=pad2(s["gmap_masks"], G),
+            gmap_pair_dists=pdp, gmap_visited_masks=pad2(s["gmap_visited_masks"], G),
+            gmap_vpids=[list(v) + [None] * (Gmax - len(v)) for v in s["gmap_vpids"]],
+            vp_pos_fts=s["vp_pos_fts"], vp_masks=torch.arange(P + 1, device=dev)[None, :] < (plen + 1)[:, None],
+            vp_nav_masks=torch.cat([ones, s["nav_types"] == 1], 1), vp_cand_vpids=s["vp_cand_vpids"], target=s["target"]))
+    idx = torch.from_numpy(off + (np.arange(B) * S_T)[None, :, None]).to(dev)             # rows of the flattened [B * S_T, H] bank
+    cat = lambda k: torch.cat([st[k] for st in steps], 0).contiguous()
+    full = {k: cat(k) for k in ("view_img_fts", "loc_fts", "nav_types", "view_lens", "gmap_step_ids", "gmap_pos_fts", "gmap_masks",
+                                "gmap_pair_dists", "gmap_visited_masks", "vp_pos_fts", "vp_masks", "vp_nav_masks", "target")}
+    full["gmap_vpids"] = [v for st in steps for v in st["gmap_vpids"]]
+    full["vp_cand_vpids"] = [v for st in steps for v in st["vp_cand_vpids"]]
+    et._taped = (steps, full, idx, Gmax, P, S_T)
+    return et._taped
+
+
+def run_episode_taped(model, et, tape=None, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
+                      ghost_compute=False):
+    """GMapNavAgent.rollout with a step-by-step FORWARD (`on_step(t, fused_logits)` may pick the next viewpoint, agent.py:409-500) and ONE
+    episode-batched BACKWARD (vln_imagine_amd.ops.EpisodeTape, see hamt/episode.py:run_episode_taped): the T `panorama` / `navigation`
+    calls write their activations into slices of episode-wide buffers, a ghost pass of the same model code over T x B samples records the
+    autograd graph, and backward runs on T x longer launches (DUET's per-step launches are 0.2-1.2 k rows: latency-bound). Every step's
+    map is padded to the episode's largest (masked like a ragged batch's padding); map-node images are rows of a bank of panorama
+    outputs that only ever grows (agent.py:468-479), so the ghost pass gathers every step's nodes from the one full bank. The text-side
+    K / V projections are made once per episode (model.project_text). Results equal run_episode's to rounding (tests/test_tape_gpu.py)."""
+    from vln_imagine_amd import ops
+    ep, B, T, dev = et.ep, et.B, et.T, et.device
+    steps, full, idx, Gmax, P, S_T = _taped_inputs(et)
+    tape = tape if tape is not None else ops.EpisodeTape(T)
+    assert tape.T >= T
+    tape.reset()
+    txt = model("language", {"txt_ids": et.txt_ids, "txt_masks": et.txt_masks})
+    img = model("imagine", {"imagine_feats": et.imagine_feats, "imagine_masks": et.imagine_masks})
+    aux = None
+    if use_aux:
+        aux, img = model("align_with_contrastive_loss", {
+            "align_txt_embeds": txt, "txt_masks": et.txt_masks, "align_imagine_embeds": img, "imagine_masks": et.imagine_masks,
+            "obs_instr_ids": [f"i{b}" for b in range(B)], "sub_instr_segs": ep.sub_instr_segs,
+            "sub_instr_imag_flag": ep.sub_instr_imag_flag, "noun_phrase_segs": ep.noun_phrase_segs})
+    kv_g, kv_l, lm = model.project_text(txt, et.txt_masks, img, et.imagine_masks)          # once per episode, with autograd
+    H = txt.shape[-1]
+    dt = kv_g[0].dtype
+    bank = getattr(tape, "_bank", None)                      # [B, S_T, H]: zero row, then (avg_t, pano_t); rows of later steps stay zero
+    if bank is None or bank.shape != (B, S_T, H) or bank.dtype != dt:
+        bank = tape._bank = torch.zeros((B, S_T, H), dtype=dt, device=dev)
+
+    def nav_batch(st, gmap_img, vp_img, kvg, kvl, mask, rows):
+        return {"txt_embeds": None, "txt_masks": None, "text_kv": (kvg, kvl, mask), "gmap_img_embeds": gmap_img,
+                "gmap_step_ids": st["gmap_step_ids"], "gmap_pos_fts": st["gmap_pos_fts"], "gmap_masks": st["gmap_masks"],
+                "gmap_pair_dists": st["gmap_pair_dists"], "gmap_visited_masks": st["gmap_visited_masks"], "gmap_vpids": st["gmap_vpids"],
+                "vp_img_embeds": vp_img, "vp_pos_fts": st["vp_pos_fts"], "vp_masks": st["vp_masks"], "vp_nav_masks": st["vp_nav_masks"],
+                "vp_obj_masks": None, "vp_cand_vpids": st["vp_cand_vpids"], "imagine_embeds": None, "imagine_masks": None}
+
+    step_logits = []
+    for t, st in enumerate(steps):
+        with tape.record("panorama", t):
+            pano, pmask = model("panorama", {"view_img_fts": st["view_img_fts"], "obj_img_fts": None, "loc_fts": st["loc_fts"],
+                                             "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": None})
+        with torch.no_grad():
+            avg = (pano * pmask.unsqueeze(2)).sum(1) / st["view_lens"].to(pano.dtype)[:, None]
+            o = 1 + t * (P + 1)
+            bank[:, o] = avg
+            bank[:, o + 1:o + 1 + P] = pano
+            gmap_img = bank.reshape(B * S_T, H).index_select(0, idx[t].reshape(-1)).view(B, Gmax, H)
+            vp_img = torch.cat([torch.zeros_like(pano[:, :1]), pano], 1)
+        with tape.record("navigation", t):
+            nav = model("navigation", nav_batch(st, gmap_img, vp_img, kv_g, kv_l, lm, B))
+        step_logits.append(nav["fused_logits"])
+        if on_step is not None:
+            on_step(t, nav["fused_logits"])
+    # ---- ghost pass over the T x B samples ----
+    with tape.ghost("panorama", compute=ghost_compute):
+        pano_all, pmask_all = model("panorama", {"view_img_fts": full["view_img_fts"], "obj_img_fts": None, "loc_fts": full["loc_fts"],
+                                                 "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None})
+    avg_all = (pano_all * pmask_all.unsqueeze(2)).sum(1) / full["view_lens"].to(pano_all.dtype)[:, None]          # [T * B, H]
+    pieces = [pano_all.new_zeros((B, 1, H))]
+    for t in range(T):
+        pieces += [avg_all[t * B:(t + 1) * B].unsqueeze(1), pano_all[t * B:(t + 1) * B]]
+    rows = torch.cat(pieces, 1).reshape(B * S_T, H)                                        # the full bank, with autograd
+    gmap_all = rows.index_select(0, idx.reshape(-1)).view(T * B, Gmax, H)                   # step t's nodes only point at steps <= t
+    vp_all = torch.cat([pano_all.new_zeros((T * B, 1, H)), pano_all], 1)
+    rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+    Lt = kv_g[0].shape[0] // B
+    repkv = lambda kv: kv.view(B, Lt, -1).unsqueeze(0).expand(T, B, Lt, kv.shape[-1]).reshape(T * B * Lt, kv.shape[-1])
+    with tape.ghost("navigation", compute=ghost_compute):
+        nav = model("navigation", nav_batch(full, gmap_all, vp_all, [repkv(k) for k in kv_g], [repkv(k) for k in kv_l], rep(lm), T * B))
+    ml_loss = criterion(nav["fused_logits"], full["target"])
+    loss = ml_loss * train_ml / B
+    if use_aux and torch.is_tensor(aux):
+        loss = loss + cosine_weight * aux
+    Tn = lambda x: list(x.view((T, B) + tuple(x.shape[1:])))
+    return {"loss": loss, "ml_loss": ml_loss, "aux": aux, "fused": Tn(nav["fused_logits"]), "global": Tn(nav["global_logits"]),
+            "local": Tn(nav["local_logits"]), "pano": Tn(pano_all), "step_logits": step_logits, "txt_embeds": txt,
+            "imagine_embeds": img, "tape": tape, "gmax": Gmax}

@@ -269,15 +269,27 @@ class GlocalTextPathNavCMT(nn.Module):
                 (ie.nav_type_embedding.weight, "gather", nav_types.reshape(-1).contiguous()),
                 (self.embeddings.token_type_embeddings.weight[1], "bcast", None)]
         x = ops.sum_layer_norm(srcs, ie.layer_norm.weight, ie.layer_norm.bias, B * S, dt, HID_EPS).view(B, S, -1)
-        x = F.dropout(x, self.config.hidden_dropout_prob, self.training)
+        x = ops.dropout(x, self.config.hidden_dropout_prob, self.training)
         masks = torch.arange(S, device=x.device)[None, :] < pano_lens[:, None]          # gen_seq_masks
         if ie.pano_encoder is not None:
             x = ie.pano_encoder(x, masks)
         return x, masks
 
+    def project_text(self, txt_embeds, txt_masks, imagine_embeds=None, imagine_masks=None):
+        """The language side of every `navigation` call of an episode, built once by the caller: (per-layer K/V projections of the global
+        encoder, of the local encoder, additive key mask) of text (+ imagination tokens). Pass it as batch['text_kv']; an episode tape
+        (duet/episode.py:run_episode_taped) does, because a projection made inside a recorded step would belong to step 0 only."""
+        c, dt = self.config, self.compute_dtype
+        txt, tm = txt_embeds.to(dt), txt_masks
+        if c.imagine_enc_pano and c.concat_imagine_with == "language":
+            txt, tm = torch.cat([txt, imagine_embeds.to(dt)], 1), torch.cat([tm, imagine_masks], 1)
+        txt = txt.contiguous()
+        return (self.global_encoder.encoder.project_context(txt), self.local_encoder.encoder.project_context(txt),
+                ops.additive_mask(tm).contiguous())
+
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
                                     gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
-                                    vp_nav_masks, vp_obj_masks, vp_cand_vpids, imagine_embeds=None, imagine_masks=None):
+                                    vp_nav_masks, vp_obj_masks, vp_cand_vpids, imagine_embeds=None, imagine_masks=None, text_kv=None):
         c, dt = self.config, self.compute_dtype
         ge, le = self.global_encoder, self.local_encoder
         B, G = gmap_masks.shape
@@ -298,7 +310,10 @@ class GlocalTextPathNavCMT(nn.Module):
             return txt.contiguous(), ops.additive_mask(tm).contiguous()
 
         kv_g = kv_l = None
-        if CACHE_TEXT_KV:
+        if text_kv is not None:
+            kv_g, kv_l, lm = text_kv
+            txt = None
+        elif CACHE_TEXT_KV:
             # the language stream is never updated (use_lang2visn_attn False), so its per-layer K/V projections are the same
             # for every step of an episode: project once, reduce their gradient once - and build the concatenated stream and its
             # mask only then. Key = identity of the caller-held embeddings and masks (strong refs keep the ids unique) + the
@@ -407,5 +422,5 @@ class GlocalTextPathNavCMT(nn.Module):
                 batch["gmap_pos_fts"], batch["gmap_masks"], batch["gmap_pair_dists"], batch["gmap_visited_masks"],
                 batch["gmap_vpids"], batch["vp_img_embeds"], batch["vp_pos_fts"], batch["vp_masks"], batch["vp_nav_masks"],
                 batch.get("vp_obj_masks"), batch["vp_cand_vpids"], imagine_embeds=batch.get("imagine_embeds"),
-                imagine_masks=batch.get("imagine_masks"))
+                imagine_masks=batch.get("imagine_masks"), text_kv=batch.get("text_kv"))
         raise NotImplementedError("wrong mode: %s" % mode)
