@@ -665,6 +665,7 @@ def main():
                        "grad_allreduce": (args.grad_comm + " payload, flat arena, flush -> all-reduce pipeline, RCCL") if (world > 1 or forced) else "none (1 GPU)",
                        "steps_per_sec": round(args.T * args.batch * world / sec, 1),
                        "loss": round(last_loss, 5)},
+            "argv": " ".join(sys.argv[1:]),
             "roofline": roof, "cpu_baseline": cpu, "bf16_vs_fp32": parity, "extras": extras or None,
             "time_batched": extras.get("time_batched"),
         }

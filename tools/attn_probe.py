@@ -60,3 +60,30 @@ dual("self-attention, both streams", (86, 41), (86, 41))
 dual("last layer, [CLS] query + vision", (1, 41), (86, 41))
 single("text encoder self-attention", 80, 80)
 single("history panorama encoder", 36, 36)
+
+
+def layout(name, Sq, Sk, Bx):
+    """The same work with every head's rows CONTIGUOUS (nh = 1, B x 12 'samples' of 64 columns, row stride 128 B) against the model's
+    layout (heads = 128-byte column slices of [rows, 2304] rows, row stride 4608 B): what the strided 128-byte pieces cost."""
+    q, kv = r(Bx * Sq, 3 * H), r(Bx * Sk, 3 * H)
+    km = torch.zeros(Bx, Sk, device="cuda")
+    qs, ks, vs = q[:, :H], kv[:, H:2 * H], kv[:, 2 * H:]
+    o, l = ops.attn_fwd(qs, ks, vs, Bx, Sq, Sk, km)
+    f1 = timeit(lambda: ops.attn_fwd(qs, ks, vs, Bx, Sq, Sk, km))
+    do, dq, dkv = torch.randn_like(o), torch.empty_like(q), torch.empty_like(kv)
+    b1 = timeit(lambda: ops.attn_bwd(qs, ks, vs, o, do, l, dq[:, :H], dkv[:, H:2 * H], dkv[:, 2 * H:], Bx, Sq, Sk, km))
+    B2 = Bx * 12
+    q2, k2, v2 = r(B2 * Sq, 64), r(B2 * Sk, 64), r(B2 * Sk, 64)
+    km2 = torch.zeros(B2, Sk, device="cuda")
+    o2, l2 = ops.attn_fwd(q2, k2, v2, B2, Sq, Sk, km2, nh=1)
+    f2 = timeit(lambda: ops.attn_fwd(q2, k2, v2, B2, Sq, Sk, km2, nh=1))
+    do2, dq2, dk2, dv2 = torch.randn_like(o2), torch.empty_like(q2), torch.empty_like(k2), torch.empty_like(v2)
+    b2 = timeit(lambda: ops.attn_bwd(q2, k2, v2, o2, do2, l2, dq2, dk2, dv2, B2, Sq, Sk, km2, nh=1))
+    print(f"{name:28s} B {Bx:4d} Sq {Sq} Sk {Sk}: model layout fwd {f1:6.1f} bwd {b1:6.1f} us | heads contiguous fwd {f2:6.1f} bwd {b2:6.1f} us", flush=True)
+
+
+layout("text self-attention", 80, 80, 64)
+layout("vision queries, lang keys", 43, 86, 64)
+layout("lang queries, vision keys", 86, 43, 64)
+layout("episode-batched backward", 86, 43, 384)
+layout("episode-batched backward", 43, 86, 384)

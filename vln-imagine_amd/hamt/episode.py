@@ -104,6 +104,22 @@ def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2,
     count (x T) and the launch count (/ T) change. Sampling / RL rollouts cannot use this (actions feed back)."""
     ep, B, T = et.ep, et.B, et.T
     dev = et.txt_ids.device
+    cat = et.full
+    # the history encoder of all T steps (13.8 k-row launches) runs on a second stream beside the text encoder (5.1 k-row launches that
+    # fill half of the chip); autograd then runs its backward on that stream too, beside the text encoder's
+    side = None
+    if dev.type == "cuda":
+        for k in ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats"):
+            cat(k)
+        main = torch.cuda.current_stream()
+        side = getattr(et, "_side", None)
+        if side is None:
+            side = et._side = torch.cuda.Stream()
+        side.wait_stream(main)
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        h_all = model("history", hist_img_feats=cat("hist_img_feats"), hist_ang_feats=cat("hist_ang_feats"),
+                      ob_step_ids=torch.arange(T, device=dev).repeat_interleave(B),
+                      hist_pano_img_feats=cat("hist_pano_img_feats"), hist_pano_ang_feats=cat("hist_pano_ang_feats"))
     txt = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
     img = model("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None if bypass else et.imagine_masks)
     aux = None
@@ -111,11 +127,9 @@ def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2,
         aux, img = model("align_with_contrastive_loss", align_txt_embeds=txt, txt_masks=et.txt_masks, align_imagine_embeds=img,
                          imagine_masks=et.imagine_masks, sub_instr_segs=ep.sub_instr_segs,
                          sub_instr_imag_flag=ep.sub_instr_imag_flag, noun_phrase_segs=ep.noun_phrase_segs)
-    cat = lambda k: torch.cat([s[k] for s in et.steps], 0)
     cls = model("history").expand(B, -1)                                                   # [B, H]
-    h_all = model("history", hist_img_feats=cat("hist_img_feats"), hist_ang_feats=cat("hist_ang_feats"),
-                  ob_step_ids=torch.arange(T, device=dev).repeat_interleave(B),
-                  hist_pano_img_feats=cat("hist_pano_img_feats"), hist_pano_ang_feats=cat("hist_pano_ang_feats"))
+    if side is not None:
+        main.wait_stream(side)
     H = h_all.shape[-1]
     hist_steps = h_all.view(T, B, H)
     # sample (t, b): [CLS, h_0 .. h_{T-2}] with the first t+1 entries valid
