@@ -497,8 +497,9 @@ def main():
         ach = tot_f / (tot_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
         try:      # HBM bytes per launch: separate rocprofv3 --pmc passes of this command (never collected inside a timed run)
-            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-            if pmc and args.dtype == "bf16" and args.model == "hamt" and args.mode == "taped" and args.train_mode:      # collected on the default workload only
+            pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                         if f.endswith("_pmc_traffic.json") and ("duet" in f) == (args.model == "duet"))
+            if pmc and args.dtype == "bf16" and args.mode == "taped" and args.train_mode:      # collected on the default workloads only
                 traffic = round(json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["bytes_per_launch"])
                 traffic_src = f"profiles/{pmc[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
         except Exception:

@@ -7,7 +7,7 @@ from vln_imagine_amd import ops, synth
 from vln_imagine_amd.train import FlatTrainer
 if "--duet" in sys.argv:
     from vln_imagine_amd.duet.config import DuetConfig
-    from vln_imagine_amd.duet.episode import DuetEpisodeTensors as EpisodeTensors, run_episode
+    from vln_imagine_amd.duet.episode import DuetEpisodeTensors as EpisodeTensors, run_episode, run_episode_taped
     from vln_imagine_amd.duet.models.vilmodel import GlocalTextPathNavCMT
     from vln_imagine_amd.duet.spec import param_shapes
     cfg = DuetConfig()
@@ -17,7 +17,7 @@ if "--duet" in sys.argv:
     et = EpisodeTensors(synth.DuetEpisode(tag="hp", B=8, L=80, V=36, I=6, T=6, ragged=False), "cuda")
 else:
     from vln_imagine_amd.hamt.config import HamtConfig
-    from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
+    from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode, run_episode_taped
     from vln_imagine_amd.hamt.models.vilmodel_cmt import NavCMT
     from vln_imagine_amd.hamt.spec import param_shapes
     cfg = HamtConfig()
@@ -26,9 +26,13 @@ else:
     model = model.cuda().eval().set_compute_dtype(torch.bfloat16)
     et = EpisodeTensors(synth.HamtEpisode(tag="hp", B=8, L=80, V=37, I=6, T=6, ragged=False), "cuda")
 tr = FlatTrainer(model)
+TAPE = ops.EpisodeTape(6) if "--taped" in sys.argv else None      # --taped: the episode-tape drivers (what bench.py times)
 def step():
     tr.zero_grad()
-    out = run_episode(model, et, criterion=ops.cross_entropy_sum, keep=False)
+    if TAPE is not None:
+        out = run_episode_taped(model, et, tape=TAPE, criterion=ops.cross_entropy_sum)
+    else:
+        out = run_episode(model, et, criterion=ops.cross_entropy_sum, keep=False)
     out["loss"].backward()
     tr.step()
 for _ in range(3): step()

@@ -235,11 +235,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(P8 p, unsigned long long* st
 // a k-tile is 2 phases of 16 MFMAs (rows 0-31 / 32-63 of the wave's tile); the two wave groups (waves 0-3 / 4-7) run one barrier apart.
 // k-tile s + 2 is requested during k-tile s (3 + 3 LDS-DMA instructions per wave); s_waitcnt vmcnt(6) in phase 2 certifies k-tile s + 1.
 // The buffer of s + 2 was last read in k-tile s - 1: no ordering subtleties beyond retiring phase 2's reads before its first barrier.
-template <int STAMP, int NL>      // NL: dedicated loader waves (0 = the 8 computing waves request their own data)
-__global__ __launch_bounds__(512 + 64 * NL) void gemm8h_kernel(P8 p, unsigned long long* stamps) {
+template <int STAMP, int NLX>     // NLX: dedicated loader waves (0 = the 8 computing waves request their own data); 5 = 4 loaders (A) + computing waves (B)
+__global__ __launch_bounds__(512 + 64 * (NLX == 5 ? 4 : NLX)) void gemm8h_kernel(P8 p, unsigned long long* stamps) {
+  constexpr int NL = NLX == 5 ? 4 : NLX;
+  constexpr bool HYB = NLX == 5;
   extern __shared__ __attribute__((aligned(16))) char dsmem[];
   constexpr int TM = 256, TN = 128, BUF = (TM + TN) * 128;     // 49152
-  constexpr int NI = NL ? 48 / NL : 6;                         // LDS-DMA instructions per requesting wave and k-tile
+  constexpr int NI = HYB ? 8 : (NL ? 48 / NL : 6);             // LDS-DMA instructions per requesting wave and k-tile
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = NL > 0 && wave >= 8;
@@ -299,7 +301,28 @@ __global__ __launch_bounds__(512 + 64 * NL) void gemm8h_kernel(P8 p, unsigned lo
 #pragma unroll
     for (int j = 0; j < NI; ++j) H_DMA(j, BUF);
     if constexpr (NI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (NI == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  }
+  const char* pgb[2];
+  auto pointb = [&](const Side& s2) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rho = (wave + 8 * j) * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((rho >> 1) & 7);
+      pgb[j] = p.B + (long)min(s2.n0 + rho, p.N - 1) * p.ldb * 2 + c * 16;
+    }
+  };
+#define HB_DMA(j, boff)                                                                                         \
+  do {                                                                                                          \
+    asm volatile("s_add_u32 m0, %1, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"                           \
+                 : : "v"(pgb[j]), "s"(lds0 + (boff) + wave * 1024), "n"(32768 + (j) * 8192) : "memory", "scc");    \
+    pgb[j] += 128;                                                                                              \
+  } while (0)
+  if (HYB && !loader) {
+    pointb(cur);
+    HB_DMA(0, 0); HB_DMA(1, 0); HB_DMA(0, BUF); HB_DMA(1, BUF);
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   }
   BAR();
 
@@ -323,6 +346,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void gemm8h_kernel(P8 p, unsigned lo
 #pragma unroll
         for (int j = NI / 2; j < NI; ++j) H_DMA(j, wbuf);
         if constexpr (NI == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if constexpr (NI == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
         BAR(); BAR();
         wbuf = wbuf == 2 * BUF ? 0 : wbuf + BUF;
@@ -362,6 +386,16 @@ __global__ __launch_bounds__(512 + 64 * NL) void gemm8h_kernel(P8 p, unsigned lo
         }
         --left;
       }
+      if constexpr (HYB) {
+        if (left == 0) {
+          int nt_ = more ? ntile : tile;
+          asm volatile("" : "+s"(nt_));
+          locate(nt_, nxt);
+          pointb(nxt);
+          left = nk;
+        }
+        --left;
+      }
       const char* rb = dsmem + rbuf;
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb)
@@ -374,6 +408,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void gemm8h_kernel(P8 p, unsigned lo
         for (int kk = 0; kk < 2; ++kk) a[mb][kk] = *(const h16x8*)(rb + mb * 2048 + (aoff ^ (kk * 64)));
       SB();
       if constexpr (NL == 0) { H_DMA(0, wbuf); H_DMA(1, wbuf); H_DMA(2, wbuf); }
+      if constexpr (HYB) HB_DMA(0, wbuf);
       BAR(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); SB();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -393,6 +428,7 @@ __global__ __launch_bounds__(512 + 64 * NL) void gemm8h_kernel(P8 p, unsigned lo
         H_DMA(3, wbuf); H_DMA(4, wbuf); H_DMA(5, wbuf);
         asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       }
+      if constexpr (HYB) { HB_DMA(1, wbuf); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       BAR(); SB();
       __builtin_amdgcn_s_setprio(1);
@@ -476,7 +512,7 @@ __global__ void fill_kernel(__bf16* x, long n, unsigned seed) {
   x[i] = (__bf16)(((float)(h & 0xFFFF) / 32768.0f) - 1.0f);
 }
 
-static int g_kind = 0;          // 0: 256 x 256, 1: 256 x 128
+static int g_kind = 0;          // 0: 256 x 256, 1..4: 256 x 128 forms
 static int tiles_of(int M, int N) { return ((M + 255) / 256) * ((N + (g_kind ? 127 : 255)) / (g_kind ? 128 : 256)); }
 static void launch(const P8& p0, hipStream_t st, bool stamp, unsigned long long* stamps) {
   P8 p = p0;
@@ -492,6 +528,11 @@ static void launch(const P8& p0, hipStream_t st, bool stamp, unsigned long long*
   if (g_kind == 2) {
     if (stamp) hipLaunchKernelGGL((gemm8h_kernel<1, 4>), dim3(G), dim3(768), 147456, st, p, stamps);
     else hipLaunchKernelGGL((gemm8h_kernel<0, 4>), dim3(G), dim3(768), 147456, st, p, stamps);
+    return;
+  }
+  if (g_kind == 4) {
+    if (stamp) hipLaunchKernelGGL((gemm8h_kernel<1, 5>), dim3(G), dim3(768), 147456, st, p, stamps);
+    else hipLaunchKernelGGL((gemm8h_kernel<0, 5>), dim3(G), dim3(768), 147456, st, p, stamps);
     return;
   }
   if (g_kind == 3) {
@@ -511,9 +552,11 @@ int main(int argc, char** argv) {
   hipFuncSetAttribute((const void*)gemm8h_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
   hipFuncSetAttribute((const void*)gemm8h_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
   hipFuncSetAttribute((const void*)gemm8h_kernel<0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  hipFuncSetAttribute((const void*)gemm8h_kernel<0, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+  hipFuncSetAttribute((const void*)gemm8h_kernel<1, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
   hipFuncSetAttribute((const void*)gemm8h_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
   g_kind = argc > 1 ? atoi(argv[1]) : 0;
-  const char* names[] = {"256 x 256, 2 buffers", "256 x 128, 3 buffers", "256 x 128, 3 buffers, 4 loader waves", "256 x 128, 3 buffers, 8 loader waves"};
+  const char* names[] = {"256 x 256, 2 buffers", "256 x 128, 3 buffers", "256 x 128, 3 buffers, 4 loader waves", "256 x 128, 3 buffers, 8 loader waves", "256 x 128, 3 buffers, 4 loader waves (A) + computing waves request B"};
   printf("kernel: %s\n", names[g_kind]);
   struct Shape { int M, N, K; bool check; };
   std::vector<Shape> shapes = {

@@ -42,7 +42,8 @@ def fam(k):
 agg, per = collections.defaultdict(lambda: [0, 0]), collections.defaultdict(lambda: [0, 0])
 for s, e, k in seg:
     agg[fam(k)][0] += 1; agg[fam(k)][1] += e - s
-    short = re.sub(r"\(.*", "", k).replace("void ", "")[-70:]
+    m_ = re.search(r"(\w+_kernel)(<[^(]*>)?", k)
+    short = (m_.group(1) + (m_.group(2) or "")[:40]) if m_ else re.sub(r"\(.*", "", k).replace("void ", "")[-70:]
     per[short][0] += 1; per[short][1] += e - s
 tot = sum(v[1] for v in agg.values())
 span = seg[-1][1] - seg[0][0]
