@@ -179,8 +179,9 @@ int vlni_scatter_add_rows(int dtype, const void* src, long lds, const long* idx,
 int vlni_scatter_add_rows_small(int dtype, const void* src, long lds_, const long* idx, float* table_grad, int rows, int H,
                                 int table_rows, void* stream);
 /* out[b] = mean_s x[b][s] (torch.mean(pano_embeddings, 1) R:612) */
-int vlni_seqmean_fwd(int dtype, const void* x, void* out, int B, int S, int H, void* stream);
-int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, int B, int S, int H, void* stream);
+/* lens (int64 [B]) non-NULL: mean over the first lens[b] rows only (DUET's masked panorama mean, r2r/agent.py:159-161) */
+int vlni_seqmean_fwd(int dtype, const void* x, void* out, const long* lens, int B, int S, int H, void* stream);
+int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, const long* lens, int B, int S, int H, void* stream);
 /* f[b][j][:] = visn[b][r0+j][:] * lang[b][0][:]  (action-head input `ob_embeds * txt_embeds[:, :1]`, R:1192; visn [B,Sv,H], lang [B,Sl,H], f [B,n,H],
    all contiguous) and its backward: dvisn / dlang are written in full (zero outside the gated rows / row 0); either may be NULL */
 int vlni_gate_rows_fwd(int dtype, const void* visn, const void* lang, void* f, int B, int Sv, int Sl, int r0, int n, int H, void* stream);
@@ -256,6 +257,16 @@ int vlni_gather_rows_or_zero(int dtype, const void* table, long ld, const long* 
 int vlni_duet_fuse_fwd(const float* gl, const float* ll, const int* src, const unsigned char* bw, float* out, int B, int G, int V,
                        void* stream);
 int vlni_duet_fuse_bwd(const float* dout, const int* src, const unsigned char* bw, float* dll, int B, int G, int V, void* stream);
+/* The whole logit tail of a DUET navigation call in one launch (VLN-DUET/map_nav_src/models/vilmodel.py:1185-1217):
+   w = sigmoid(f[b]) (f NULL: 0.5); gl = (visited | !gmask) ? -inf : graw * w; ll = nav ? lraw * (1 - w) : -inf; fused = duet_fuse(gl, ll).
+   graw [B,G] / lraw [B,V]: outputs of the two ClsPrediction heads (float32); f [B]: pre-sigmoid output of sap_fuse_linear;
+   visited, gmask [B,G] and nav [B,V]: 0/1 bytes. bwd: any of d_gl / d_ll / d_fused may be NULL; writes dgraw, dlraw and (f given) df. */
+int vlni_duet_heads_fwd(const float* graw, const float* lraw, const float* f, const unsigned char* visited, const unsigned char* gmask,
+                        const unsigned char* nav, const int* src, const unsigned char* bw, float* gl, float* ll, float* fused, int B,
+                        int G, int V, void* stream);
+int vlni_duet_heads_bwd(const float* d_gl, const float* d_ll, const float* d_fused, const float* graw, const float* lraw, const float* f,
+                        const unsigned char* visited, const unsigned char* gmask, const unsigned char* nav, const int* src,
+                        const unsigned char* bw, float* dgraw, float* dlraw, float* df, int B, int G, int V, void* stream);
 /* optimizer side of the measured step (r2r/agent_cmt.py:827-832): clip_grad_norm_ + AdamW over a flat arena */
 int vlni_adamw_step(float* p, const float* g, float* m, float* v, void* bf16_shadow, long n, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, const float* clip_coef, void* stream);

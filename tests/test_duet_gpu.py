@@ -8,7 +8,7 @@ import torch
 
 from tests.golden.variants import DUET_VARIANTS, duet_variant_setup
 from tests.test_hamt_gpu import _close
-from vln_imagine_amd import synth
+from vln_imagine_amd import ops, synth
 from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode
 from vln_imagine_amd.duet.spec import param_shapes
 
@@ -166,6 +166,78 @@ def test_logit_fusion_kernel_matches_reference_loop():
     assert (torch.isfinite(out).cpu() == fin).all() and torch.allclose(out.cpu()[fin], ref[fin], atol=1e-6)
     (out[fin.cuda()] * w.cuda()[fin.cuda()]).sum().backward()
     assert torch.allclose(gl_g.grad.cpu(), gl_r.grad, atol=1e-6) and torch.allclose(ll_g.grad.cpu(), ll_r.grad, atol=1e-6)
+
+
+@pytest.mark.parametrize("with_f", [True, False])
+def test_fused_logit_tail_matches_unfused_composition(with_f):
+    """ops.duet_heads (one launch) == sigmoid, scalings, masked_fills and ops.duet_fuse composed in torch (the round-2 path, itself pinned
+    against the literal reference loop above), all three outputs and the gradients of the three inputs; mixed use of the outputs in the
+    loss (global only / local + fused) exercises the null-gradient arguments of the backward kernel."""
+    from vln_imagine_amd.duet.models.vilmodel import GlocalTextPathNavCMT
+    torch.manual_seed(1)
+    B, G, V = 5, 9, 7
+    vpids = [[None] + [f"n{b}_{j}" for j in range(1, G)] for b in range(B)]
+    cands = [[None] + [f"n{b}_{j}" for j in (2, 3, 5)] + ["zz", "n%d_7" % b, "qq"] for b in range(B)]
+    vis = torch.zeros(B, G, dtype=torch.bool)
+    vis[:, 2] = True; vis[1, 5] = True; vis[3, 7] = True
+    gmask = torch.ones(B, G, dtype=torch.bool); gmask[2, 6:] = False
+    nav = torch.ones(B, V, dtype=torch.bool); nav[:, 5] = False; nav[4, 3] = False
+    src, bw = GlocalTextPathNavCMT.fuse_plan(vpids, vis.tolist(), cands, G, V)
+    src, bw = torch.tensor(src, dtype=torch.int32).cuda(), torch.tensor(bw, dtype=torch.uint8).cuda()
+    g0, l0, f0 = torch.randn(B, G), torch.randn(B, V), torch.randn(B)
+    wts = [torch.randn(B, G).cuda(), torch.randn(B, V).cuda(), torch.randn(B, G).cuda()]
+    visc, gmc, navc = vis.cuda(), gmask.cuda(), nav.cuda()
+
+    def unfused(g, l, f):
+        w = torch.sigmoid(f)[:, None] if f is not None else 0.5
+        gl = (g * w).masked_fill(visc | ~gmc, -float("inf"))
+        ll = (l * (1 - w)).masked_fill(~navc, -float("inf"))
+        return gl, ll, ops.duet_fuse(gl, ll, src, bw)
+
+    def fused(g, l, f):
+        return ops.duet_heads(g, l, f, visc, gmc, navc, src, bw)
+
+    for use in ((0, 1, 2), (0,), (1, 2), (2,)):
+        grads = []
+        for fn in (unfused, fused):
+            g, l = g0.clone().cuda().requires_grad_(), l0.clone().cuda().requires_grad_()
+            f = f0.clone().cuda().requires_grad_() if with_f else None
+            outs = fn(g, l, f)
+            loss = 0
+            for i in use:
+                fin = torch.isfinite(outs[i])
+                loss = loss + (outs[i][fin] * wts[i][fin]).sum()
+            loss.backward()
+            z = lambda t: t.grad if t.grad is not None else torch.zeros_like(t)          # an input no used output depends on
+            grads.append(([o.detach() for o in outs], z(g), z(l), z(f) if with_f else None))
+        (oa, ga, la, fa), (ob, gb, lb, fb) = grads
+        for a, b in zip(oa, ob):
+            assert torch.equal(torch.isfinite(a), torch.isfinite(b))
+            fin = torch.isfinite(a)
+            assert torch.allclose(a[fin], b[fin], atol=1e-6), use
+        assert torch.allclose(ga, gb, atol=1e-6) and torch.allclose(la, lb, atol=1e-6), use
+        if with_f:
+            assert torch.allclose(fa, fb, atol=1e-5), use
+
+
+def test_masked_sequence_mean():
+    """ops.seq_mean with lens == the agent's masked panorama mean (r2r/agent.py:159-161), forward and backward, fp32 and bf16."""
+    torch.manual_seed(2)
+    B, S, H = 6, 36, 768
+    lens = torch.tensor([36, 30, 1, 17, 36, 29]).cuda()
+    for dt, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        x0 = torch.randn(B, S, H, device="cuda").to(dt)
+        w = torch.randn(B, H, device="cuda").to(dt)
+        xa, xb = x0.clone().requires_grad_(), x0.clone().requires_grad_()
+        a = ops.seq_mean(xa, lens)
+        m = torch.arange(S, device="cuda")[None, :] < lens[:, None]
+        b = (xb.float() * m.unsqueeze(2)).sum(1) / lens[:, None]
+        assert torch.allclose(a.float(), b, atol=tol)
+        (a.float() * w.float()).sum().backward(); (b * w.float()).sum().backward()
+        assert torch.allclose(xa.grad.float(), xb.grad.float(), atol=tol)
+        assert (xa.grad[2, 1:] == 0).all()
+    xa = x0.float().clone().requires_grad_()
+    assert torch.allclose(ops.seq_mean(xa), xa.mean(1), atol=1e-5)               # unmasked form unchanged
 
 
 def test_bf16_trainer_step_with_odd_sized_parameters():

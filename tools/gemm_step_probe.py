@@ -12,8 +12,8 @@ from vln_imagine_amd import ops  # noqa: E402
 
 dt = torch.bfloat16
 T = int(os.environ.get("T", "1"))                       # T > 1: the row counts of T time-batched / episode-batched steps
-M0, M1 = T * 64 * 86, T * 64 * 40
-NT_VARIANTS = tuple(int(v) for v in os.environ.get("NT_VARIANTS", "5,12,13,14,15,32").split(","))
+M0, M1 = int(os.environ.get("M0", T * 64 * 86)), int(os.environ.get("M1", T * 64 * 40))   # DUET step 3: M0=448 (map) M1=1184 (viewpoint)
+NT_VARIANTS = tuple(int(v) for v in os.environ.get("NT_VARIANTS", "5,12,13,14,15,32").split(",") if not (int(v) == 15 and M0 + M1 < 6144))
 NN_VARIANTS = tuple(int(v) for v in os.environ.get("NN_VARIANTS", "4,5,6").split(","))
 ROUNDS = int(os.environ.get("ROUNDS", "3"))
 
@@ -22,9 +22,27 @@ def rnd(*shape, s=0.5):
     return (torch.randn(*shape, device="cuda") * s).to(dt)
 
 
+GRAPH = os.environ.get("GRAPH", "0") == "1"           # time n launches replayed from ONE hipGraph: short launches (< 20 us) are host-bound otherwise
+
+
 def time_call(fn, n=10):
     for _ in range(2):
         fn()
+    if GRAPH:
+        n = 20
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(n):
+                fn()
+        g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / (3 * n) * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
@@ -83,6 +101,13 @@ def run(nn, N, K, kind):
 
 def main():
     tot = {}
+    if os.environ.get("EPILOGUES"):           # the same contraction under every epilogue kind: what bias / GELU + pre-activation store / residual cost
+        N, K = (int(v) for v in os.environ["EPILOGUES"].split("x"))
+        for kind in ("plain", "res", "gelu"):
+            run(False, N, K, kind)
+        for kind in ("plain", "dact", "dres"):
+            run(True, N, K, kind)
+        return
     for nn, N, K, kind, count in ((False, 2304, 768, "plain", 2), (False, 768, 768, "res", 2), (False, 3072, 768, "gelu", 1), (False, 768, 3072, "res", 1),
                                   (True, 3072, 768, "dact", 1), (True, 768, 3072, "dres", 1), (True, 768, 2304, "dres", 2), (True, 768, 768, "plain", 2)):
         fl, us, per = run(nn, N, K, kind)

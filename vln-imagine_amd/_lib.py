@@ -44,8 +44,8 @@ SIGNATURES = {
     "vlni_smallk_linear_bwd": [I, P, L, P, L, P, P, I, I, I, P],
     "vlni_scatter_add_rows": [I, P, L, P, P, I, I, P],
     "vlni_scatter_add_rows_small": [I, P, L, P, P, I, I, I, P],
-    "vlni_seqmean_fwd": [I, P, P, I, I, I, P],
-    "vlni_seqmean_bwd": [I, P, P, I, I, I, P],
+    "vlni_seqmean_fwd": [I, P, P, P, I, I, I, P],
+    "vlni_seqmean_bwd": [I, P, P, P, I, I, I, P],
     "vlni_gate_rows_fwd": [I, P, P, P, I, I, I, I, I, I, P],
     "vlni_gate_rows_bwd": [I, P, P, P, P, P, I, I, I, I, I, I, P],
     "vlni_rowdot_fwd": [I, P, L, P, P, P, P, I, I, P],
@@ -72,6 +72,8 @@ SIGNATURES = {
     "vlni_gather_rows_or_zero": [I, P, L, P, P, I, I, P],
     "vlni_duet_fuse_fwd": [P, P, P, P, P, I, I, I, P],
     "vlni_duet_fuse_bwd": [P, P, P, P, I, I, I, P],
+    "vlni_duet_heads_fwd": [P] * 11 + [I, I, I, P],
+    "vlni_duet_heads_bwd": [P] * 14 + [I, I, I, P],
     "vlni_optim_prepare": [P, F, F, F, P, P],
     "vlni_adamw_step_dev": [P, P, P, P, P, L, P, F, F, F, F, P, P],
     "vlni_optim_prepare_groups": [P, F, F, F, P, P, P, I, I, P],

@@ -188,28 +188,33 @@ __global__ __launch_bounds__(256) void scatter_add_rows_small_kernel(const T* __
     if (k < TR && acc[k] != 0.f) atomicAdd(tab + (long)k * H + c, acc[k]);
 }
 
-// out[b][:] = mean_s x[b][s][:]   and its backward dx[b][s][:] = dout[b][:] / S
+// out[b][:] = mean over the first n rows of x[b] (n = lens[b], or S when lens is null) and its backward dx[b][s][:] = s < n ? dout[b][:] / n : 0
+// (lens: the masked panorama mean of VLN-DUET/map_nav_src/r2r/agent.py:159-161)
 template <typename T>
-__global__ __launch_bounds__(256) void seqmean_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, int B, int S, int H) {
+__global__ __launch_bounds__(256) void seqmean_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, const long* __restrict__ lens, int B,
+                                                          int S, int H) {
   const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;      // grid (B, ceil(H / 256)): 3x the blocks of one-per-sample
   if (c >= H) return;
+  const int n = lens ? (int)lens[b] : S;
   const T* xp = x + (long)b * S * H + c;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int s = 0;
-  for (; s + 3 < S; s += 4) {                                         // four rows in flight (the loop is latency-bound)
+  for (; s + 3 < n; s += 4) {                                         // four rows in flight (the loop is latency-bound)
     a0 += DT<T>::ld(xp + (long)s * H); a1 += DT<T>::ld(xp + (long)(s + 1) * H);
     a2 += DT<T>::ld(xp + (long)(s + 2) * H); a3 += DT<T>::ld(xp + (long)(s + 3) * H);
   }
-  for (; s < S; ++s) a0 += DT<T>::ld(xp + (long)s * H);
-  DT<T>::st(out + (long)b * H + c, ((a0 + a1) + (a2 + a3)) / S);
+  for (; s < n; ++s) a0 += DT<T>::ld(xp + (long)s * H);
+  DT<T>::st(out + (long)b * H + c, ((a0 + a1) + (a2 + a3)) / n);
 }
 template <typename T>
-__global__ __launch_bounds__(256) void seqmean_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, int B, int S, int H) {
+__global__ __launch_bounds__(256) void seqmean_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, const long* __restrict__ lens, int B,
+                                                          int S, int H) {
   const int b = blockIdx.x;
-  const float inv = 1.0f / S;
+  const int n = lens ? (int)lens[b] : S;
+  const float inv = 1.0f / n;
   for (int c = threadIdx.x; c < H; c += 256) {
     const float g = DT<T>::ld(dout + (long)b * H + c) * inv;
-    for (int s = 0; s < S; ++s) DT<T>::st(dx + ((long)b * S + s) * H + c, g);
+    for (int s = 0; s < S; ++s) DT<T>::st(dx + ((long)b * S + s) * H + c, s < n ? g : 0.f);
   }
 }
 
@@ -640,6 +645,80 @@ __global__ __launch_bounds__(64) void duet_fuse_bwd_kernel(const float* __restri
   }
 }
 
+// The whole tail of VLN-DUET/map_nav_src/models/vilmodel.py:1185-1217 in one launch per direction (one wave per sample):
+//   w = sigmoid(f[b]) (f == nullptr: 0.5)          global[g] = (visited[g] | !gmask[g]) ? -inf : graw[g] * w
+//   local[j] = nav[j] ? lraw[j] * (1 - w) : -inf    fused = duet_fuse(global, local)   (kernel above)
+// Replaces sigmoid, two scalings, 1 - w, two mask expressions, two masked_fills and the fuse launch (12 launches forward, as many backward).
+__device__ __forceinline__ float duet_w(const float* f, int b) { return f ? 1.f / (1.f + __expf(-f[b])) : 0.5f; }
+__global__ __launch_bounds__(64) void duet_heads_fwd_kernel(const float* __restrict__ graw, const float* __restrict__ lraw,
+                                                            const float* __restrict__ f, const unsigned char* __restrict__ visited,
+                                                            const unsigned char* __restrict__ gmask, const unsigned char* __restrict__ nav,
+                                                            const int* __restrict__ src, const unsigned char* __restrict__ bw,
+                                                            float* __restrict__ gl, float* __restrict__ ll, float* __restrict__ fused,
+                                                            int G, int V) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float w = duet_w(f, b), ninf = -__builtin_inff();
+  auto local = [&](int j) { return nav[b * V + j] ? lraw[b * V + j] * (1.f - w) : ninf; };
+  float s = 0.f;
+  for (int j = lane; j < V; j += 64) {
+    const float v = local(j);
+    ll[b * V + j] = v;
+    if (bw[b * V + j]) s += v;
+  }
+  s = wave_sum(s);
+  for (int g = lane; g < G; g += 64) {
+    const float v = (visited[b * G + g] || !gmask[b * G + g]) ? ninf : graw[b * G + g] * w;
+    gl[b * G + g] = v;
+    const int c = src[b * G + g];
+    float o = v;
+    if (g == 0) o += local(0);
+    else if (c >= 0) o += local(c);
+    else if (c == -2) o += s;
+    fused[b * G + g] = o;
+  }
+}
+// d_gl / d_ll / d_fused may each be null (output unused). dgraw, dlraw always written; df when f is given.
+__global__ __launch_bounds__(64) void duet_heads_bwd_kernel(const float* __restrict__ d_gl, const float* __restrict__ d_ll,
+                                                            const float* __restrict__ d_fu, const float* __restrict__ graw,
+                                                            const float* __restrict__ lraw, const float* __restrict__ f,
+                                                            const unsigned char* __restrict__ visited, const unsigned char* __restrict__ gmask,
+                                                            const unsigned char* __restrict__ nav, const int* __restrict__ src,
+                                                            const unsigned char* __restrict__ bw, float* __restrict__ dgraw,
+                                                            float* __restrict__ dlraw, float* __restrict__ df, int G, int V) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float w = duet_w(f, b);
+  float sb = 0.f, dw = 0.f;
+  if (d_fu)
+    for (int g = lane; g < G; g += 64)
+      if (g > 0 && src[b * G + g] == -2) sb += d_fu[b * G + g];
+  sb = wave_sum(sb);
+  for (int g = lane; g < G; g += 64) {
+    const bool dead = visited[b * G + g] || !gmask[b * G + g];
+    float d = 0.f;
+    if (!dead) {
+      d = (d_gl ? d_gl[b * G + g] : 0.f) + (d_fu ? d_fu[b * G + g] : 0.f);
+      dw += d * graw[b * G + g];
+    }
+    dgraw[b * G + g] = d * w;
+  }
+  for (int j = lane; j < V; j += 64) {
+    float d = 0.f;
+    if (nav[b * V + j]) {
+      d = d_ll ? d_ll[b * V + j] : 0.f;
+      if (d_fu) {
+        if (j == 0) d += d_fu[b * G];
+        for (int g = 1; g < G; ++g)
+          if (src[b * G + g] == j) d += d_fu[b * G + g];
+        if (bw[b * V + j]) d += sb;
+      }
+      dw -= d * lraw[b * V + j];
+    }
+    dlraw[b * V + j] = d * (1.f - w);
+  }
+  dw = wave_sum(dw);
+  if (df && lane == 0) df[b] = dw * w * (1.f - w);
+}
+
 // Observation / panorama tensors assembled ON THE DEVICE from a resident feature table (replaces the numpy
 // concatenations + 7 MB host->device copy per step of VLN-HAMT/finetune_src/r2r/agent_cmt.py:130-176 and
 // VLN-DUET/map_nav_src/r2r/agent.py:67-97). One block per output slot (b, v):
@@ -798,19 +877,19 @@ extern "C" int vlni_scatter_add_rows_small(int dtype, const void* src, long lds_
   return VLNI_OK;
 }
 
-extern "C" int vlni_seqmean_fwd(int dtype, const void* x, void* out, int B, int S, int H, void* stream) {
+extern "C" int vlni_seqmean_fwd(int dtype, const void* x, void* out, const long* lens, int B, int S, int H, void* stream) {
   VLNI_CHECK(B > 0 && S > 0 && H > 0, VLNI_EINVAL, "seqmean_fwd: %d %d %d", B, S, H);
-  BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_fwd_kernel<float>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, B, S, H),
-           hipLaunchKernelGGL((seqmean_fwd_kernel<__bf16>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)out, B, S, H),
-          hipLaunchKernelGGL((seqmean_fwd_kernel<_Float16>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)out, B, S, H));
+  BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_fwd_kernel<float>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)out, lens, B, S, H),
+           hipLaunchKernelGGL((seqmean_fwd_kernel<__bf16>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (__bf16*)out, lens, B, S, H),
+          hipLaunchKernelGGL((seqmean_fwd_kernel<_Float16>), dim3(B, cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)out, lens, B, S, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
-extern "C" int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, int B, int S, int H, void* stream) {
+extern "C" int vlni_seqmean_bwd(int dtype, const void* dout, void* dx, const long* lens, int B, int S, int H, void* stream) {
   VLNI_CHECK(B > 0 && S > 0 && H > 0, VLNI_EINVAL, "seqmean_bwd: %d %d %d", B, S, H);
-  BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_bwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)dout, (float*)dx, B, S, H),
-           hipLaunchKernelGGL((seqmean_bwd_kernel<__bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, (__bf16*)dx, B, S, H),
-          hipLaunchKernelGGL((seqmean_bwd_kernel<_Float16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dout, (_Float16*)dx, B, S, H));
+  BY_DTYPE(dtype, hipLaunchKernelGGL((seqmean_bwd_kernel<float>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float*)dout, (float*)dx, lens, B, S, H),
+           hipLaunchKernelGGL((seqmean_bwd_kernel<__bf16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const __bf16*)dout, (__bf16*)dx, lens, B, S, H),
+          hipLaunchKernelGGL((seqmean_bwd_kernel<_Float16>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dout, (_Float16*)dx, lens, B, S, H));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -1011,6 +1090,28 @@ extern "C" int vlni_duet_fuse_bwd(const float* dout, const int* src, const unsig
                                   void* stream) {
   VLNI_CHECK(B > 0 && G > 0 && V > 0 && dout && src && bw && dll, VLNI_EINVAL, "duet_fuse_bwd: B=%d G=%d V=%d", B, G, V);
   hipLaunchKernelGGL(duet_fuse_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, dout, src, bw, dll, G, V);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+extern "C" int vlni_duet_heads_fwd(const float* graw, const float* lraw, const float* f, const unsigned char* visited,
+                                   const unsigned char* gmask, const unsigned char* nav, const int* src, const unsigned char* bw,
+                                   float* gl, float* ll, float* fused, int B, int G, int V, void* stream) {
+  VLNI_CHECK(B > 0 && G > 0 && V > 0 && graw && lraw && visited && gmask && nav && src && bw && gl && ll && fused, VLNI_EINVAL,
+             "duet_heads_fwd: B=%d G=%d V=%d", B, G, V);
+  hipLaunchKernelGGL(duet_heads_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, graw, lraw, f, visited, gmask, nav, src, bw, gl, ll,
+                     fused, G, V);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+extern "C" int vlni_duet_heads_bwd(const float* d_gl, const float* d_ll, const float* d_fused, const float* graw, const float* lraw,
+                                   const float* f, const unsigned char* visited, const unsigned char* gmask, const unsigned char* nav,
+                                   const int* src, const unsigned char* bw, float* dgraw, float* dlraw, float* df, int B, int G, int V,
+                                   void* stream) {
+  VLNI_CHECK(B > 0 && G > 0 && V > 0 && graw && lraw && visited && gmask && nav && src && bw && dgraw && dlraw && (df || !f), VLNI_EINVAL,
+             "duet_heads_bwd: B=%d G=%d V=%d", B, G, V);
+  hipLaunchKernelGGL(duet_heads_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, d_gl, d_ll, d_fused, graw, lraw, f, visited, gmask,
+                     nav, src, bw, dgraw, dlraw, df, G, V);
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

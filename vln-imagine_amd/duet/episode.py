@@ -54,7 +54,11 @@ def run_episode(model, et, use_aux=True, train_ml=0.2, cosine_weight=0.5, criter
             "view_img_fts": s["view_img_fts"], "obj_img_fts": s.get("obj_img_fts"), "loc_fts": s["loc_fts"],
             "nav_types": s["nav_types"], "view_lens": s["view_lens"], "obj_lens": s.get("obj_lens")})
         plen = s["view_lens"] + s["obj_lens"] if has_obj else s["view_lens"]
-        avg = (pano * pano_masks.unsqueeze(2)).sum(1) / plen.to(pano.dtype)[:, None]      # agent.py:468-469
+        if pano.is_cuda:                                                                  # masked mean, agent.py:468-469
+            from vln_imagine_amd import ops
+            avg = ops.seq_mean(pano, plen.contiguous())
+        else:                                                                             # the CPU oracle driven through this loop (tests)
+            avg = (pano * pano_masks.unsqueeze(2)).sum(1) / plen.to(pano.dtype)[:, None]
         assert pano.shape[1] == et.pano_widths[t]
         if bank is None:
             bank = [torch.zeros_like(avg).unsqueeze(1)]
@@ -106,15 +110,15 @@ def _taped_inputs(et):
     Gs = [s["gmap_masks"].shape[1] for s in et.steps]
     Gmax, P = max(Gs), et.pano_widths[0]
     assert all(w == P for w in et.pano_widths)
-    S_T = 1 + T * (P + 1)                                   # bank rows per sample: zero row, then (avg_t, pano_t) per step
-    base = 1 + np.arange(T) * (P + 1)
+    # bank rows: (t, b, 0) = panorama mean of step t, (t, b, 1 + v) = view v of step t's panorama; one zero row at the very end
+    ZERO = T * B * (P + 1)
     pad2 = lambda x, G: torch.cat([x, x.new_zeros((B, Gmax - G) + tuple(x.shape[2:]))], 1) if G < Gmax else x
-    steps, off = [], np.zeros((T, B, Gmax), np.int64)
+    steps, off = [], np.full((T, B, Gmax), ZERO, np.int64)
     for t, s in enumerate(et.steps):
         G = Gs[t]
         for b, srcs in enumerate(ep.steps[t]["node_src"]):
             for j, src in enumerate(srcs):
-                off[t, b, j + 1] = base[src[1]] + (0 if src[0] == "avg" else 1 + src[2])
+                off[t, b, j + 1] = (src[1] * B + b) * (P + 1) + (0 if src[0] == "avg" else 1 + src[2])
         pd = s["gmap_pair_dists"]
         pdp = pd.new_zeros((B, Gmax, Gmax))
         pdp[:, :G, :G] = pd
@@ -127,13 +131,13 @@ def _taped_inputs(et):
             gmap_vpids=[list(v) + [None] * (Gmax - len(v)) for v in s["gmap_vpids"]],
             vp_pos_fts=s["vp_pos_fts"], vp_masks=torch.arange(P + 1, device=dev)[None, :] < (plen + 1)[:, None],
             vp_nav_masks=torch.cat([ones, s["nav_types"] == 1], 1), vp_cand_vpids=s["vp_cand_vpids"], target=s["target"]))
-    idx = torch.from_numpy(off + (np.arange(B) * S_T)[None, :, None]).to(dev)             # rows of the flattened [B * S_T, H] bank
+    idx = torch.from_numpy(off).to(dev)                                                  # rows of the flattened [T * B * (P + 1) + 1, H] bank
     cat = lambda k: torch.cat([st[k] for st in steps], 0).contiguous()
     full = {k: cat(k) for k in ("view_img_fts", "loc_fts", "nav_types", "view_lens", "gmap_step_ids", "gmap_pos_fts", "gmap_masks",
                                 "gmap_pair_dists", "gmap_visited_masks", "vp_pos_fts", "vp_masks", "vp_nav_masks", "target")}
     full["gmap_vpids"] = [v for st in steps for v in st["gmap_vpids"]]
     full["vp_cand_vpids"] = [v for st in steps for v in st["vp_cand_vpids"]]
-    et._taped = (steps, full, idx, Gmax, P, S_T)
+    et._taped = (steps, full, idx, Gmax, P, ZERO)
     return et._taped
 
 
@@ -148,7 +152,7 @@ def run_episode_taped(model, et, tape=None, use_aux=True, train_ml=0.2, cosine_w
     K / V projections are made once per episode (model.project_text). Results equal run_episode's to rounding (tests/test_tape_gpu.py)."""
     from vln_imagine_amd import ops
     ep, B, T, dev = et.ep, et.B, et.T, et.device
-    steps, full, idx, Gmax, P, S_T = _taped_inputs(et)
+    steps, full, idx, Gmax, P, ZERO = _taped_inputs(et)
     tape = tape if tape is not None else ops.EpisodeTape(T)
     assert tape.T >= T
     tape.reset()
@@ -163,9 +167,13 @@ def run_episode_taped(model, et, tape=None, use_aux=True, train_ml=0.2, cosine_w
     kv_g, kv_l, lm = model.project_text(txt, et.txt_masks, img, et.imagine_masks)          # once per episode, with autograd
     H = txt.shape[-1]
     dt = kv_g[0].dtype
-    bank = getattr(tape, "_bank", None)                      # [B, S_T, H]: zero row, then (avg_t, pano_t); rows of later steps stay zero
-    if bank is None or bank.shape != (B, S_T, H) or bank.dtype != dt:
-        bank = tape._bank = torch.zeros((B, S_T, H), dtype=dt, device=dev)
+    # bank [T * B * (P + 1) + 1, H] of panorama outputs (layout: _taped_inputs); rows of later steps and the last row stay zero.
+    # vpbuf [T, B, 1 + P, H]: each step's viewpoint tokens, slot 0 = the zero [STOP] embedding (agent.py:164-166)
+    bank = getattr(tape, "_bank", None)
+    if bank is None or bank.shape != (ZERO + 1, H) or bank.dtype != dt:
+        bank = tape._bank = torch.zeros((ZERO + 1, H), dtype=dt, device=dev)
+        tape._vpbuf = torch.zeros((T, B, 1 + P, H), dtype=dt, device=dev)
+    bank4, vpbuf = bank[:ZERO].view(T, B, P + 1, H), tape._vpbuf
 
     def nav_batch(st, gmap_img, vp_img, kvg, kvl, mask, rows):
         return {"txt_embeds": None, "txt_masks": None, "text_kv": (kvg, kvl, mask), "gmap_img_embeds": gmap_img,
@@ -180,12 +188,11 @@ def run_episode_taped(model, et, tape=None, use_aux=True, train_ml=0.2, cosine_w
             pano, pmask = model("panorama", {"view_img_fts": st["view_img_fts"], "obj_img_fts": None, "loc_fts": st["loc_fts"],
                                              "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": None})
         with torch.no_grad():
-            avg = (pano * pmask.unsqueeze(2)).sum(1) / st["view_lens"].to(pano.dtype)[:, None]
-            o = 1 + t * (P + 1)
-            bank[:, o] = avg
-            bank[:, o + 1:o + 1 + P] = pano
-            gmap_img = bank.reshape(B * S_T, H).index_select(0, idx[t].reshape(-1)).view(B, Gmax, H)
-            vp_img = torch.cat([torch.zeros_like(pano[:, :1]), pano], 1)
+            bank4[t, :, 0] = ops.seq_mean(pano, st["view_lens"])                 # masked mean, agent.py:468-469
+            bank4[t, :, 1:] = pano
+            gmap_img = bank.index_select(0, idx[t].reshape(-1)).view(B, Gmax, H)
+            vp_img = vpbuf[t]
+            vp_img[:, 1:] = pano
         with tape.record("navigation", t):
             nav = model("navigation", nav_batch(st, gmap_img, vp_img, kv_g, kv_l, lm, B))
         step_logits.append(nav["fused_logits"])
@@ -195,13 +202,10 @@ def run_episode_taped(model, et, tape=None, use_aux=True, train_ml=0.2, cosine_w
     with tape.ghost("panorama", compute=ghost_compute):
         pano_all, pmask_all = model("panorama", {"view_img_fts": full["view_img_fts"], "obj_img_fts": None, "loc_fts": full["loc_fts"],
                                                  "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None})
-    avg_all = (pano_all * pmask_all.unsqueeze(2)).sum(1) / full["view_lens"].to(pano_all.dtype)[:, None]          # [T * B, H]
-    pieces = [pano_all.new_zeros((B, 1, H))]
-    for t in range(T):
-        pieces += [avg_all[t * B:(t + 1) * B].unsqueeze(1), pano_all[t * B:(t + 1) * B]]
-    rows = torch.cat(pieces, 1).reshape(B * S_T, H)                                        # the full bank, with autograd
+    avg_all = ops.seq_mean(pano_all, full["view_lens"])                                     # [T * B, H]
+    rows = F.pad(torch.cat([avg_all.unsqueeze(1), pano_all], 1).reshape(ZERO, H), (0, 0, 0, 1))   # the full bank, with autograd
     gmap_all = rows.index_select(0, idx.reshape(-1)).view(T * B, Gmax, H)                   # step t's nodes only point at steps <= t
-    vp_all = torch.cat([pano_all.new_zeros((T * B, 1, H)), pano_all], 1)
+    vp_all = F.pad(pano_all, (0, 0, 1, 0))
     rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
     Lt = kv_g[0].shape[0] // B
     repkv = lambda kv: kv.view(B, Lt, -1).unsqueeze(0).expand(T, B, Lt, kv.shape[-1]).reshape(T * B * Lt, kv.shape[-1])

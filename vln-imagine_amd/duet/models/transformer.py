@@ -47,7 +47,7 @@ class TransformerEncoder(nn.Module):
 
     def forward(self, x, valid_mask):
         """valid_mask [B,S] bool (True = real view). Padded keys get -inf (src_key_padding_mask semantics)."""
-        km = torch.zeros(valid_mask.shape, dtype=torch.float32, device=x.device).masked_fill(~valid_mask, float("-inf"))
+        km = ops.additive_mask(valid_mask, inf=True)
         for l in self.layers:
             x = l(x, km)
         return ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)

@@ -297,7 +297,7 @@ class GlocalTextPathNavCMT(nn.Module):
             + ge.gmap_pos_embeddings.embed(gmap_pos_fts, dt)
         sprels = None
         if ge.sprel_linear is not None:                                                     # reference :1145-1147
-            sprels = (gmap_pair_dists * ge.sprel_linear.weight[0, 0] + ge.sprel_linear.bias[0]).contiguous()
+            sprels = torch.addcmul(ge.sprel_linear.bias[0], gmap_pair_dists, ge.sprel_linear.weight[0, 0])
         vp = vp_img_embeds.to(dt) + le.vp_pos_embeddings.embed(vp_pos_fts, dt)
         def language_side():
             """text (+ imagination tokens) and its additive key mask (reference :1110-1125)"""
@@ -348,14 +348,11 @@ class GlocalTextPathNavCMT(nn.Module):
         else:
             gmap = ge.encoder(txt, lm, gmap, gm, sprels, kvs=kv_g)
             vp = le.encoder(txt, lm, vp, vm, kvs=kv_l)
-        if self.sap_fuse_linear is None:
-            fuse = 0.5
-        else:
-            fuse = torch.sigmoid(self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1).contiguous()))[:, None]
-        ninf = -float("inf")
-        global_logits = (self.global_sap_head(gmap) * fuse).masked_fill(gmap_visited_masks | ~gmap_masks, ninf)
-        local_logits = (self.local_sap_head(vp) * (1 - fuse)).masked_fill(~vp_nav_masks, ninf)
-        fused_logits = self._fuse(global_logits, local_logits, gmap_vpids, gmap_visited_masks, vp_cand_vpids)
+        # reference :1185-1217: fuse weight, the two masked heads and the global / local fusion - one launch (ops.duet_heads)
+        f = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1).contiguous())
+        src, bw = self._fuse_plan(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, vp.shape[1])
+        global_logits, local_logits, fused_logits = ops.duet_heads(self.global_sap_head(gmap), self.local_sap_head(vp), f,
+                                                                   gmap_visited_masks, gmap_masks, vp_nav_masks, src, bw)
         obj_logits = self.og_head(vp, ~vp_obj_masks) if vp_obj_masks is not None else None      # reference :1220-1225
         return {"gmap_embeds": gmap, "vp_embeds": vp, "global_logits": global_logits, "local_logits": local_logits,
                 "fused_logits": fused_logits, "obj_logits": obj_logits}
@@ -381,22 +378,27 @@ class GlocalTextPathNavCMT(nn.Module):
                     src[i][j] = cand[vp] if vp in cand else -2
         return src, bw
 
-    def _fuse(self, gl, ll, gmap_vpids, visited_masks, vp_cand_vpids):
-        """fused[i,0] = g+l (stop); an unvisited map node takes the local logit of the candidate that IS that node,
-        otherwise the summed local logits of the already-visited candidates (backtrack) -- reference :1198-1217.
-        The per-sample python loop only builds an index plan (cached per (vpid lists, visited mask) identity, so a
-        teacher-forced / replayed episode pays the device->host read of the visited mask once); the arithmetic is one kernel."""
-        (B, G), V = gl.shape, ll.shape[1]
+    def _fuse_plan(self, gmap_vpids, visited_masks, vp_cand_vpids, G, V):
+        """Index plan of the fusion (reference :1198-1217: fused[i,0] = g+l (stop); an unvisited map node takes the local logit of the
+        candidate that IS that node, otherwise the summed local logits of the already-visited candidates (backtrack)) as device tensors,
+        cached per (vpid lists, visited mask) identity, so a teacher-forced / replayed episode pays the device->host read of the visited
+        mask once. The arithmetic is part of ops.duet_heads."""
+        B = len(gmap_vpids)
         key = (id(gmap_vpids), id(vp_cand_vpids), id(visited_masks), visited_masks._version, B, G, V)
         hit = self._fuse_plans.get(key)
         if hit is None:
             src, bw = self.fuse_plan(gmap_vpids, visited_masks.tolist(), vp_cand_vpids, G, V)
             if len(self._fuse_plans) >= 64:
                 self._fuse_plans.clear()
-            hit = self._fuse_plans[key] = (torch.tensor(src, dtype=torch.int32, device=gl.device),
-                                           torch.tensor(bw, dtype=torch.uint8, device=gl.device),
+            dev = visited_masks.device
+            hit = self._fuse_plans[key] = (torch.tensor(src, dtype=torch.int32, device=dev), torch.tensor(bw, dtype=torch.uint8, device=dev),
                                            (gmap_vpids, vp_cand_vpids, visited_masks))     # strong refs keep the ids unique
-        return ops.duet_fuse(gl, ll, hit[0], hit[1])
+        return hit[0], hit[1]
+
+    def _fuse(self, gl, ll, gmap_vpids, visited_masks, vp_cand_vpids):
+        """Fusion of already-masked logits alone (kept for callers that hold the two logit tensors)."""
+        src, bw = self._fuse_plan(gmap_vpids, visited_masks, vp_cand_vpids, gl.shape[1], ll.shape[1])
+        return ops.duet_fuse(gl, ll, src, bw)
 
     def forward(self, mode, batch, **kwargs):
         c = self.config

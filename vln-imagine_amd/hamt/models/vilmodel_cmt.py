@@ -605,21 +605,23 @@ class NavCMT(nn.Module):
         if return_cross_attention_probs and c.no_lang_ca:
             raise NotImplementedError("return_cross_attention_probs with no_lang_ca (the reference's own comment: 'this might break')")
         cross_probs, self_probs = [], []
-        hm, om = ops.additive_mask(hist_masks), ops.additive_mask(ob_masks)
         hist = hist_embeds.to(dt)
         if self.encoder.h_layers is not None:
+            hm = ops.additive_mask(hist_masks)
             for l in self.encoder.h_layers:
                 hist = l(hist, hm)
         ob = self.img_embeddings(ob_img_feats, ob_ang_feats, self.embeddings.token_type_embeddings.weight[1],
                                  ob_nav_types, dt)
         if self.encoder.r_layers is not None:
+            om = ops.additive_mask(ob_masks)
             for l in self.encoder.r_layers:
                 ob = l(ob, om)
         if self.fix_obs_embedding:
             ob = ob.detach()
         nh, no = hist.shape[1], ob.shape[1]
         txt_list = txt_embeds if isinstance(txt_embeds, list) else None
-        visn, vm = torch.cat([hist, ob], 1), torch.cat([hm, om], 1)
+        visn = torch.cat([hist, ob], 1)
+        vm = ops.additive_mask(torch.cat([hist_masks, ob_masks], 1))              # one conversion for the concatenated stream (:1059-1061)
         img_side = c.concat_imagine_with if c.imagine_enc_pano else None
         if c.imagine_enc_pano:
             assert imagine_embeds is not None

@@ -617,10 +617,13 @@ def cast(x, dtype, tape=False):
     return out
 
 
-def additive_mask(m):
-    """bool/0-1 mask [B,S] -> float32 additive (1-m)*-10000 (vilmodel_cmt.py:1010-1012). One kernel for bool masks."""
+def additive_mask(m, inf=False):
+    """bool/0-1 mask [B,S] -> float32 additive (1-m)*-10000 (vilmodel_cmt.py:1010-1012). One kernel for bool masks.
+    inf=True: -inf instead of -10000 (nn.MultiheadAttention's key_padding_mask, VLN-DUET/map_nav_src/models/transformer.py:71-89)."""
     if m.dtype == torch.bool:
-        return torch.where(m, _ZERO_NEG[0], _ZERO_NEG[1])
+        return torch.where(m, _ZERO_NEG[0], _ZERO_NEG[2 if inf else 1])
+    if inf:
+        return torch.where(m != 0, _ZERO_NEG[0], _ZERO_NEG[2])
     return (1.0 - m.to(torch.float32)) * NEG_MASK
 
 
@@ -634,7 +637,8 @@ class _Consts:
         dev = torch.cuda.current_device()
         c = self._c.get(dev)
         if c is None:
-            c = self._c[dev] = (torch.zeros((), dtype=torch.float32, device="cuda"), torch.full((), NEG_MASK, dtype=torch.float32, device="cuda"))
+            c = self._c[dev] = (torch.zeros((), dtype=torch.float32, device="cuda"), torch.full((), NEG_MASK, dtype=torch.float32, device="cuda"),
+                                torch.full((), float("-inf"), dtype=torch.float32, device="cuda"))
         return c[i]
 
 
@@ -1780,13 +1784,15 @@ class _SumLayerNorm(torch.autograd.Function):
 
 class _SeqMean(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, lens):
         B, S, H = x.shape
         x = _chk(x, "x").contiguous()
+        if lens is not None:
+            assert lens.shape == (B,) and lens.dtype == torch.int64 and lens.is_contiguous()
         out = _new((B, H), x.dtype, x.device)
         if not _ghost():
-            _lib.call("vlni_seqmean_fwd", _dt(x), x.data_ptr(), out.data_ptr(), B, S, H, _st())
-        ctx.dims = (B, S, H)
+            _lib.call("vlni_seqmean_fwd", _dt(x), x.data_ptr(), out.data_ptr(), _p(lens), B, S, H, _st())
+        ctx.dims, ctx.lens = (B, S, H), lens
         return out
 
     @staticmethod
@@ -1794,8 +1800,8 @@ class _SeqMean(torch.autograd.Function):
         B, S, H = ctx.dims
         dout = dout.contiguous()
         dx = torch.empty((B, S, H), dtype=dout.dtype, device=dout.device)
-        _lib.call("vlni_seqmean_bwd", _dt(dout), dout.data_ptr(), dx.data_ptr(), B, S, H, _st())
-        return dx
+        _lib.call("vlni_seqmean_bwd", _dt(dout), dout.data_ptr(), dx.data_ptr(), _p(ctx.lens), B, S, H, _st())
+        return dx, None
 
 
 class _RowDot(torch.autograd.Function):
@@ -1806,7 +1812,7 @@ class _RowDot(torch.autograd.Function):
         shp = h.shape
         h2 = _rows(_chk(h, "h"))
         rows, H = h2.shape
-        m8 = mask.reshape(-1).to(torch.uint8).contiguous() if mask is not None else None
+        m8 = _u8(mask).reshape(-1) if mask is not None else None
         out = _new((rows,), torch.float32, h.device)
         if not _ghost():
             _lib.call("vlni_rowdot_fwd", _dt(h2), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(bias), _p(m8), out.data_ptr(),
@@ -1859,6 +1865,51 @@ class _DuetFuse(torch.autograd.Function):
 
 def duet_fuse(gl, ll, src, bw):
     return _DuetFuse.apply(gl, ll, src, bw)
+
+
+def _u8(m):
+    """bool / uint8 mask as contiguous bytes (a bool tensor is reinterpreted, not copied)."""
+    m = m.contiguous()
+    return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+
+
+class _DuetHeads(torch.autograd.Function):
+    """(global_logits, local_logits, fused_logits) of a DUET navigation call from the two heads' raw outputs, the pre-sigmoid fuse
+    weight, the masks and the fusion plan: ONE launch per direction (vlni_duet_heads_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, graw, lraw, f, visited, gmask, nav, src, bw):
+        graw, lraw = _chk(graw, "global head").float().contiguous(), lraw.float().contiguous()
+        (B, G), V = graw.shape, lraw.shape[1]
+        assert src.shape == (B, G) and bw.shape == (B, V) and src.dtype == torch.int32 and bw.dtype == torch.uint8
+        assert visited.shape == (B, G) and gmask.shape == (B, G) and nav.shape == (B, V)
+        if f is not None:
+            f = f.float().reshape(B).contiguous()
+        vis8, gm8, nav8 = _u8(visited), _u8(gmask), _u8(nav)
+        gl, ll, fu = _new((B, G), torch.float32, graw.device), _new((B, V), torch.float32, graw.device), _new((B, G), torch.float32, graw.device)
+        if not _ghost():
+            _lib.call("vlni_duet_heads_fwd", graw.data_ptr(), lraw.data_ptr(), _p(f), vis8.data_ptr(), gm8.data_ptr(), nav8.data_ptr(),
+                      src.data_ptr(), bw.data_ptr(), gl.data_ptr(), ll.data_ptr(), fu.data_ptr(), B, G, V, _st())
+        ctx.save_for_backward(graw, lraw, f, vis8, gm8, nav8, src, bw)
+        ctx.set_materialize_grads(False)                # an unused output's gradient arrives as None, not as a zero tensor
+        return gl, ll, fu
+
+    @staticmethod
+    def backward(ctx, d_gl, d_ll, d_fu):
+        graw, lraw, f, vis8, gm8, nav8, src, bw = ctx.saved_tensors
+        (B, G), V = graw.shape, lraw.shape[1]
+        c = lambda d: None if d is None else d.float().contiguous()
+        d_gl, d_ll, d_fu = c(d_gl), c(d_ll), c(d_fu)
+        dgraw, dlraw = torch.empty_like(graw), torch.empty_like(lraw)
+        df = torch.empty((B,), dtype=torch.float32, device=graw.device) if f is not None else None
+        _lib.call("vlni_duet_heads_bwd", _p(d_gl), _p(d_ll), _p(d_fu), graw.data_ptr(), lraw.data_ptr(), _p(f), vis8.data_ptr(),
+                  gm8.data_ptr(), nav8.data_ptr(), src.data_ptr(), bw.data_ptr(), dgraw.data_ptr(), dlraw.data_ptr(), _p(df), B, G, V, _st())
+        return dgraw, dlraw, df, None, None, None, None, None
+
+
+def duet_heads(graw, lraw, f, visited, gmask, nav, src, bw):
+    """f: [B] / [B,1] pre-sigmoid fuse weight or None (fixed 0.5, glocal_fuse off)."""
+    return _DuetHeads.apply(graw, lraw, f, visited, gmask, nav, src, bw)
 
 
 class _CrossEntropySum(torch.autograd.Function):
@@ -2097,8 +2148,9 @@ def sum_layer_norm(srcs, g, b, rows, out_dtype, eps=1e-12):
     return _SumLayerNorm.apply(spec, idxs, eps, out_dtype, rows, g, b, *[t for t, _, _ in srcs])
 
 
-def seq_mean(x):
-    return _SeqMean.apply(x)
+def seq_mean(x, lens=None):
+    """[B,S,H] -> [B,H] mean over the sequence; lens (int64 [B]): over each sample's first lens[b] rows only."""
+    return _SeqMean.apply(x, lens)
 
 
 def row_dot(h, w, bias, mask):
