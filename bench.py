@@ -589,6 +589,43 @@ def main():
                 if md != args.mode:
                     s_, _, _, _ = measure(w, trainer, k_extra, 2, mode=md, graph=args.graph, what=md)
                     extras[md] = line(s_, w.flops, note)
+        if args.model == "hamt" and args.graph:
+            # a SAMPLED rollout's launch pattern: T + 2 graph replays with the host in between (it reads step t's logits - one sync per
+            # step - and only then provides step t + 1's observation and step t's history features), ONE episode-batched backward
+            from vln_imagine_amd.hamt.buckets import EpisodeBuffers, SteppedEpisodeGraphs
+            import gc
+            gc.collect()
+            bufs = EpisodeBuffers(args.batch, args.L, args.V, args.I, args.T, dev).load(w.et.ep)
+            sg = SteppedEpisodeGraphs(trainer, w.model, bufs)
+
+            def sampled_episode():
+                sg.begin()
+                acts = []
+                for t in range(args.T):
+                    for k in EpisodeBuffers.OBS_KEYS:
+                        bufs.steps[t][k].copy_(w.et.steps[t][k])
+                    if t > 0:
+                        for k in EpisodeBuffers.HIST_KEYS:
+                            bufs.steps[t - 1][k].copy_(w.et.steps[t - 1][k])
+                    sg.step(t)
+                    acts.append(sg.logits(t).argmax(1).cpu())             # the host decides where to go
+                for k in EpisodeBuffers.HIST_KEYS:
+                    bufs.steps[args.T - 1][k].copy_(w.et.steps[args.T - 1][k])
+                return sg.finish()
+
+            sampled_episode()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(k_extra):
+                sampled_episode()
+            fence()
+            s_ = (time.perf_counter() - t0) / k_extra
+            log(f"sampled-stepped: timed {1e3 * s_:.2f} ms/step")
+            extras["sampled_stepped"] = line(s_, w.flops, "a sampled rollout's pattern (hamt.buckets.SteppedEpisodeGraphs): begin | T step graphs | ghost + "
+                                                          "backward + optimizer, the host reading each step's logits (argmax, one sync) before it writes the next "
+                                                          "observation; history call lags one step (no side-stream overlap); same episode-batched backward")
+            del sg, bufs
+            gc.collect()
         if args.model == "hamt" and args.lang_rows == "all":
             w.model.visual_lang_rows = "cls"
             s_, _, _, _ = measure(w, trainer, k_extra, 2, mode=args.mode, graph=args.graph, what="cls-rows")

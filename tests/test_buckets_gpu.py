@@ -107,3 +107,90 @@ def test_bucket_replay_costs_what_a_fixed_shape_replay_costs():
         assert bucket_ms <= 1.25 * fixed_ms + 0.5, (bucket_ms, fixed_ms)
     finally:
         tr.close()
+
+
+def _grads(model):
+    return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+
+def test_lagging_history_tape_equals_step_by_step_autograd():
+    """TapedEpisode(lag_history=True) - the order a sampled rollout forces: history of step t - 1 opens step t - gives run_episode's
+    logits, loss and gradients (fp32, ragged episode)."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.episode import run_episode_taped
+    cfg = HamtConfig(**HAMT_C1)
+    model = build_product(cfg)
+    et = EpisodeTensors(synth.HamtEpisode(tag="lag", B=4, L=64, V=31, I=I, T=4, ragged=True), "cuda")
+    ref = run_episode(model, et, criterion=ops.cross_entropy_sum)
+    ref["loss"].backward()
+    g_ref = _grads(model)
+    model.zero_grad(set_to_none=True)
+    seen = []
+    out = run_episode_taped(model, et, criterion=ops.cross_entropy_sum, lag_history=True, on_step=lambda t, lg, st: seen.append((lg.clone(), st.clone())))
+    out["loss"].backward()
+    g_lag = _grads(model)
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) <= 1e-5 * max(1.0, abs(float(ref["loss"].detach())))
+    for t in range(et.T):
+        fin = torch.isfinite(ref["logits"][t])
+        assert torch.equal(torch.isfinite(seen[t][0]), fin)
+        assert torch.allclose(seen[t][0][fin], ref["logits"][t][fin], atol=2e-5), t
+        assert torch.allclose(seen[t][1], ref["states"][t], atol=2e-5), t
+    assert g_ref.keys() == g_lag.keys()
+    for n in g_ref:
+        assert torch.allclose(g_lag[n], g_ref[n], atol=1e-5 + 1e-4 * float(g_ref[n].abs().max())), n
+
+
+def test_stepped_episode_graphs_train_like_the_eager_tape():
+    """hamt.buckets.SteppedEpisodeGraphs: begin | T step graphs | backward + optimizer, the host writing step t's observation and step
+    t - 1's history features only just before step t's replay (what a sampled rollout does) - the same losses, per-step logits and
+    parameters as the eager lagging tape on the same stream of episodes."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.buckets import EpisodeBuffers, SteppedEpisodeGraphs
+    from vln_imagine_amd.hamt.episode import run_episode_taped
+    from vln_imagine_amd.train import FlatTrainer
+    cfg = HamtConfig(**HAMT_C1)
+    L, V, T = 64, 31, 3
+    eps = [synth.HamtEpisode(tag=f"st{i}", B=B, L=L - 3 * i, V=V - i, I=I, T=T, ragged=True) for i in range(4)]
+    m_g, m_e = build_product(cfg), build_product(cfg)
+    tr_g, tr_e = FlatTrainer(m_g, lr=1e-4), FlatTrainer(m_e, lr=1e-4)
+    try:
+        # ---- eager reference: the lagging tape on its own static buffers ----
+        bufs_e = EpisodeBuffers(B, L, V, I, T, "cuda")
+        losses_e, logits_e = [], []
+        head = m_e.contrastive_alignment_model
+        for ep in eps:
+            bufs_e.load(ep)
+            tr_e.zero_grad()
+            head.set_static_plan(bufs_e.plan)
+            out = run_episode_taped(m_e, bufs_e, criterion=ops.cross_entropy_sum, lag_history=True)
+            head.set_static_plan(None)
+            out["loss"].backward()
+            tr_e.allreduce_grads()
+            tr_e.step()
+            losses_e.append(float(out["loss"]))
+            logits_e.append([t.detach().clone() for t in out["step_logits"]])
+        # ---- graphs: the warm-up trains on episode 0, episodes 1.. replay ----
+        bufs = EpisodeBuffers(B, L, V, I, T, "cuda").load(eps[0])
+        g = SteppedEpisodeGraphs(tr_g, m_g, bufs)
+        for i, ep in enumerate(eps[1:], 1):
+            bufs.load(ep, steps=False)
+            g.begin()
+            for t in range(T):
+                bufs.put_hist_lens(t, ep.hist_lens[t])
+                bufs.put_step(t, ep.steps[t], keys=EpisodeBuffers.OBS_KEYS + ("target",))
+                if t > 0:
+                    bufs.put_step(t - 1, ep.steps[t - 1], keys=EpisodeBuffers.HIST_KEYS)
+                g.step(t)
+                a, b = g.logits(t), logits_e[i][t]
+                fin = torch.isfinite(b)
+                assert torch.equal(torch.isfinite(a), fin) and torch.allclose(a[fin], b[fin], atol=1e-4), (i, t)
+            bufs.put_step(T - 1, ep.steps[T - 1], keys=EpisodeBuffers.HIST_KEYS)
+            loss = g.finish()
+            assert abs(float(loss) - losses_e[i]) <= 1e-4 * max(1.0, abs(losses_e[i])), (i, float(loss), losses_e[i])
+        assert tr_g.step_no == tr_e.step_no == len(eps)
+        # Adam moves an element by about lr per step whatever its gradient's size: elements whose gradient is rounding noise (atomic
+        # summation order differs between a replay and an eager run) may differ by a few lr, the rest agree
+        d = (tr_g.flat_p - tr_e.flat_p).abs()
+        assert float(d.max()) <= 2 * 1e-4 * len(eps) and float(d.mean()) <= 2e-6, (float(d.max()), float(d.mean()))
+    finally:
+        tr_g.close(); tr_e.close()

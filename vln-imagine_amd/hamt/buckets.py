@@ -28,18 +28,24 @@ class EpisodeBuffers:
         z = lambda *s, dt=torch.float32: torch.zeros(s, dtype=dt, device=dev)
         self.txt_ids, self.txt_masks = z(B, L, dt=torch.int64), z(B, L, dt=torch.bool)
         self.imagine_feats, self.imagine_masks = z(B, I, feat), z(B, I, dt=torch.bool)
-        self.steps = [dict(ob_img_feats=z(B, V, feat), ob_ang_feats=z(B, V, ang), ob_nav_types=z(B, V, dt=torch.int64),
-                           ob_masks=z(B, V, dt=torch.bool), target=z(B, dt=torch.int64), hist_img_feats=z(B, feat),
-                           hist_ang_feats=z(B, ang), hist_pano_img_feats=z(B, pano, feat), hist_pano_ang_feats=z(B, pano, ang))
-                      for _ in range(T)]
+        # step inputs live in ONE [T * B, ...] buffer per key (step t = rows [t B, (t + 1) B)): run_episode reads the per-step views,
+        # the episode tape (hamt.episode.TapedEpisode) the whole buffers through full(k)
+        self._full = dict(ob_img_feats=z(T * B, V, feat), ob_ang_feats=z(T * B, V, ang), ob_nav_types=z(T * B, V, dt=torch.int64),
+                          ob_masks=z(T * B, V, dt=torch.bool), target=z(T * B, dt=torch.int64), hist_img_feats=z(T * B, feat),
+                          hist_ang_feats=z(T * B, ang), hist_pano_img_feats=z(T * B, pano, feat), hist_pano_ang_feats=z(T * B, pano, ang))
+        self.steps = [{k: v[t * B:(t + 1) * B] for k, v in self._full.items()} for t in range(T)]
         self.step_ids = [torch.tensor([i], device=dev) for i in range(T)]
         self.hist_masks = [torch.ones((B, t + 1), dtype=torch.bool, device=dev) for t in range(T)]
+        self.hist_lens_dev = (torch.arange(T, device=dev) + 1)[:, None].expand(T, B).contiguous()     # [T, B], model_HAMT.py:62-63
         cap = B * I
         self.plan = dict(rows=z(cap, dt=torch.int64), scored=z(cap, dt=torch.int64), seg_off=z(cap + 1, dt=torch.int32),
                          tok_rows=z(B * L, dt=torch.int32), weight=z(cap), count=torch.ones((), dtype=torch.float32, device=dev),
                          target=torch.full((cap,), cap, dtype=torch.int64, device=dev))
         self.ep = self                       # run_episode reads the annotation lists from `.ep`; the static plan replaces them
         self.sub_instr_segs = self.sub_instr_imag_flag = self.noun_phrase_segs = None
+
+    def full(self, k):
+        return self._full[k]
 
     @staticmethod
     def _put(dst, src):
@@ -48,18 +54,34 @@ class EpisodeBuffers:
         host[tuple(slice(0, n) for n in src.shape)] = src
         dst.copy_(torch.from_numpy(host), non_blocking=False)
 
-    def load(self, ep):
+    OBS_KEYS = ("ob_img_feats", "ob_ang_feats", "ob_nav_types", "ob_masks")
+    HIST_KEYS = ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats")
+
+    def put_step(self, t, src, keys=None):
+        """Writes step t's inputs `keys` (default: all of observation, history features, target) from numpy arrays, padded to the bucket."""
+        for k in keys or (self.OBS_KEYS + self.HIST_KEYS + ("target",)):
+            buf = self.steps[t][k]
+            if k == "target":
+                buf.copy_(torch.from_numpy(np.asarray(src[k])))
+            else:
+                self._put(buf, np.asarray(src[k], dtype=np.float32) if buf.dtype == torch.float32 else src[k])
+
+    def put_hist_lens(self, t, lens):
+        """History length of every sample before step t (model_HAMT.py:62-63); step t's graph reads it."""
+        self.hist_lens_dev[t].copy_(torch.as_tensor(lens))
+        self.hist_masks[t].copy_(torch.arange(t + 1)[None, :] < torch.as_tensor(lens)[:, None])
+
+    def load(self, ep, steps=True):
+        """Instruction side (text, imaginations, alignment plan) and - unless steps=False: a rollout fills them as it goes - all T steps."""
         assert ep.B == self.B and ep.I == self.I and ep.T == self.T and ep.L <= self.L and ep.V <= self.V, "episode does not fit the bucket"
         self._put(self.txt_ids, ep.txt_ids)
         self._put(self.txt_masks, ep.txt_masks)
         self._put(self.imagine_feats, ep.imagine_feats.astype(np.float32))
         self._put(self.imagine_masks, ep.imagine_masks)
-        for dst, src in zip(self.steps, ep.steps):
-            for k, buf in dst.items():
-                if k == "target":
-                    buf.copy_(torch.from_numpy(src[k]))
-                else:
-                    self._put(buf, np.asarray(src[k], dtype=np.float32) if buf.dtype == torch.float32 else src[k])
+        if steps:
+            for t, src in enumerate(ep.steps):
+                self.put_hist_lens(t, ep.hist_lens[t])
+                self.put_step(t, src)
         # ---- the alignment head's index lists (the reference's triple loop, vilmodel_cmt.py:755-785, with its assertions) ----
         B, L, I, cap = self.B, self.L, self.I, self.B * self.I
         rows, scored, seg_off, tok = [], [], [0], []
@@ -150,3 +172,68 @@ class HamtGraphBuckets:
             return loss, logits
         loss = ent[1]()
         return loss, ent[2]["logits"]
+
+
+class SteppedEpisodeGraphs:
+    """Graph replay for rollouts whose next observation depends on the action (sampling / RL, r2r/agent_cmt.py:498-606, :814-827): the
+    episode is captured as T + 2 graphs - begin | step 0 | ... | step T-1 | ghost pass + backward + optimizer - over one set of static
+    buffers (`bufs`, an EpisodeBuffers); between two replays the caller reads step t's logits (`logits(t)`, a static tensor), picks the
+    action, asks its simulator, and writes step t + 1's observation and step t's history features into `bufs` (`put_step`). The history
+    call lags by one step (TapedEpisode(lag_history=True)). The backward is still ONE episode-batched pass.
+
+        g = SteppedEpisodeGraphs(trainer, model, bufs)           # one eager warm-up episode on the data in `bufs`, then the capture
+        g.begin()                                               # after bufs.load_text(...) / load(ep)
+        for t in range(T):
+            g.step(t); a = g.logits(t).argmax(1)                # host decides; bufs.put_step(t + 1, ...), bufs.put_history(t, ...)
+        loss = g.finish()                                       # targets written into bufs.full('target') before this
+    """
+
+    def __init__(self, trainer, model, bufs, tape=None, want_states=False, **episode_kw):
+        from vln_imagine_amd.hamt.episode import TapedEpisode
+        self.trainer, self.model, self.bufs = trainer, model, bufs
+        self.head = getattr(model, "contrastive_alignment_model", None)
+        self.ep = TapedEpisode(model, bufs, tape if tape is not None else ops.EpisodeTape(bufs.T), criterion=ops.cross_entropy_sum,
+                               lag_history=True, want_states=want_states, **episode_kw)
+        self._out, self._steps = {}, {}
+
+        def begin():
+            if self.head is not None:
+                self.head.set_static_plan(bufs.plan)
+            try:
+                self.ep.begin()
+            finally:
+                if self.head is not None:
+                    self.head.set_static_plan(None)
+
+        def step(t):
+            def run():
+                lg, st = self.ep.step(t)
+                self._steps[t] = (lg.detach(), st.detach() if st is not None else None)
+            return run
+
+        def finish():
+            out = self.ep.finish()
+            loss = out["loss"]
+            if model.compute_dtype == torch.float16:               # the fused step divides the trainer's loss scale out again
+                (loss * trainer.loss_scale).backward()
+            else:
+                loss.backward()
+            self._out["logits"] = [t.detach() for t in out["logits"]]
+            return loss.detach()
+
+        self.graphs = trainer.capture(finish, warmup=1, stages=[begin] + [step(t) for t in range(bufs.T)])
+
+    def begin(self):
+        self.graphs.stage(0)
+
+    def step(self, t):
+        self.graphs.stage(1 + t)
+
+    def logits(self, t):
+        return self._steps[t][0]
+
+    def state(self, t):
+        return self._steps[t][1]
+
+    def finish(self):
+        return self.graphs.finish()

@@ -150,105 +150,168 @@ def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2,
             "imagine_embeds": img, "hist": list(hist_steps)}
 
 
-def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
-                      ghost_compute=False, overlap_history=True):
+class TapedEpisode:
     """Step-by-step FORWARD - the call pattern a sampled rollout needs: step t + 1's observation may depend on the action chosen from step
-    t's logits (`on_step(t, logits, states)`, r2r/agent_cmt.py:498-606) - and ONE episode-batched BACKWARD (vln_imagine_amd.ops.EpisodeTape):
-    the T `visual` / `history` calls write their activations into slices of episode-wide buffers, a ghost pass of the same model code
-    over the T x B samples records the autograd graph without launching a kernel, and loss.backward() then runs on T x longer launches.
+    t's logits (r2r/agent_cmt.py:498-606) - and ONE episode-batched BACKWARD (vln_imagine_amd.ops.EpisodeTape): the T `visual` /
+    `history` calls write their activations into slices of episode-wide buffers, a ghost pass of the same model code over the T x B
+    samples records the autograd graph without launching a kernel, and loss.backward() then runs on T x longer launches.
     Valid because no transformer output of step t enters step t + 1's input: history tokens are re-encoded from features
-    (vilmodel_cmt.py:576-618, 1056-1205). Every step sees the history padded to T entries ([CLS, h_0 .. h_{t-1}, 0 ..] with the mask of
+    (vilmodel_cmt.py:576-618, 1056-1205). Every step sees the history padded to T entries ([CLS, h_0 .. h_{t-1}, ...] with the mask of
     model_HAMT.py:62-63); logits, loss and gradients equal run_episode's to rounding (tests/test_tape_gpu.py).
-    ghost_compute=True (tests): the batched pass COMPUTES with the recorded dropout seeds instead of reusing the steps' buffers.
-    overlap_history: step t's `history` call (the panorama encoder: 2.3 k-row launches that fill a fifth of the chip) runs on a second
-    stream beside step t's `visual` call - both read features and h_0 .. h_{t-1} only - and its ghost pass is recorded on that stream, so
-    autograd runs the history encoder's batched backward there too, beside the text encoder's."""
-    from vln_imagine_amd import ops
-    ep, B, T = et.ep, et.B, et.T
-    dev = et.txt_ids.device
-    tape = tape if tape is not None else ops.EpisodeTape(T)
-    assert tape.T >= T
-    tape.reset()
-    txt = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
-    img = model("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None if bypass else et.imagine_masks)
-    aux = None
-    if use_aux:
-        aux, img = model("align_with_contrastive_loss", align_txt_embeds=txt, txt_masks=et.txt_masks, align_imagine_embeds=img,
-                         imagine_masks=et.imagine_masks, sub_instr_segs=ep.sub_instr_segs,
-                         sub_instr_imag_flag=ep.sub_instr_imag_flag, noun_phrase_segs=ep.noun_phrase_segs)
-    cls = model("history").expand(B, -1)                                                   # [B, H]
-    H, dt = cls.shape[-1], cls.dtype
-    ar = torch.arange(T, device=dev)
-    lens = et.hist_lens_dev[:T]                                                            # [T, B] history length before step t
-    valid = ar[None, None, :] < lens[:, :, None]                                            # [step t, sample b, entry j]
-    hm_full = valid.reshape(T * B, T).contiguous()
-    # history inputs of all steps: sample (t, b) holds [CLS, h_0 .. h_{t-1}, 0 ...]. Entries beyond t are never written, so the buffer is
-    # zeroed once per tape; the recorded steps read slices of it, the ghost pass an autograd expression with the same values
-    hb = getattr(tape, "_hist_buf", None)
-    if hb is None or hb.shape != (T, B, T, H) or hb.dtype != dt:
-        hb = tape._hist_buf = torch.zeros((T, B, T, H), dtype=dt, device=dev)
-    with torch.no_grad():
-        hb[:, :, 0] = cls
-    f = et.full
-    for k in ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats", "ob_img_feats", "ob_ang_feats",
-              "ob_nav_types", "ob_masks", "target"):
-        f(k)                                                   # built (once) on the main stream before any side-stream reader
-    main = torch.cuda.current_stream() if dev.type == "cuda" else None
-    side = None
-    if overlap_history and main is not None:
-        side = getattr(tape, "_side", None)
-        if side is None:
-            side = tape._side = torch.cuda.Stream()
 
-    def history_step(t, sl):
-        with tape.record("history", t):
-            return model("history", hist_img_feats=f("hist_img_feats")[sl], hist_ang_feats=f("hist_ang_feats")[sl],
-                         ob_step_ids=et.step_ids[t], hist_pano_img_feats=f("hist_pano_img_feats")[sl],
-                         hist_pano_ang_feats=f("hist_pano_ang_feats")[sl])
+    Three phases, so that each can be its own captured hipGraph with host code (action choice, simulator) between them
+    (train.GraphedStep(stages=...), hamt.buckets.SteppedEpisodeGraphs):
+      begin()     language, imaginations, alignment head, history [CLS]
+      step(t)     -> (logits [B, V], state [B, H] or None); reads step t's slices of et.full(k)
+      finish()    ghost pass + loss -> the dict run_episode_taped returns
 
-    step_logits = []
-    for t in range(T):
+    lag_history=False (teacher forcing: the view taken at step t is known up front): step t's `history` call (the panorama encoder: 2.3 k-row
+      launches that fill a fifth of the chip) runs on a second stream beside step t's `visual` call - both read features and h_0 .. h_{t-1}
+      only - and its ghost pass is recorded on that stream, so autograd runs the history encoder's batched backward there too.
+    lag_history=True (sampled rollouts: the history features of step t exist only after the action was chosen from step t's logits):
+      `history` of step t - 1 opens step t, the last one opens finish(); et.hist_lens_dev[t] is read inside step t, so the caller may
+      write it (and step t's observation / step t - 1's history features) any time before step t.
+    ghost_compute=True (tests): the batched pass COMPUTES with the recorded dropout seeds instead of reusing the steps' buffers."""
+
+    def __init__(self, model, et, tape=None, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum,
+                 ghost_compute=False, overlap_history=True, lag_history=False, want_states=False):
+        from vln_imagine_amd import ops
+        self.model, self.et, self.B, self.T = model, et, et.B, et.T
+        self.tape = tape if tape is not None else ops.EpisodeTape(et.T)
+        assert self.tape.T >= et.T
+        self.bypass, self.use_aux, self.train_ml, self.cosine_weight, self.criterion = bypass, use_aux, train_ml, cosine_weight, criterion
+        self.ghost_compute, self.lag, self.want_states = ghost_compute, lag_history, want_states
+        self.overlap = overlap_history and not lag_history
+        self.step_logits = []
+
+    def _history(self, t):
+        f, B = self.et.full, self.B
         sl = slice(t * B, (t + 1) * B)
-        if side is not None:
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                h = history_step(t, sl)
+        with self.tape.record("history", t):
+            return self.model("history", hist_img_feats=f("hist_img_feats")[sl], hist_ang_feats=f("hist_ang_feats")[sl],
+                              ob_step_ids=self.et.step_ids[t], hist_pano_img_feats=f("hist_pano_img_feats")[sl],
+                              hist_pano_ang_feats=f("hist_pano_ang_feats")[sl])
+
+    def begin(self):
+        model, et, tape, B, T = self.model, self.et, self.tape, self.B, self.T
+        ep = et.ep
+        dev = et.txt_ids.device
+        tape.reset()
+        self.step_logits = []
+        self.txt = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
+        img = model("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None if self.bypass else et.imagine_masks)
+        self.aux = None
+        if self.use_aux:
+            self.aux, img = model("align_with_contrastive_loss", align_txt_embeds=self.txt, txt_masks=et.txt_masks, align_imagine_embeds=img,
+                                  imagine_masks=et.imagine_masks, sub_instr_segs=ep.sub_instr_segs,
+                                  sub_instr_imag_flag=ep.sub_instr_imag_flag, noun_phrase_segs=ep.noun_phrase_segs)
+        self.img = img
+        self.cls = cls = model("history").expand(B, -1)                                        # [B, H]
+        H, dt = cls.shape[-1], cls.dtype
+        self.ar = torch.arange(T, device=dev)
+        # history inputs of all steps: sample (t, b) holds [CLS, h_0 .. h_{t-1}, ...]. Entries beyond a sample's history length are masked
+        # keys: teacher forcing zeroes them (all lengths are known), a lagging history leaves later entries as they are (finite: the buffer
+        # is zeroed once per tape). The recorded steps read slices of it, the ghost pass an autograd expression with the same values
+        hb = getattr(tape, "_hist_buf", None)
+        if hb is None or hb.shape != (T, B, T, H) or hb.dtype != dt:
+            hb = tape._hist_buf = torch.zeros((T, B, T, H), dtype=dt, device=dev)
+        self.hb = hb
+        with torch.no_grad():
+            hb[:, :, 0] = cls
+        if not self.lag:
+            lens = et.hist_lens_dev[:T]                                                        # [T, B] history length before step t
+            self.valid = self.ar[None, None, :] < lens[:, :, None]                             # [step t, sample b, entry j]
+            self.hm_full = self.valid.reshape(T * B, T).contiguous()
+        for k in ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats", "ob_img_feats", "ob_ang_feats",
+                  "ob_nav_types", "ob_masks", "target"):
+            et.full(k)                                         # built (once) on the main stream before any side-stream reader
+        self.main = torch.cuda.current_stream() if dev.type == "cuda" else None
+        self.side = None
+        if self.overlap and self.main is not None:
+            self.side = getattr(tape, "_side", None)
+            if self.side is None:
+                self.side = tape._side = torch.cuda.Stream()
+
+    def step(self, t):
+        model, et, tape, B, T, hb = self.model, self.et, self.tape, self.B, self.T, self.hb
+        f, main, side = et.full, self.main, self.side
+        sl = slice(t * B, (t + 1) * B)
+        if self.lag:
+            if t > 0:
+                h = self._history(t - 1)
+                with torch.no_grad():
+                    hb[t:, :, t] = h
+            hm = self.ar[None, :] < et.hist_lens_dev[t][:, None]
+        else:
+            hm = self.hm_full[sl]
+            if side is not None:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    h = self._history(t)
         with tape.record("visual", t):
             lg, txt_o, hist_o, ob_o = model(
-                "visual", txt_embeds=txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm_full[sl],
+                "visual", txt_embeds=self.txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm,
                 ob_img_feats=f("ob_img_feats")[sl], ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
-                ob_masks=f("ob_masks")[sl], imagine_embeds=img, imagine_masks=et.imagine_masks)
-        step_logits.append(lg)
-        if on_step is not None:
-            on_step(t, lg, txt_o[:, 0] * hist_o[:, 0])
+                ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=et.imagine_masks)
+        self.step_logits.append(lg)
+        state = txt_o[:, 0] * hist_o[:, 0] if self.want_states else None                      # model_HAMT.py:86
+        if not self.lag:
+            if side is not None:
+                main.wait_stream(side)
+            else:
+                h = self._history(t)
+            if t + 1 < T:
+                with torch.no_grad():
+                    hb[t + 1:, :, t + 1] = h * self.valid[t + 1:, :, t + 1, None].to(h.dtype)
+        return lg, state
+
+    def finish(self):
+        """The ghost pass: the same two calls on the T x B samples; no kernels, only the autograd graph over the filled buffers."""
+        model, et, tape, B, T = self.model, self.et, self.tape, self.B, self.T
+        f, main, side, ar = et.full, self.main, self.side, self.ar
+        if self.lag:
+            self._history(T - 1)                     # consumed by no step; run so that the batched backward reads defined activations
+            valid = ar[None, None, :] < et.hist_lens_dev[:T][:, :, None]
+            hm_full = valid.reshape(T * B, T).contiguous()
+        else:
+            valid, hm_full = self.valid, self.hm_full
+        if side is not None:
+            side.wait_stream(main)
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+            with tape.ghost("history", compute=self.ghost_compute):
+                h_all = model("history", hist_img_feats=f("hist_img_feats"), hist_ang_feats=f("hist_ang_feats"),
+                              ob_step_ids=ar.repeat_interleave(B), hist_pano_img_feats=f("hist_pano_img_feats"),
+                              hist_pano_ang_feats=f("hist_pano_ang_feats"))
         if side is not None:
             main.wait_stream(side)
+        H = h_all.shape[-1]
+        prefix = torch.cat([self.cls.to(h_all.dtype).unsqueeze(0), h_all.view(T, B, H)[:T - 1]], 0)    # entries 0 .. T-1 as [entry, B, H]
+        if self.lag:                                                  # entry j of sample (t, b): written for every t >= j, never masked to zero
+            hist = prefix.permute(1, 0, 2).unsqueeze(0).expand(T, B, T, H)
         else:
-            h = history_step(t, sl)
-        if t + 1 < T:
-            with torch.no_grad():
-                hb[t + 1:, :, t + 1] = h * valid[t + 1:, :, t + 1, None].to(h.dtype)
-    # ---- ghost pass: the same two calls on the T x B samples; no kernels, only the autograd graph over the filled buffers ----
-    if side is not None:
-        side.wait_stream(main)
-    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-        with tape.ghost("history", compute=ghost_compute):
-            h_all = model("history", hist_img_feats=f("hist_img_feats"), hist_ang_feats=f("hist_ang_feats"),
-                          ob_step_ids=ar.repeat_interleave(B), hist_pano_img_feats=f("hist_pano_img_feats"),
-                          hist_pano_ang_feats=f("hist_pano_ang_feats"))
-    if side is not None:
-        main.wait_stream(side)
-    prefix = torch.cat([cls.to(h_all.dtype).unsqueeze(0), h_all.view(T, B, H)[:T - 1]], 0)    # entries 0 .. T-1 as [entry, B, H]
-    hist = prefix.permute(1, 0, 2).unsqueeze(0) * valid.to(h_all.dtype)[:, :, :, None]        # [T, B, T, H], zeros beyond the valid entries
-    rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
-    with tape.ghost("visual", compute=ghost_compute):
-        logits, txt_o, hist_o, ob_o = model(
-            "visual", txt_embeds=rep(txt), txt_masks=rep(et.txt_masks), hist_embeds=hist.reshape(T * B, T, H), hist_masks=hm_full,
-            ob_img_feats=f("ob_img_feats"), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
-            ob_masks=f("ob_masks"), imagine_embeds=rep(img), imagine_masks=rep(et.imagine_masks))
-    ml_loss = criterion(logits, f("target"))
-    loss = ml_loss * train_ml / B
-    if use_aux and torch.is_tensor(aux):
-        loss = loss + cosine_weight * aux
-    return {"loss": loss, "ml_loss": ml_loss, "aux": aux, "logits": list(logits.view(T, B, -1)), "step_logits": step_logits,
-            "txt_embeds": txt, "imagine_embeds": img, "hist": list(h_all.view(T, B, H)), "tape": tape}
+            hist = prefix.permute(1, 0, 2).unsqueeze(0) * valid.to(h_all.dtype)[:, :, :, None]        # zeros beyond the valid entries
+        rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+        with tape.ghost("visual", compute=self.ghost_compute):
+            logits, txt_o, hist_o, ob_o = model(
+                "visual", txt_embeds=rep(self.txt), txt_masks=rep(et.txt_masks), hist_embeds=hist.reshape(T * B, T, H), hist_masks=hm_full,
+                ob_img_feats=f("ob_img_feats"), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
+                ob_masks=f("ob_masks"), imagine_embeds=rep(self.img), imagine_masks=rep(et.imagine_masks))
+        ml_loss = self.criterion(logits, f("target"))
+        loss = ml_loss * self.train_ml / B
+        if self.use_aux and torch.is_tensor(self.aux):
+            loss = loss + self.cosine_weight * self.aux
+        return {"loss": loss, "ml_loss": ml_loss, "aux": self.aux, "logits": list(logits.view(T, B, -1)), "step_logits": self.step_logits,
+                "txt_embeds": self.txt, "imagine_embeds": self.img, "hist": list(h_all.view(T, B, H)), "tape": tape}
+
+
+def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
+                      ghost_compute=False, overlap_history=True, lag_history=False):
+    """One episode through TapedEpisode: begin, T steps (`on_step(t, logits, state)` may choose the action), finish."""
+    te = TapedEpisode(model, et, tape, bypass, use_aux, train_ml, cosine_weight, criterion, ghost_compute, overlap_history, lag_history,
+                      want_states=on_step is not None)
+    te.begin()
+    for t in range(et.T):
+        lg, state = te.step(t)
+        if on_step is not None:
+            on_step(t, lg, state)
+    return te.finish()

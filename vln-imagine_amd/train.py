@@ -455,7 +455,7 @@ class FlatTrainer:
         for p in self.params:
             p._vlni_defer = bool(on)
 
-    def capture(self, fwd_bwd, warmup=1):
+    def capture(self, fwd_bwd, warmup=1, stages=()):
         """Captures the training step into hipGraphs and returns a callable that replays them.
 
         fwd_bwd() runs forward + backward (on fixed-shape, fixed-address inputs; refill them in place between calls) and
@@ -464,21 +464,31 @@ class FlatTrainer:
         `overlap_chunks` graphs and the RCCL all-reduce of each chunk runs eagerly on a side stream under the next chunk's
         weight-gradient GEMMs (a collective is never part of a capture). `warmup` REAL steps run first on a side stream
         (lazy initialisation, GEMM autotune). Drop every reference to earlier losses / outputs before calling this: an
-        autograd graph that is still alive keeps its AccumulateGrad nodes on the old stream, which breaks the capture."""
-        return GraphedStep(self, fwd_bwd, warmup)
+        autograd graph that is still alive keeps its AccumulateGrad nodes on the old stream, which breaks the capture.
+        `stages`: phases to capture as separate graphs in front of fwd_bwd (GraphedStep)."""
+        return GraphedStep(self, fwd_bwd, warmup, stages)
 
 
 class GraphedStep:
-    def __init__(self, trainer, fwd_bwd, warmup=1):
+    """One training step as replayable hipGraphs: [zero_grad + forward + backward] -> gradient flush (one graph per exchange range
+    when world > 1) -> [clip + AdamW]. `stages`: callables that run BEFORE fwd_bwd, each captured as its own graph in the same
+    memory pool - the phases of an episode between which the host must act (a sampled rollout: begin / step 0 / ... / step T-1 with the
+    action choice and the simulator in between, hamt.episode.TapedEpisode); replay them in order with stage(i), then finish().
+    Calling the object replays everything back to back."""
+
+    def __init__(self, trainer, fwd_bwd, warmup=1, stages=()):
         import gc
         self.trainer = trainer
         self.epoch = trainer.graph_epoch
+        stages = list(stages)
         gc.collect()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 trainer.zero_grad()
+                for st in stages:
+                    st()
                 fwd_bwd()
                 trainer.allreduce_grads()
                 trainer.step()
@@ -493,10 +503,23 @@ class GraphedStep:
         # With a process group alive its watchdog thread may make HIP calls while this thread captures: capture in thread-local error
         # mode so that those calls neither fail nor invalidate the capture (torch's default "global" mode would do both)
         mode = dict(capture_error_mode="thread_local") if (dist.is_available() and dist.is_initialized()) else {}
-        self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb, **mode):
+        self.g_stages, pool = [], None
+
+        def first():
             self.seed_base.add_(7919)
             trainer.zero_grad()
+        for i, st in enumerate(stages):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **(dict(pool=pool) if pool is not None else {}), **mode):
+                if i == 0:
+                    first()
+                st()
+            pool = g.pool()
+            self.g_stages.append(g)
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb, **(dict(pool=pool) if pool is not None else {}), **mode):
+            if not stages:
+                first()
             self.loss = fwd_bwd()
             if not split:
                 trainer.flush()
@@ -517,7 +540,12 @@ class GraphedStep:
             trainer.step()
         trainer.step_no -= 1                   # recorded, not executed
 
-    def __call__(self):
+    def stage(self, i):
+        if self.epoch != self.trainer.graph_epoch:
+            raise RuntimeError("a parameter group was switched on / off after this step was captured: capture() again")
+        self.g_stages[i].replay()
+
+    def finish(self):
         if self.epoch != self.trainer.graph_epoch:
             raise RuntimeError("a parameter group was switched on / off after this step was captured: capture() again")
         self.g_fb.replay()
@@ -526,3 +554,8 @@ class GraphedStep:
         self.g_opt.replay()
         self.trainer.step_no += 1
         return self.loss
+
+    def __call__(self):
+        for i in range(len(self.g_stages)):
+            self.stage(i)
+        return self.finish()
