@@ -152,8 +152,10 @@ def test_stepped_episode_graphs_train_like_the_eager_tape():
     L, V, T = 64, 31, 3
     eps = [synth.HamtEpisode(tag=f"st{i}", B=B, L=L - 3 * i, V=V - i, I=I, T=T, ragged=True) for i in range(4)]
     m_g, m_e = build_product(cfg), build_product(cfg)
-    tr_g, tr_e = FlatTrainer(m_g, lr=1e-4), FlatTrainer(m_e, lr=1e-4)
+    LR = 1e-6           # Adam moves every element by about lr per step whatever its gradient's size: keep the two models' drift below the tolerances
+    tr_g, tr_e = FlatTrainer(m_g, lr=LR), FlatTrainer(m_e, lr=LR)
     try:
+        p0 = tr_g.flat_p.clone()
         # ---- eager reference: the lagging tape on its own static buffers ----
         bufs_e = EpisodeBuffers(B, L, V, I, T, "cuda")
         losses_e, logits_e = [], []
@@ -183,14 +185,15 @@ def test_stepped_episode_graphs_train_like_the_eager_tape():
                 g.step(t)
                 a, b = g.logits(t), logits_e[i][t]
                 fin = torch.isfinite(b)
-                assert torch.equal(torch.isfinite(a), fin) and torch.allclose(a[fin], b[fin], atol=1e-4), (i, t)
+                assert torch.equal(torch.isfinite(a), fin) and float((a[fin] - b[fin]).abs().max()) <= 1e-4 * max(1.0, float(b[fin].abs().max())), (i, t)
             bufs.put_step(T - 1, ep.steps[T - 1], keys=EpisodeBuffers.HIST_KEYS)
             loss = g.finish()
             assert abs(float(loss) - losses_e[i]) <= 1e-4 * max(1.0, abs(losses_e[i])), (i, float(loss), losses_e[i])
         assert tr_g.step_no == tr_e.step_no == len(eps)
-        # Adam moves an element by about lr per step whatever its gradient's size: elements whose gradient is rounding noise (atomic
-        # summation order differs between a replay and an eager run) may differ by a few lr, the rest agree
+        # elements whose gradient is rounding noise (atomic summation order differs between a replay and an eager run) may differ by a
+        # few lr, the rest agree; and both did train
         d = (tr_g.flat_p - tr_e.flat_p).abs()
-        assert float(d.max()) <= 2 * 1e-4 * len(eps) and float(d.mean()) <= 2e-6, (float(d.max()), float(d.mean()))
+        moved = (tr_g.flat_p - p0).abs()
+        assert float(d.max()) <= 2 * LR * len(eps) and float(d.mean()) <= 0.05 * float(moved.mean()), (float(d.max()), float(d.mean()), float(moved.mean()))
     finally:
         tr_g.close(); tr_e.close()
