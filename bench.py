@@ -160,7 +160,10 @@ class Workload:
         'time_batched' (HAMT) = forward AND backward on T x B samples (teacher forcing only)."""
         kw = {} if criterion is None else {"criterion": criterion}
         if mode == "time_batched":
-            from vln_imagine_amd.hamt.episode import run_episode_time_batched
+            if self.family == "duet":
+                from vln_imagine_amd.duet.episode import run_episode_time_batched
+            else:
+                from vln_imagine_amd.hamt.episode import run_episode_time_batched
             return run_episode_time_batched(model or self.model, et or self.et, **kw)
         if mode == "taped":
             from vln_imagine_amd import ops
@@ -582,6 +585,9 @@ def main():
         if args.model == "duet" and args.mode != "stepwise":
             s_, _, _, _ = measure(w, trainer, k_extra, 2, mode="stepwise", graph=args.graph, what="stepwise")
             extras["stepwise"] = line(s_, w.flops, "one autograd graph per `panorama` / `navigation` call (rounds 1-2's path)")
+        if args.model == "duet" and args.mode != "time_batched":
+            s_, _, _, _ = measure(w, trainer, k_extra, 2, mode="time_batched", graph=args.graph, what="time_batched")
+            extras["time_batched"] = line(s_, w.flops, "forward AND backward on T x B samples, maps padded to the episode's largest (teacher forcing only); same results")
         if args.model == "hamt":
             for md, note in (("stepwise", "one autograd graph per `visual` / `history` call (rounds 1-2's headline path): T x shorter backward launches"),
                              ("time_batched", "forward AND backward on T x B samples (teacher forcing only); same results"),

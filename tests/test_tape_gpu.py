@@ -176,3 +176,120 @@ def test_duet_taped_bf16_with_dropout_is_consistent_with_its_computed_batch():
         assert (a[fin] - b[fin]).abs().max().item() < 3e-5 and (c[fin] - b[fin]).abs().max().item() < 3e-5, t
     assert abs(o1["loss"].item() - o2["loss"].item()) < 1e-5
     _grads_close(m1, m2, 5e-5, "duet dropout")
+
+
+@pytest.mark.parametrize("variant", ["c1_T3_dense", "c1_shipped"])
+def test_duet_time_batched_episode_equals_stepwise_fp32(variant):
+    """DUET under teacher forcing as ONE panorama call and ONE navigation call on T x B samples (duet.episode.run_episode_time_batched):
+    logits of every step, loss and every gradient equal the step-by-step rollout (float32)."""
+    from tests.golden.variants import duet_variant_setup
+    from tests.test_duet_gpu import build_product as build_duet
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode as run_duet, run_episode_time_batched
+    cfg, ep = duet_variant_setup(variant)
+    et = DuetEpisodeTensors(ep, "cuda")
+    m1, m2 = build_duet(cfg), build_duet(cfg)
+    o1 = run_duet(m1, et, criterion=ops.cross_entropy_sum)
+    o1["loss"].backward()
+    o2 = run_episode_time_batched(m2, et, criterion=ops.cross_entropy_sum)
+    o2["loss"].backward()
+    assert abs(o1["loss"].item() - o2["loss"].item()) < 1e-5
+    for t in range(ep.T):
+        for key in ("fused", "global", "local"):
+            a, b = o1[key][t], o2[key][t][:, :o1[key][t].shape[1]]
+            fin = torch.isfinite(a)
+            assert (torch.isfinite(b) == fin).all(), (key, t)
+            assert (a[fin] - b[fin]).abs().max().item() < 3e-5, (key, t)
+    _grads_close(m1, m2, 5e-5, variant)
+
+
+def _duet_stream(n, B, I, T):
+    from vln_imagine_amd import synth
+    return [synth.DuetEpisode(tag=f"ds{i}", B=B, L=80 - 7 * (i % 3), V=36, I=I, T=T, ragged=True) for i in range(n)]
+
+
+def test_duet_bucket_graphs_replay_with_eager_logits():
+    """duet.buckets.DuetGraphBuckets: episodes with different text lengths and map sizes padded into one (L, Gmax, T) bucket replay from the
+    bucket's captured step with the logits of the unpadded eager rollout at the current weights; padded map nodes can never be chosen."""
+    from tests.test_duet_gpu import build_product as build_duet
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.duet.buckets import DuetGraphBuckets
+    from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode as run_duet
+    from vln_imagine_amd.train import FlatTrainer
+    B, I, T = 4, 4, 3
+    cfg = duet_cfg_c1()
+    model = build_duet(cfg)
+    tr = FlatTrainer(model, lr=1e-5)
+    gb = DuetGraphBuckets(tr, model, B, I, l_buckets=(80,), g_buckets=(16,))
+    try:
+        for i, ep in enumerate(_duet_stream(4, B, I, T)):
+            with torch.no_grad():
+                ref = run_duet(model, DuetEpisodeTensors(ep, "cuda"), criterion=ops.cross_entropy_sum)
+            p0 = tr.flat_p.clone()
+            loss, fused = gb.step(ep)
+            assert abs(float(loss) - float(ref["loss"])) <= 1e-4 * max(1.0, abs(float(ref["loss"]))), i
+            for t in range(T):
+                G = ref["fused"][t].shape[1]
+                a, b = fused[t][:, :G], ref["fused"][t]
+                fin = torch.isfinite(b)
+                assert torch.equal(torch.isfinite(a), fin) and (a[fin] - b[fin]).abs().max().item() <= 1e-4 * max(1.0, b[fin].abs().max().item()), (i, t)
+                assert bool(torch.isinf(fused[t][:, G:]).all())
+            assert not torch.equal(tr.flat_p, p0)
+        assert len(gb.buckets) == 1 and tr.step_no == 4
+    finally:
+        tr.close()
+
+
+def duet_cfg_c1():
+    from tests.golden.variants import duet_variant_setup
+    return duet_variant_setup("c1_T3_dense")[0]
+
+
+def test_duet_stepped_episode_graphs_train_like_the_eager_tape():
+    """duet.buckets.SteppedEpisodeGraphs: begin | T step graphs | backward + optimizer with the host writing step t (panorama, map, fusion
+    plan, node sources) only just before step t's replay - per-step logits, losses and parameters of the eager tape on the same episodes."""
+    from tests.test_duet_gpu import build_product as build_duet
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.duet.buckets import DuetEpisodeBuffers, SteppedEpisodeGraphs
+    from vln_imagine_amd.duet.episode import run_episode_taped as run_duet_taped
+    from vln_imagine_amd.train import FlatTrainer
+    B, I, T, L, G = 4, 4, 3, 80, 16
+    cfg = duet_cfg_c1()
+    eps = _duet_stream(4, B, I, T)
+    m_g, m_e = build_duet(cfg), build_duet(cfg)
+    LR = 1e-6
+    tr_g, tr_e = FlatTrainer(m_g, lr=LR), FlatTrainer(m_e, lr=LR)
+    try:
+        p0 = tr_g.flat_p.clone()
+        bufs_e = DuetEpisodeBuffers(B, L, I, T, G, "cuda")
+        head = m_e.contrastive_alignment_model
+        losses_e, logits_e = [], []
+        for ep in eps:
+            bufs_e.load(ep)
+            tr_e.zero_grad()
+            head.set_static_plan(bufs_e.plan)
+            out = run_duet_taped(m_e, bufs_e, criterion=ops.cross_entropy_sum)
+            head.set_static_plan(None)
+            out["loss"].backward()
+            tr_e.allreduce_grads()
+            tr_e.step()
+            losses_e.append(float(out["loss"].detach()))
+            logits_e.append([t.detach().clone() for t in out["step_logits"]])
+        bufs = DuetEpisodeBuffers(B, L, I, T, G, "cuda").load(eps[0])
+        g = SteppedEpisodeGraphs(tr_g, m_g, bufs)
+        for i, ep in enumerate(eps[1:], 1):
+            bufs.load(ep, steps=False)
+            g.begin()
+            for t in range(T):
+                bufs.put_step(t, ep.steps[t])
+                g.step(t)
+                a, b = g.logits(t), logits_e[i][t]
+                fin = torch.isfinite(b)
+                assert torch.equal(torch.isfinite(a), fin) and float((a[fin] - b[fin]).abs().max()) <= 1e-4 * max(1.0, float(b[fin].abs().max())), (i, t)
+            loss = g.finish()
+            assert abs(float(loss) - losses_e[i]) <= 1e-4 * max(1.0, abs(losses_e[i])), (i, float(loss), losses_e[i])
+        d, moved = (tr_g.flat_p - tr_e.flat_p).abs(), (tr_g.flat_p - p0).abs()
+        assert tr_g.step_no == tr_e.step_no == len(eps)
+        assert float(d.max()) <= 2 * LR * len(eps) and float(d.mean()) <= 0.05 * float(moved.mean()), (float(d.max()), float(d.mean()), float(moved.mean()))
+    finally:
+        tr_g.close(); tr_e.close()

@@ -141,81 +141,131 @@ def _taped_inputs(et):
     return et._taped
 
 
-def run_episode_taped(model, et, tape=None, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
-                      ghost_compute=False):
-    """GMapNavAgent.rollout with a step-by-step FORWARD (`on_step(t, fused_logits)` may pick the next viewpoint, agent.py:409-500) and ONE
-    episode-batched BACKWARD (vln_imagine_amd.ops.EpisodeTape, see hamt/episode.py:run_episode_taped): the T `panorama` / `navigation`
+def _nav_batch(st, gmap_img, vp_img, kvg, kvl, mask):
+    return {"txt_embeds": None, "txt_masks": None, "text_kv": (kvg, kvl, mask), "gmap_img_embeds": gmap_img,
+            "gmap_step_ids": st["gmap_step_ids"], "gmap_pos_fts": st["gmap_pos_fts"], "gmap_masks": st["gmap_masks"],
+            "gmap_pair_dists": st["gmap_pair_dists"], "gmap_visited_masks": st["gmap_visited_masks"], "gmap_vpids": st["gmap_vpids"],
+            "vp_img_embeds": vp_img, "vp_pos_fts": st["vp_pos_fts"], "vp_masks": st["vp_masks"], "vp_nav_masks": st["vp_nav_masks"],
+            "vp_obj_masks": None, "vp_cand_vpids": st["vp_cand_vpids"], "imagine_embeds": None, "imagine_masks": None,
+            "fuse_plan": st.get("fuse_plan")}
+
+
+class TapedEpisode:
+    """GMapNavAgent.rollout with a step-by-step FORWARD (the caller may pick the next viewpoint from step t's fused logits, agent.py:409-500)
+    and ONE episode-batched BACKWARD (vln_imagine_amd.ops.EpisodeTape, see hamt/episode.py:TapedEpisode): the T `panorama` / `navigation`
     calls write their activations into slices of episode-wide buffers, a ghost pass of the same model code over T x B samples records the
     autograd graph, and backward runs on T x longer launches (DUET's per-step launches are 0.2-1.2 k rows: latency-bound). Every step's
     map is padded to the episode's largest (masked like a ragged batch's padding); map-node images are rows of a bank of panorama
     outputs that only ever grows (agent.py:468-479), so the ghost pass gathers every step's nodes from the one full bank. The text-side
-    K / V projections are made once per episode (model.project_text). Results equal run_episode's to rounding (tests/test_tape_gpu.py)."""
-    from vln_imagine_amd import ops
-    ep, B, T, dev = et.ep, et.B, et.T, et.device
-    steps, full, idx, Gmax, P, ZERO = _taped_inputs(et)
-    tape = tape if tape is not None else ops.EpisodeTape(T)
-    assert tape.T >= T
-    tape.reset()
-    txt = model("language", {"txt_ids": et.txt_ids, "txt_masks": et.txt_masks})
-    img = model("imagine", {"imagine_feats": et.imagine_feats, "imagine_masks": et.imagine_masks})
-    aux = None
-    if use_aux:
-        aux, img = model("align_with_contrastive_loss", {
-            "align_txt_embeds": txt, "txt_masks": et.txt_masks, "align_imagine_embeds": img, "imagine_masks": et.imagine_masks,
-            "obs_instr_ids": [f"i{b}" for b in range(B)], "sub_instr_segs": ep.sub_instr_segs,
-            "sub_instr_imag_flag": ep.sub_instr_imag_flag, "noun_phrase_segs": ep.noun_phrase_segs})
-    kv_g, kv_l, lm = model.project_text(txt, et.txt_masks, img, et.imagine_masks)          # once per episode, with autograd
-    H = txt.shape[-1]
-    dt = kv_g[0].dtype
-    # bank [T * B * (P + 1) + 1, H] of panorama outputs (layout: _taped_inputs); rows of later steps and the last row stay zero.
-    # vpbuf [T, B, 1 + P, H]: each step's viewpoint tokens, slot 0 = the zero [STOP] embedding (agent.py:164-166)
-    bank = getattr(tape, "_bank", None)
-    if bank is None or bank.shape != (ZERO + 1, H) or bank.dtype != dt:
-        bank = tape._bank = torch.zeros((ZERO + 1, H), dtype=dt, device=dev)
-        tape._vpbuf = torch.zeros((T, B, 1 + P, H), dtype=dt, device=dev)
-    bank4, vpbuf = bank[:ZERO].view(T, B, P + 1, H), tape._vpbuf
+    K / V projections are made once per episode (model.project_text). Results equal run_episode's to rounding (tests/test_tape_gpu.py).
 
-    def nav_batch(st, gmap_img, vp_img, kvg, kvl, mask, rows):
-        return {"txt_embeds": None, "txt_masks": None, "text_kv": (kvg, kvl, mask), "gmap_img_embeds": gmap_img,
-                "gmap_step_ids": st["gmap_step_ids"], "gmap_pos_fts": st["gmap_pos_fts"], "gmap_masks": st["gmap_masks"],
-                "gmap_pair_dists": st["gmap_pair_dists"], "gmap_visited_masks": st["gmap_visited_masks"], "gmap_vpids": st["gmap_vpids"],
-                "vp_img_embeds": vp_img, "vp_pos_fts": st["vp_pos_fts"], "vp_masks": st["vp_masks"], "vp_nav_masks": st["vp_nav_masks"],
-                "vp_obj_masks": None, "vp_cand_vpids": st["vp_cand_vpids"], "imagine_embeds": None, "imagine_masks": None}
+    Phases (each may be its own captured graph, duet.buckets): begin() | step(t) -> fused logits [B, Gmax] | finish() -> result dict.
+    Step t reads step t's slices of the padded inputs only (`_taped_inputs`: static buffers when `et` is a duet.buckets.DuetEpisodeBuffers, which
+    a rollout fills as it goes), finish() all of them."""
 
-    step_logits = []
-    for t, st in enumerate(steps):
+    def __init__(self, model, et, tape=None, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, ghost_compute=False):
+        from vln_imagine_amd import ops
+        self.model, self.et, self.B, self.T = model, et, et.B, et.T
+        self.tape = tape if tape is not None else ops.EpisodeTape(et.T)
+        assert self.tape.T >= et.T
+        self.use_aux, self.train_ml, self.cosine_weight, self.criterion, self.ghost_compute = use_aux, train_ml, cosine_weight, criterion, ghost_compute
+        self.step_logits = []
+
+    def _language(self):
+        model, et, B = self.model, self.et, self.B
+        ep = et.ep
+        self.txt = model("language", {"txt_ids": et.txt_ids, "txt_masks": et.txt_masks})
+        img = model("imagine", {"imagine_feats": et.imagine_feats, "imagine_masks": et.imagine_masks})
+        self.aux = None
+        if self.use_aux:
+            self.aux, img = model("align_with_contrastive_loss", {
+                "align_txt_embeds": self.txt, "txt_masks": et.txt_masks, "align_imagine_embeds": img, "imagine_masks": et.imagine_masks,
+                "obs_instr_ids": [f"i{b}" for b in range(B)], "sub_instr_segs": ep.sub_instr_segs,
+                "sub_instr_imag_flag": ep.sub_instr_imag_flag, "noun_phrase_segs": ep.noun_phrase_segs})
+        self.img = img
+        self.kv_g, self.kv_l, self.lm = model.project_text(self.txt, et.txt_masks, img, et.imagine_masks)   # once per episode, with autograd
+
+    def begin(self):
+        et, tape, B, T = self.et, self.tape, self.B, self.T
+        self.steps, self.full, self.idx, self.Gmax, self.P, self.ZERO = _taped_inputs(et)
+        tape.reset()
+        self.step_logits = []
+        self._language()
+        H, dt, dev, P, ZERO = self.txt.shape[-1], self.kv_g[0].dtype, et.device, self.P, self.ZERO
+        # bank [T * B * (P + 1) + 1, H] of panorama outputs (layout: _taped_inputs); rows of later steps and the last row stay zero.
+        # vpbuf [T, B, 1 + P, H]: each step's viewpoint tokens, slot 0 = the zero [STOP] embedding (agent.py:164-166)
+        bank = getattr(tape, "_bank", None)
+        if bank is None or bank.shape != (ZERO + 1, H) or bank.dtype != dt:
+            bank = tape._bank = torch.zeros((ZERO + 1, H), dtype=dt, device=dev)
+            tape._vpbuf = torch.zeros((T, B, 1 + P, H), dtype=dt, device=dev)
+        self.bank, self.bank4, self.vpbuf = bank, bank[:ZERO].view(T, B, P + 1, H), tape._vpbuf
+
+    def step(self, t):
+        from vln_imagine_amd import ops
+        model, tape, B, st = self.model, self.tape, self.B, self.steps[t]
         with tape.record("panorama", t):
             pano, pmask = model("panorama", {"view_img_fts": st["view_img_fts"], "obj_img_fts": None, "loc_fts": st["loc_fts"],
                                              "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": None})
         with torch.no_grad():
-            bank4[t, :, 0] = ops.seq_mean(pano, st["view_lens"])                 # masked mean, agent.py:468-469
-            bank4[t, :, 1:] = pano
-            gmap_img = bank.index_select(0, idx[t].reshape(-1)).view(B, Gmax, H)
-            vp_img = vpbuf[t]
+            self.bank4[t, :, 0] = ops.seq_mean(pano, st["view_lens"])                 # masked mean, agent.py:468-469
+            self.bank4[t, :, 1:] = pano
+            gmap_img = self.bank.index_select(0, self.idx[t].reshape(-1)).view(B, self.Gmax, -1)
+            vp_img = self.vpbuf[t]
             vp_img[:, 1:] = pano
         with tape.record("navigation", t):
-            nav = model("navigation", nav_batch(st, gmap_img, vp_img, kv_g, kv_l, lm, B))
-        step_logits.append(nav["fused_logits"])
+            nav = model("navigation", _nav_batch(st, gmap_img, vp_img, self.kv_g, self.kv_l, self.lm))
+        self.step_logits.append(nav["fused_logits"])
+        return nav["fused_logits"]
+
+    def _batched(self, ctx_pano, ctx_nav):
+        """`panorama` and `navigation` on all T x B samples (the ghost pass of the tape; the whole forward under teacher forcing)."""
+        from vln_imagine_amd import ops
+        model, B, T, full, Gmax, ZERO = self.model, self.B, self.T, self.full, self.Gmax, self.ZERO
+        kv_g, kv_l, lm = self.kv_g, self.kv_l, self.lm
+        H = self.txt.shape[-1]
+        with ctx_pano:
+            pano_all, pmask_all = model("panorama", {"view_img_fts": full["view_img_fts"], "obj_img_fts": None, "loc_fts": full["loc_fts"],
+                                                     "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None})
+        avg_all = ops.seq_mean(pano_all, full["view_lens"])                                     # [T * B, H]
+        rows = F.pad(torch.cat([avg_all.unsqueeze(1), pano_all], 1).reshape(ZERO, H), (0, 0, 0, 1))   # the full bank, with autograd
+        gmap_all = rows.index_select(0, self.idx.reshape(-1)).view(T * B, Gmax, H)              # step t's nodes only point at steps <= t
+        vp_all = F.pad(pano_all, (0, 0, 1, 0))
+        rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+        Lt = kv_g[0].shape[0] // B
+        repkv = lambda kv: kv.view(B, Lt, -1).unsqueeze(0).expand(T, B, Lt, kv.shape[-1]).reshape(T * B * Lt, kv.shape[-1])
+        with ctx_nav:
+            nav = model("navigation", _nav_batch(full, gmap_all, vp_all, [repkv(k) for k in kv_g], [repkv(k) for k in kv_l], rep(lm)))
+        ml_loss = self.criterion(nav["fused_logits"], full["target"])
+        loss = ml_loss * self.train_ml / B
+        if self.use_aux and torch.is_tensor(self.aux):
+            loss = loss + self.cosine_weight * self.aux
+        Tn = lambda x: list(x.view((T, B) + tuple(x.shape[1:])))
+        return {"loss": loss, "ml_loss": ml_loss, "aux": self.aux, "fused": Tn(nav["fused_logits"]), "global": Tn(nav["global_logits"]),
+                "local": Tn(nav["local_logits"]), "pano": Tn(pano_all), "step_logits": self.step_logits, "txt_embeds": self.txt,
+                "imagine_embeds": self.img, "tape": self.tape, "gmax": Gmax}
+
+    def finish(self):
+        return self._batched(self.tape.ghost("panorama", compute=self.ghost_compute), self.tape.ghost("navigation", compute=self.ghost_compute))
+
+
+def run_episode_taped(model, et, tape=None, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
+                      ghost_compute=False):
+    """One episode through TapedEpisode: begin, T steps (`on_step(t, fused_logits)` may pick the next viewpoint), finish."""
+    te = TapedEpisode(model, et, tape, use_aux, train_ml, cosine_weight, criterion, ghost_compute)
+    te.begin()
+    for t in range(et.T):
+        lg = te.step(t)
         if on_step is not None:
-            on_step(t, nav["fused_logits"])
-    # ---- ghost pass over the T x B samples ----
-    with tape.ghost("panorama", compute=ghost_compute):
-        pano_all, pmask_all = model("panorama", {"view_img_fts": full["view_img_fts"], "obj_img_fts": None, "loc_fts": full["loc_fts"],
-                                                 "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None})
-    avg_all = ops.seq_mean(pano_all, full["view_lens"])                                     # [T * B, H]
-    rows = F.pad(torch.cat([avg_all.unsqueeze(1), pano_all], 1).reshape(ZERO, H), (0, 0, 0, 1))   # the full bank, with autograd
-    gmap_all = rows.index_select(0, idx.reshape(-1)).view(T * B, Gmax, H)                   # step t's nodes only point at steps <= t
-    vp_all = F.pad(pano_all, (0, 0, 1, 0))
-    rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
-    Lt = kv_g[0].shape[0] // B
-    repkv = lambda kv: kv.view(B, Lt, -1).unsqueeze(0).expand(T, B, Lt, kv.shape[-1]).reshape(T * B * Lt, kv.shape[-1])
-    with tape.ghost("navigation", compute=ghost_compute):
-        nav = model("navigation", nav_batch(full, gmap_all, vp_all, [repkv(k) for k in kv_g], [repkv(k) for k in kv_l], rep(lm), T * B))
-    ml_loss = criterion(nav["fused_logits"], full["target"])
-    loss = ml_loss * train_ml / B
-    if use_aux and torch.is_tensor(aux):
-        loss = loss + cosine_weight * aux
-    Tn = lambda x: list(x.view((T, B) + tuple(x.shape[1:])))
-    return {"loss": loss, "ml_loss": ml_loss, "aux": aux, "fused": Tn(nav["fused_logits"]), "global": Tn(nav["global_logits"]),
-            "local": Tn(nav["local_logits"]), "pano": Tn(pano_all), "step_logits": step_logits, "txt_embeds": txt,
-            "imagine_embeds": img, "tape": tape, "gmax": Gmax}
+            on_step(t, lg)
+    return te.finish()
+
+
+def run_episode_time_batched(model, et, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum):
+    """Teacher forcing (agent.py:449-467 with the ground-truth path): all T panoramas as ONE `panorama` call on T x B samples and all T
+    `navigation` calls as one on maps padded to the episode's largest - forward AND backward on T x longer launches, no tape. The same
+    logits, loss and gradients as run_episode to rounding (tests/test_tape_gpu.py); a sampled rollout cannot use this."""
+    import contextlib
+    te = TapedEpisode(model, et, None, use_aux, train_ml, cosine_weight, criterion)
+    te.steps, te.full, te.idx, te.Gmax, te.P, te.ZERO = _taped_inputs(et)
+    te._language()
+    return te._batched(contextlib.nullcontext(), contextlib.nullcontext())

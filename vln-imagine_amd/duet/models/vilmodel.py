@@ -289,7 +289,10 @@ class GlocalTextPathNavCMT(nn.Module):
 
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
                                     gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
-                                    vp_nav_masks, vp_obj_masks, vp_cand_vpids, imagine_embeds=None, imagine_masks=None, text_kv=None):
+                                    vp_nav_masks, vp_obj_masks, vp_cand_vpids, imagine_embeds=None, imagine_masks=None, text_kv=None,
+                                    fuse_plan=None):
+        """fuse_plan = (src [B,G] int32, bw [B,V] uint8): the caller's own index plan of the global / local fusion (fuse_plan() lists as device
+        tensors, e.g. static buffers a captured graph reads); default: built from gmap_vpids / vp_cand_vpids here and cached."""
         c, dt = self.config, self.compute_dtype
         ge, le = self.global_encoder, self.local_encoder
         B, G = gmap_masks.shape
@@ -350,7 +353,7 @@ class GlocalTextPathNavCMT(nn.Module):
             vp = le.encoder(txt, lm, vp, vm, kvs=kv_l)
         # reference :1185-1217: fuse weight, the two masked heads and the global / local fusion - one launch (ops.duet_heads)
         f = None if self.sap_fuse_linear is None else self.sap_fuse_linear(torch.cat([gmap[:, 0], vp[:, 0]], 1).contiguous())
-        src, bw = self._fuse_plan(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, vp.shape[1])
+        src, bw = fuse_plan if fuse_plan is not None else self._fuse_plan(gmap_vpids, gmap_visited_masks, vp_cand_vpids, G, vp.shape[1])
         global_logits, local_logits, fused_logits = ops.duet_heads(self.global_sap_head(gmap), self.local_sap_head(vp), f,
                                                                    gmap_visited_masks, gmap_masks, vp_nav_masks, src, bw)
         obj_logits = self.og_head(vp, ~vp_obj_masks) if vp_obj_masks is not None else None      # reference :1220-1225
@@ -424,5 +427,5 @@ class GlocalTextPathNavCMT(nn.Module):
                 batch["gmap_pos_fts"], batch["gmap_masks"], batch["gmap_pair_dists"], batch["gmap_visited_masks"],
                 batch["gmap_vpids"], batch["vp_img_embeds"], batch["vp_pos_fts"], batch["vp_masks"], batch["vp_nav_masks"],
                 batch.get("vp_obj_masks"), batch["vp_cand_vpids"], imagine_embeds=batch.get("imagine_embeds"),
-                imagine_masks=batch.get("imagine_masks"), text_kv=batch.get("text_kv"))
+                imagine_masks=batch.get("imagine_masks"), text_kv=batch.get("text_kv"), fuse_plan=batch.get("fuse_plan"))
         raise NotImplementedError("wrong mode: %s" % mode)

@@ -82,7 +82,12 @@ class EpisodeBuffers:
             for t, src in enumerate(ep.steps):
                 self.put_hist_lens(t, ep.hist_lens[t])
                 self.put_step(t, src)
-        # ---- the alignment head's index lists (the reference's triple loop, vilmodel_cmt.py:755-785, with its assertions) ----
+        self._load_plan(ep)
+        return self
+
+    def _load_plan(self, ep):
+        """The alignment head's index lists (the reference's triple loop, vilmodel_cmt.py:755-785, with its assertions) into self.plan;
+        `self`: anything with B, L, I and the plan buffers (duet.buckets.DuetEpisodeBuffers shares this)."""
         B, L, I, cap = self.B, self.L, self.I, self.B * self.I
         rows, scored, seg_off, tok = [], [], [0], []
         for b in range(B):
@@ -111,7 +116,6 @@ class EpisodeBuffers:
         p["weight"].copy_(torch.from_numpy(pad([1.0] * n, cap, 0.0).astype(np.float32)))
         p["target"].copy_(torch.from_numpy(pad([rows[j] for j in scored], cap, cap).astype(np.int64)))  # pads -> the scratch row
         p["count"].fill_(float(max(n, 1)))
-        return self
 
 
 class HamtGraphBuckets:
