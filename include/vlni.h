@@ -156,6 +156,17 @@ int vlni_sum_layernorm_fwd(int dtype, int n, const void* const* src, const long*
                            const int* src_is_f32, const float* gamma, const float* beta, float eps, void* y, long ldy,
                            void* xsum, long ldxs, float* mean, float* rstd, int rows, int H, void* stream);
 
+/* y = LayerNorm(x + bias + residual): the BertSelfOutput / BertOutput tail (R:144-148,186-190) for a dense output made elsewhere (this
+ * library's own GEMM adds bias and residual in its epilogue and is followed by vlni_layernorm_fwd). bias / residual / xsum may be NULL;
+ * xsum keeps the pre-norm sum for the backward. bwd: dx is the gradient of x AND of residual; dgamma / dbeta / dbias accumulate (+=),
+ * dbias may be NULL. */
+int vlni_bias_residual_layernorm_fwd(int dtype, const void* x, long ldx, const float* bias, const void* residual, long ldr,
+                                     const float* gamma, const float* beta, float eps, void* y, long ldy, void* xsum, long ldxs, float* mean,
+                                     float* rstd, int rows, int H, void* stream);
+int vlni_bias_residual_layernorm_bwd(int dtype, const void* dy, long lddy, const void* xsum, long ldxs, const float* gamma,
+                                     const float* mean, const float* rstd, void* dx, long lddx, float* dgamma, float* dbeta, float* dbias,
+                                     int rows, int H, void* stream);
+
 int vlni_cast(int src_dtype, int dst_dtype, const void* src, void* dst, long n, void* stream);
 /* dst[c][r] = src[r][c] (r < R), zero for R <= r < Rpad: wgrad operands and transposed weight shadows */
 int vlni_transpose(int src_dtype, int dst_dtype, const void* src, long lds, void* dst, long ldd, int R, int C, int Rpad,

@@ -708,3 +708,42 @@ def test_dual_layernorm_equals_two_launches(ops, dtype, p_drop):
             assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())
     none = ops._ln_bwd_to2(dys, xs, gs, bs, means, rstds, (False, True))
     assert none[0][1] is None and none[1][1] is not None and torch.equal(none[0][0], ops.ln_bwd(dys[0], xs[0], gs[0], means[0], rstds[0])[0])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("eps", [1e-12, 1e-5])
+def test_bias_residual_layernorm_entry_points(ops, dtype, eps):
+    """vlni_bias_residual_layernorm_fwd/bwd through the C ABI (raw pointers) against LayerNorm(dropout_0(x + bias) + residual) in torch:
+    the BertSelfOutput / BertOutput tail, VLN-HAMT/finetune_src/models/vilmodel_cmt.py:144-148,186-190."""
+    from vln_imagine_amd import _lib
+    torch.manual_seed(5)
+    rows, H = 333, 768
+    x0, r0 = (torch.randn(rows, H, device="cuda") * 0.7).to(dtype), (torch.randn(rows, H, device="cuda") * 0.7).to(dtype)
+    bias, gamma, beta = (torch.randn(H, device="cuda") * s + o for s, o in ((0.1, 0.0), (0.2, 1.0), (0.1, 0.0)))
+    dy = (torch.randn(rows, H, device="cuda") * 0.5).to(dtype)
+    dtc = ops._DT[dtype]
+    st = torch.cuda.current_stream().cuda_stream
+    y, xs = torch.empty_like(x0), torch.empty_like(x0)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    _lib.call("vlni_bias_residual_layernorm_fwd", dtc, x0.data_ptr(), H, bias.data_ptr(), r0.data_ptr(), H, gamma.data_ptr(), beta.data_ptr(), eps,
+              y.data_ptr(), H, xs.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), rows, H, st)
+    dx = torch.empty_like(x0)
+    dg, db, dbias = (torch.zeros(H, device="cuda") for _ in range(3))
+    _lib.call("vlni_bias_residual_layernorm_bwd", dtc, dy.data_ptr(), H, xs.data_ptr(), H, gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+              dx.data_ptr(), H, dg.data_ptr(), db.data_ptr(), dbias.data_ptr(), rows, H, st)
+    xr, rr = x0.double().requires_grad_(), r0.double().requires_grad_()
+    br, gr, ber = bias.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    ref = torch.nn.functional.layer_norm(xr + br + rr, (H,), gr, ber, eps)
+    ref.backward(dy.double())
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    assert (y.double() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item())
+    assert (dx.double() - xr.grad).abs().max().item() <= tol * max(1.0, xr.grad.abs().max().item())
+    assert torch.equal(xr.grad, rr.grad)
+    wtol = 1e-4 if dtype == torch.float32 else 5e-2
+    for got, want in ((dg, gr.grad), (db, ber.grad), (dbias, br.grad)):
+        assert (got.double() - want).abs().max().item() <= wtol * max(1.0, want.abs().max().item())
+    # without bias / residual / saved sum: plain LayerNorm
+    _lib.call("vlni_bias_residual_layernorm_fwd", dtc, x0.data_ptr(), H, 0, 0, 0, gamma.data_ptr(), beta.data_ptr(), eps,
+              y.data_ptr(), H, 0, 0, mean.data_ptr(), rstd.data_ptr(), rows, H, st)
+    ref2 = torch.nn.functional.layer_norm(x0.double(), (H,), gamma.double(), beta.double(), eps)
+    assert (y.double() - ref2).abs().max().item() <= tol * max(1.0, ref2.abs().max().item())

@@ -37,6 +37,8 @@ SIGNATURES = {
     "vlni_layernorm_fwd_dual": [I, P, P, P, P, F, P, P, P, P, P, I, P],
     "vlni_layernorm_bwd_dual": [I, P, P, P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, F, P, P],
     "vlni_sum_layernorm_fwd": [I, I, P, P, P, P, P, P, F, P, L, P, L, P, P, I, I, P],
+    "vlni_bias_residual_layernorm_fwd": [I, P, L, P, P, L, P, P, F, P, L, P, L, P, P, I, I, P],
+    "vlni_bias_residual_layernorm_bwd": [I, P, L, P, L, P, P, P, P, L, P, P, P, I, I, P],
     "vlni_cast": [I, I, P, P, L, P],
     "vlni_transpose": [I, I, P, L, P, L, I, I, I, P],
     "vlni_colsum": [I, P, L, I, I, P, P],

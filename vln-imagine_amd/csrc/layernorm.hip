@@ -390,3 +390,30 @@ extern "C" int vlni_sum_layernorm_fwd(int dtype, int n, const void* const* src, 
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
+
+// BertSelfOutput / BertOutput tail (VLN-HAMT/finetune_src/models/vilmodel_cmt.py:144-148,186-190) as ONE launch per direction for a dense
+// output that does not come from this library's GEMM (whose epilogue adds the bias and the residual itself, leaving plain LayerNorm):
+//   fwd  y = LayerNorm(x + bias + residual); xsum (optional) keeps the pre-norm sum - the `x` the backward needs
+//   bwd  dx = d(x) = d(residual) (+= nothing), dgamma / dbeta += ..., dbias += column sums of dx
+// Built from the sum-of-sources LayerNorm and the LayerNorm backward above (SURVEY 8b names these two entry points).
+extern "C" int vlni_colsum(int dtype, const void* x, long ldx, int rows, int N, float* out, void* stream);
+extern "C" int vlni_bias_residual_layernorm_fwd(int dtype, const void* x, long ldx, const float* bias, const void* residual, long ldr,
+                                                const float* gamma, const float* beta, float eps, void* y, long ldy, void* xsum, long ldxs,
+                                                float* mean, float* rstd, int rows, int H, void* stream) {
+  VLNI_CHECK(x && gamma && beta && y && mean && rstd, VLNI_EINVAL, "bias_residual_layernorm_fwd: null pointer");
+  const void* src[3];
+  long ld[3];
+  int f32[3], n = 0;
+  src[n] = x; ld[n] = ldx; f32[n++] = 0;
+  if (residual) { src[n] = residual; ld[n] = ldr; f32[n++] = 0; }
+  if (bias) { src[n] = bias; ld[n] = 0; f32[n++] = 1; }
+  return vlni_sum_layernorm_fwd(dtype, n, src, ld, nullptr, f32, gamma, beta, eps, y, ldy, xsum, ldxs, mean, rstd, rows, H, stream);
+}
+extern "C" int vlni_bias_residual_layernorm_bwd(int dtype, const void* dy, long lddy, const void* xsum, long ldxs, const float* gamma,
+                                                const float* mean, const float* rstd, void* dx, long lddx, float* dgamma, float* dbeta,
+                                                float* dbias, int rows, int H, void* stream) {
+  int rc = vlni_layernorm_bwd(dtype, dy, lddy, xsum, ldxs, gamma, mean, rstd, dx, lddx, dgamma, dbeta, rows, H, nullptr, 0, nullptr, 0, 0.f, 0u,
+                              stream);
+  if (rc || !dbias) return rc;
+  return vlni_colsum(dtype, dx, lddx, rows, H, dbias, stream);
+}
