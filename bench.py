@@ -224,8 +224,8 @@ def cpu_baseline(args, shipped):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (SURVEY 8d: >= 50 after 10 warm-up; a step is ~30 ms)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"],
                     help="compute dtype; fp16 = BASELINE.json configs[4] (float16 MFMA + dynamic loss scaling, float32 masters)")
     ap.add_argument("--batch", type=int, default=None, help="episodes per GPU (default: 64 HAMT, 32 DUET = BASELINE.json configs[1] / [3])")
@@ -343,6 +343,8 @@ def main():
             return bool(f.item() > 0)
         return flag
 
+    median_ms = {}
+
     def measure(w, trainer, steps, warmup, mode="stepwise", graph=True, what="step"):
         """W untimed warm-up steps, capture, then EXACTLY `steps` steps between fences; max over ranks. Returns (seconds per step,
         launch description, last loss, eager step callable)."""
@@ -406,12 +408,17 @@ def main():
                 launch = "hipGraph replay (zero+fwd+bwd | wgrad flush%s | clip+AdamW)" % (
                     " in %d ranges, RCCL all-reduce of each range on a side stream under the next" % len(trainer.comm_ranges())
                     if (world > 1 or forced) else "")
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]     # one event per step boundary: the median step (8d)
         fence()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        marks[0].record()
+        for i_ in range(steps):
             loss = step()
+            marks[i_ + 1].record()
         fence()
         dt = time.perf_counter() - t0
+        per = sorted(marks[i_].elapsed_time(marks[i_ + 1]) for i_ in range(steps))
+        median_ms[what] = round(per[len(per) // 2], 3)
         if world > 1:
             tt = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -576,7 +583,7 @@ def main():
     # ---- extra lines, reported beside `value` (never instead of it) -------------------------------------------------------
     extras = {}
     if world == 1 and not forced and not args.no_extras:
-        k_extra = max(3, min(args.steps, 8))
+        k_extra = max(3, min(args.steps, 20))
 
         def line(sec_, flops_, note):
             return {"value": round(args.batch / sec_, 2), "unit": "episodes/s", "ms_per_step": round(sec_ * 1e3, 3),
@@ -697,6 +704,7 @@ def main():
             "metric": "episodes/sec (fwd+bwd) HAMT-Imagine 9L, batch 64" if args.model == "hamt"
             else "episodes/sec (fwd+bwd) DUET-Imagine 9L+2pano+4+4X, batch 32", "value": round(eps, 2), "unit": "episodes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "ms_per_step_median": median_ms.get("step"),            # HIP events at the step boundaries of the same timed region (this rank)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{w.label}, batch {args.batch}/GPU, {args.L} text, {args.V} obs tokens, "
                                    f"{args.I} imaginations, T={args.T} steps/episode, freeze={args.freeze}, "
