@@ -290,3 +290,62 @@ def test_bench_starts_its_own_ranks():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_duet_static_episode_buffers_hold_the_padded_episode():
+    """duet.buckets.DuetEpisodeBuffers (what the captured DUET graphs read) == the padded step inputs duet.episode._taped_inputs builds from a
+    resident episode: same tensors inside the bucket, masked / neutral values in the padding, the same node -> bank-row table, and the fusion
+    plan tensors equal to the plan the model would build from the python lists (models/vilmodel.py:1198-1217)."""
+    import numpy as np
+    import torch
+    from vln_imagine_amd import synth
+    from vln_imagine_amd.duet.buckets import DuetEpisodeBuffers
+    from vln_imagine_amd.duet.episode import DuetEpisodeTensors, _taped_inputs
+    from vln_imagine_amd.duet.models.vilmodel import GlocalTextPathNavCMT
+    B, I, T = 3, 3, 3
+    ep = synth.DuetEpisode(tag="bufs", B=B, L=40, V=36, I=I, T=T, ragged=True)
+    et = DuetEpisodeTensors(ep, "cpu")
+    steps, full, idx, Gmax, P, ZERO = _taped_inputs(et)
+    GB, LB = Gmax + 3, 48
+    bufs = DuetEpisodeBuffers(B, LB, I, T, GB, "cpu").load(ep)
+    assert bufs.ZERO == ZERO and torch.equal(bufs.txt_ids[:, :40], et.txt_ids) and not bufs.txt_masks[:, 40:].any()
+    for k in ("view_img_fts", "loc_fts", "nav_types", "view_lens", "vp_pos_fts", "vp_masks", "vp_nav_masks", "target"):
+        assert torch.equal(bufs.full[k], full[k]), k
+    for k in ("gmap_step_ids", "gmap_pos_fts", "gmap_masks", "gmap_visited_masks"):
+        assert torch.equal(bufs.full[k][:, :Gmax], full[k]) and not bufs.full[k][:, Gmax:].any(), k
+    assert torch.equal(bufs.full["gmap_pair_dists"][:, :Gmax, :Gmax], full["gmap_pair_dists"])
+    assert torch.equal(bufs.idx[:, :, :Gmax], idx) and (bufs.idx[:, :, Gmax:] == ZERO).all()
+    vpids = [list(v) + [None] * (GB - len(v)) for v in full["gmap_vpids"]]
+    vis = torch.zeros(T * B, GB, dtype=torch.bool)
+    vis[:, :Gmax] = full["gmap_visited_masks"]
+    src, bw = GlocalTextPathNavCMT.fuse_plan(vpids, vis.tolist(), full["vp_cand_vpids"], GB, P + 1)
+    assert np.array_equal(bufs.src.numpy(), np.asarray(src, np.int32)) and np.array_equal(bufs.bw.numpy(), np.asarray(bw, np.uint8))
+    assert bufs._taped[1] is bufs.full and all(s["fuse_plan"][0].data_ptr() == bufs.src[t * B:(t + 1) * B].data_ptr() for t, s in enumerate(bufs.steps))
+
+
+def test_hamt_static_episode_buffers_are_slices_of_whole_episode_tensors():
+    """hamt.buckets.EpisodeBuffers: the per-step views run_episode reads and the [T * B, ...] tensors the episode tape reads are the same
+    storage; put_step / put_hist_lens write one step without touching the others."""
+    import numpy as np
+    import torch
+    from vln_imagine_amd import synth
+    from vln_imagine_amd.hamt.buckets import EpisodeBuffers
+    B, I, T, L, V = 3, 3, 3, 48, 31
+    ep = synth.HamtEpisode(tag="hb", B=B, L=40, V=29, I=I, T=T, ragged=True)
+    bufs = EpisodeBuffers(B, L, V, I, T, "cpu").load(ep)
+    for t in range(T):
+        for k in EpisodeBuffers.OBS_KEYS + EpisodeBuffers.HIST_KEYS + ("target",):
+            got, want = bufs.steps[t][k], np.asarray(ep.steps[t][k])
+            assert got.data_ptr() == bufs.full(k)[t * B:(t + 1) * B].data_ptr()
+            sl = tuple(slice(0, n) for n in want.shape)
+            assert np.array_equal(got.numpy()[sl], want.astype(got.numpy().dtype)), (t, k)
+            if k in ("ob_img_feats", "ob_masks", "ob_nav_types"):
+                assert not got.numpy()[:, 29:].any(), (t, k)                   # padded views: zero features, mask False, nav type 0
+    assert torch.equal(bufs.hist_lens_dev, torch.tensor(ep.hist_lens))
+    before = bufs.full("ob_img_feats").clone()
+    other = synth.HamtEpisode(tag="hb2", B=B, L=40, V=29, I=I, T=T, ragged=True)
+    bufs.put_step(1, other.steps[1], keys=EpisodeBuffers.OBS_KEYS)
+    bufs.put_hist_lens(2, [1, 2, 3])
+    after = bufs.full("ob_img_feats")
+    assert torch.equal(after[:B], before[:B]) and torch.equal(after[2 * B:], before[2 * B:]) and not torch.equal(after[B:2 * B], before[B:2 * B])
+    assert bufs.hist_lens_dev[2].tolist() == [1, 2, 3] and bufs.hist_masks[2].tolist() == [[True, False, False], [True, True, False], [True, True, True]]
