@@ -22,7 +22,7 @@
 //                                  192x128 / 128x192 (two 40-KiB stages: two blocks per CU with 17 % fewer operand bytes per flop)
 //   gemm_nn_glds_kernel   (+16)    B given as [K,N]: transposing LDS reads on the weight itself (bf16 dgrad without a W^T copy)
 //   gemm_tn_*_kernel               weight gradients dY^T X straight from row-major dY and X (ds_read_b64_tr_b16), grouped segments
-// What bounds them on the K = 768 shapes of this workload is the CU's vector-memory pipe (~66 GB/s per CU), see DESIGN.md section 6.
+// What bounds them on the K = 768 shapes of this workload is the CU's vector-memory pipe (~66 GB/s per CU), see DESIGN.md sections 6-7.
 #include <stdlib.h>
 
 #include <type_traits>
