@@ -360,6 +360,7 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
     seeds = _arr(ctypes.c_uint, (_shift(drop[1][0], M0 * N), _shift(drop[1][1], M1 * N)) if drop else (0, 0))
     cargs = (_dt(a0), ptr2(a), ld2(a), ptr2(b), ld2(b), ptr2(outs), ld2(outs), _arr(ctypes.c_int, (M0, M1)), N, K,
              ptr2(bias), act, ptr2(residual), ld2(residual), ptr2(preact), ld2(preact), ptr2(dact_src), ld2(dact_src), dact)
+    launch = lambda v: _lib.call("vlni_gemm_nt_dual", *cargs, v, drop[0] if drop else 0.0, seeds, _st())
     variant = 21 if kn else 0
     if AUTOTUNE:
         key = (a0.dtype, M0, M1, N, K, act, dact, residual[0] is not None, preact[0] is not None, kn)
@@ -367,9 +368,8 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
         if variant is None and torch.cuda.is_current_stream_capturing():
             variant = 21 if kn else 0
         elif variant is None:
-            variant = _GEMM_BEST[key] = _pick([16 + u for u in NN_VARIANTS] if kn else _nt_variants(M0 + M1, K, a0.dtype),
-                                              lambda v: _lib.call("vlni_gemm_nt_dual", *cargs, v, drop[0] if drop else 0.0, seeds, _st()))
-    _lib.call("vlni_gemm_nt_dual", *cargs, variant, drop[0] if drop else 0.0, seeds, _st())
+            variant = _GEMM_BEST[key] = _pick([16 + u for u in NN_VARIANTS] if kn else _nt_variants(M0 + M1, K, a0.dtype), launch)
+    launch(variant)
     return outs
 
 
