@@ -639,6 +639,37 @@ def main():
                                                           "observation; history call lags one step (no side-stream overlap); same episode-batched backward")
             del sg, bufs
             gc.collect()
+        if args.model == "duet" and args.graph:
+            # DUET's sampled-rollout pattern: T + 2 graph replays; before step t the host reads step t - 1's logits (one sync) and writes step t's
+            # panorama, map tensors, node sources and fusion plan into the static buffers (host-built numpy -> device copies, as the agent would)
+            from vln_imagine_amd.duet.buckets import DuetEpisodeBuffers, SteppedEpisodeGraphs as DuetStepped
+            import gc
+            gc.collect()
+            gmax = max(s_["gmap_masks"].shape[1] for s_ in w.et.ep.steps)
+            dbufs = DuetEpisodeBuffers(args.batch, args.L, args.I, args.T, gmax, dev).load(w.et.ep)
+            dsg = DuetStepped(trainer, w.model, dbufs)
+
+            def duet_sampled_episode():
+                dsg.begin()
+                for t in range(args.T):
+                    dbufs.put_step(t, w.et.ep.steps[t])
+                    dsg.step(t)
+                    dsg.logits(t).argmax(1).cpu()
+                return dsg.finish()
+
+            duet_sampled_episode()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(k_extra):
+                duet_sampled_episode()
+            fence()
+            s_ = (time.perf_counter() - t0) / k_extra
+            log(f"sampled-stepped: timed {1e3 * s_:.2f} ms/step")
+            extras["sampled_stepped"] = line(s_, w.flops, "a sampled rollout's pattern (duet.buckets.SteppedEpisodeGraphs): begin | T step graphs | ghost + backward + "
+                                                          "optimizer; before every step the host reads the previous logits (one sync), builds the step's map tensors / node "
+                                                          "sources / fusion plan in numpy and copies them with the panorama features (3.5 MB) into the static buffers")
+            del dsg, dbufs
+            gc.collect()
         if args.model == "hamt" and args.lang_rows == "all":
             w.model.visual_lang_rows = "cls"
             s_, _, _, _ = measure(w, trainer, k_extra, 2, mode=args.mode, graph=args.graph, what="cls-rows")

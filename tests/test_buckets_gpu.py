@@ -197,3 +197,37 @@ def test_stepped_episode_graphs_train_like_the_eager_tape():
         assert float(d.max()) <= 2 * LR * len(eps) and float(d.mean()) <= 0.05 * float(moved.mean()), (float(d.max()), float(d.mean()), float(moved.mean()))
     finally:
         tr_g.close(); tr_e.close()
+
+
+@pytest.mark.parametrize("lag", [False, True])
+def test_taped_episode_with_ended_samples_equals_step_by_step_autograd(lag):
+    """Samples that ended early keep their history length (model_HAMT.py:62-63: later history tokens are masked) and their targets become the ignore
+    index (agent_cmt.py:547): the tape - teacher-forced order and the lagging order of a sampled rollout - still gives run_episode's logits, loss
+    and gradients."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.episode import run_episode_taped
+    cfg = HamtConfig(**HAMT_C1)
+    model = build_product(cfg)
+    ep = synth.HamtEpisode(tag="ended", B=4, L=64, V=31, I=I, T=4, ragged=True)
+    stop = {1: 2, 3: 1}                                            # sample -> the step after which it has ended
+    for t in range(ep.T):
+        for b, s in stop.items():
+            ep.hist_lens[t][b] = min(t + 1, s + 1)
+            if t > s:
+                ep.steps[t]["target"][b] = -100
+    et = EpisodeTensors(ep, "cuda")
+    ref = run_episode(model, et, criterion=ops.cross_entropy_sum)
+    ref["loss"].backward()
+    g_ref = _grads(model)
+    model.zero_grad(set_to_none=True)
+    out = run_episode_taped(model, et, criterion=ops.cross_entropy_sum, lag_history=lag)
+    out["loss"].backward()
+    g_tape = _grads(model)
+    assert abs(float(out["loss"].detach()) - float(ref["loss"].detach())) <= 1e-5 * max(1.0, abs(float(ref["loss"].detach())))
+    for t in range(et.T):
+        fin = torch.isfinite(ref["logits"][t])
+        assert torch.equal(torch.isfinite(out["step_logits"][t]), fin)
+        assert torch.allclose(out["step_logits"][t][fin], ref["logits"][t][fin], atol=2e-5), t
+    assert g_ref.keys() == g_tape.keys()
+    for n in g_ref:
+        assert torch.allclose(g_tape[n], g_ref[n], atol=1e-5 + 1e-4 * float(g_ref[n].abs().max())), n
