@@ -573,6 +573,19 @@ def main():
         parity = {k: (round(v, 6) if isinstance(v, float) else v) for k, v in parity.items()}
         parity["sample"] = (f"B=8, T={args.T}, fwd+bwd at the timed model's current weights; fp32 = the exact-fp32 MFMA path held to the "
                             "reference goldens at 1e-4")
+        # what the 16-bit all-reduce payload of N > 1 adds on top: the float32 gradient arena of this slice through the pack /
+        # unpack kernels of the exchange (vlni_scale_cast, 1/N pre-division folded in) - per rank; a ring sum of N such payloads adds at most sqrt(N) of it
+        g32 = trainer.flat_g
+        nrm = float(g32.norm())
+        if nrm > 0:
+            pk = torch.empty(g32.numel(), dtype=torch.bfloat16, device=g32.device)
+            back = torch.empty_like(g32)
+            st_ = torch.cuda.current_stream().cuda_stream
+            from vln_imagine_amd import _lib
+            _lib.call("vlni_scale_cast", 0, 1, g32.data_ptr(), pk.data_ptr(), g32.numel(), 0.125, st_)
+            _lib.call("vlni_scale_cast", 1, 0, pk.data_ptr(), back.data_ptr(), g32.numel(), 8.0, st_)
+            parity["grad_allreduce_bf16_payload_rel_l2"] = round(float((back - g32).norm()) / nrm, 6)
+            del pk, back
         log(f"bf16 vs fp32: {parity}")
         del w32, o16, o32, ws
         if args.train_mode:
