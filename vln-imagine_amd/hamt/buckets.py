@@ -186,9 +186,10 @@ class SteppedEpisodeGraphs:
     call lags by one step (TapedEpisode(lag_history=True)). The backward is still ONE episode-batched pass.
 
         g = SteppedEpisodeGraphs(trainer, model, bufs)           # one eager warm-up episode on the data in `bufs`, then the capture
-        g.begin()                                               # after bufs.load_text(...) / load(ep)
+        g.begin()                                               # after bufs.load(ep, steps=False) (or load(ep))
         for t in range(T):
-            g.step(t); a = g.logits(t).argmax(1)                # host decides; bufs.put_step(t + 1, ...), bufs.put_history(t, ...)
+            g.step(t); a = g.logits(t).argmax(1)                # host decides; then bufs.put_hist_lens(t + 1, ...), bufs.put_step(t + 1, obs, keys=OBS_KEYS)
+                                                                # and bufs.put_step(t, hist, keys=HIST_KEYS) (the view taken at step t)
         loss = g.finish()                                       # targets written into bufs.full('target') before this
     """
 
