@@ -12,6 +12,8 @@ head's index lists (agent_cmt.py:436-459 -> models/vilmodel_cmt.py:755-785) beco
 Padded key positions carry the additive mask -10000: their softmax weight is exp(-10000 - max) = 0 in float32, so every real row
 of every activation - and every logit - is bit-identical to the unpadded eager run (tests/test_buckets_gpu.py); weight gradients
 differ by summation order only (more zero rows)."""
+import os
+
 import numpy as np
 import torch
 
@@ -37,6 +39,7 @@ class EpisodeBuffers:
         self.step_ids = [torch.tensor([i], device=dev) for i in range(T)]
         self.hist_masks = [torch.ones((B, t + 1), dtype=torch.bool, device=dev) for t in range(T)]
         self.hist_lens_dev = (torch.arange(T, device=dev) + 1)[:, None].expand(T, B).contiguous()     # [T, B], model_HAMT.py:62-63
+        self.hist_mask_T = torch.arange(T, device=dev)[None, None, :] < self.hist_lens_dev[:, :, None]  # [T, B, T]: step t's mask over T padded entries
         cap = B * I
         self.plan = dict(rows=z(cap, dt=torch.int64), scored=z(cap, dt=torch.int64), seg_off=z(cap + 1, dt=torch.int32),
                          tok_rows=z(B * L, dt=torch.int32), weight=z(cap), count=torch.ones((), dtype=torch.float32, device=dev),
@@ -68,8 +71,10 @@ class EpisodeBuffers:
 
     def put_hist_lens(self, t, lens):
         """History length of every sample before step t (model_HAMT.py:62-63); step t's graph reads it."""
-        self.hist_lens_dev[t].copy_(torch.as_tensor(lens))
-        self.hist_masks[t].copy_(torch.arange(t + 1)[None, :] < torch.as_tensor(lens)[:, None])
+        lens = np.asarray(lens, dtype=np.int64)                 # (numpy on the host: torch CPU ops on 8-element tensors cost more than the copies)
+        self.hist_lens_dev[t].copy_(torch.from_numpy(lens))
+        self.hist_masks[t].copy_(torch.from_numpy(np.arange(t + 1)[None, :] < lens[:, None]))
+        self.hist_mask_T[t].copy_(torch.from_numpy(np.arange(self.T)[None, :] < lens[:, None]))
 
     def load(self, ep, steps=True):
         """Instruction side (text, imaginations, alignment plan) and - unless steps=False: a rollout fills them as it goes - all T steps."""
@@ -242,3 +247,74 @@ class SteppedEpisodeGraphs:
 
     def finish(self):
         return self.graphs.finish()
+
+
+class SteppedInferenceGraphs:
+    """Forward-only rollouts (validation: Seq2SeqCMTAgent.test -> rollout(train_ml=None, feedback='argmax'), r2r/agent_cmt.py:700-760) from captured
+    graphs: begin (language, imaginations, history [CLS]) | step t (history of step t - 1, then visual) under no_grad, no tape, no trainer - nothing
+    is kept for a backward. Same static buffers and the same host protocol as SteppedEpisodeGraphs; `logits(t)` is a static tensor.
+
+        g = SteppedInferenceGraphs(model, bufs)                 # one eager warm-up on the data in `bufs`, then the capture
+        g.begin(); [g.step(t), g.logits(t) ...]
+    """
+
+    def __init__(self, model, bufs, bypass=True, want_states=False):
+        self.model, self.bufs, self.T = model, bufs, bufs.T
+        self._logits, self._states = {}, {}
+        B, T, dev = bufs.B, bufs.T, bufs.device
+        st = {}
+
+        def begin():
+            if hasattr(model, "_lang_side"):
+                model._lang_side = None
+            st["txt"] = model("language", txt_ids=bufs.txt_ids, txt_masks=bufs.txt_masks)
+            st["img"] = model("imagine", imagine_pano_img_feats=bufs.imagine_feats, imagine_masks=None if bypass else bufs.imagine_masks)
+            cls = model("history").expand(B, -1)
+            if "hb" not in st:
+                st["hb"] = torch.zeros((B, T, cls.shape[-1]), dtype=cls.dtype, device=dev)       # [CLS, h_0 .. h_{T-2}]; later entries masked
+            st["hb"][:, 0] = cls
+
+        def step(t):
+            def run():
+                s = bufs.steps
+                if t > 0:
+                    st["hb"][:, t] = model("history", hist_img_feats=s[t - 1]["hist_img_feats"], hist_ang_feats=s[t - 1]["hist_ang_feats"],
+                                           ob_step_ids=bufs.step_ids[t - 1], hist_pano_img_feats=s[t - 1]["hist_pano_img_feats"],
+                                           hist_pano_ang_feats=s[t - 1]["hist_pano_ang_feats"])
+                hm = bufs.hist_mask_T[t]                            # [B, T] static, written by the host with the lengths (put_hist_lens)
+                lg, txt_o, hist_o, _ = model("visual", txt_embeds=st["txt"], txt_masks=bufs.txt_masks, hist_embeds=st["hb"], hist_masks=hm,
+                                             ob_img_feats=s[t]["ob_img_feats"], ob_ang_feats=s[t]["ob_ang_feats"], ob_nav_types=s[t]["ob_nav_types"],
+                                             ob_masks=s[t]["ob_masks"], imagine_embeds=st["img"], imagine_masks=bufs.imagine_masks)
+                self._logits[t] = lg
+                if want_states:
+                    self._states[t] = txt_o[:, 0] * hist_o[:, 0]
+            return run
+
+        stages = [begin] + [step(t) for t in range(T)]
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                         # eager warm-up (lazy initialisation, GEMM autotune at these row counts)
+                for f in stages:
+                    f()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graphs, pool = [], None
+            for f in stages:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **(dict(pool=pool) if pool is not None else {})):
+                    f()
+                pool = g.pool()
+                self.graphs.append(g)
+
+    def begin(self):
+        self.graphs[0].replay()
+
+    def step(self, t):
+        self.graphs[1 + t].replay()
+
+    def logits(self, t):
+        return self._logits[t]
+
+    def state(self, t):
+        return self._states[t]

@@ -38,6 +38,7 @@ class EpisodeTensors:
         self._full = {}
         # history length before each step, [T, B] (model_HAMT.py:62-63), resident: a captured step must not copy host data
         self.hist_lens_dev = torch.tensor(ep.hist_lens, device=dev)
+        self.hist_mask_T = torch.arange(ep.T, device=dev)[None, None, :] < self.hist_lens_dev[:, :, None]      # [T, B, T]
 
     def full(self, k):
         """Step inputs `k` of all T steps as ONE [T*B, ...] tensor (step t = rows [t B, (t + 1) B)), built once."""
@@ -220,7 +221,7 @@ class TapedEpisode:
             hb[:, :, 0] = cls
         if not self.lag:
             lens = et.hist_lens_dev[:T]                                                        # [T, B] history length before step t
-            self.valid = self.ar[None, None, :] < lens[:, :, None]                             # [step t, sample b, entry j]
+            self.valid = et.hist_mask_T if hasattr(et, "hist_mask_T") else self.ar[None, None, :] < lens[:, :, None]   # [step t, sample b, entry j]
             self.hm_full = self.valid.reshape(T * B, T).contiguous()
         for k in ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats", "ob_img_feats", "ob_ang_feats",
                   "ob_nav_types", "ob_masks", "target"):
@@ -241,7 +242,8 @@ class TapedEpisode:
                 h = self._history(t - 1)
                 with torch.no_grad():
                     hb[t:, :, t] = h
-            hm = self.ar[None, :] < et.hist_lens_dev[t][:, None]
+            # step t's mask over the T padded entries: a static tensor the host wrote with the lengths where the episode lives in static buffers
+            hm = et.hist_mask_T[t] if hasattr(et, "hist_mask_T") else self.ar[None, :] < et.hist_lens_dev[t][:, None]
         else:
             hm = self.hm_full[sl]
             if side is not None:
@@ -271,7 +273,7 @@ class TapedEpisode:
         f, main, side, ar = et.full, self.main, self.side, self.ar
         if self.lag:
             self._history(T - 1)                     # consumed by no step; run so that the batched backward reads defined activations
-            valid = ar[None, None, :] < et.hist_lens_dev[:T][:, :, None]
+            valid = et.hist_mask_T if hasattr(et, "hist_mask_T") else ar[None, None, :] < et.hist_lens_dev[:T][:, :, None]
             hm_full = valid.reshape(T * B, T).contiguous()
         else:
             valid, hm_full = self.valid, self.hm_full
