@@ -309,7 +309,7 @@ def test_duet_static_episode_buffers_hold_the_padded_episode():
     GB, LB = Gmax + 3, 48
     bufs = DuetEpisodeBuffers(B, LB, I, T, GB, "cpu").load(ep)
     assert bufs.ZERO == ZERO and torch.equal(bufs.txt_ids[:, :40], et.txt_ids) and not bufs.txt_masks[:, 40:].any()
-    for k in ("view_img_fts", "loc_fts", "nav_types", "view_lens", "vp_pos_fts", "vp_masks", "vp_nav_masks", "target"):
+    for k in ("view_img_fts", "loc_fts", "nav_types", "view_lens", "vp_pos_fts", "vp_masks", "vp_nav_masks", "pano_masks", "target"):
         assert torch.equal(bufs.full[k], full[k]), k
     for k in ("gmap_step_ids", "gmap_pos_fts", "gmap_masks", "gmap_visited_masks"):
         assert torch.equal(bufs.full[k][:, :Gmax], full[k]) and not bufs.full[k][:, Gmax:].any(), k

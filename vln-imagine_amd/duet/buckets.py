@@ -35,9 +35,10 @@ class DuetEpisodeBuffers:
         full = dict(view_img_fts=z(N, P, feat), loc_fts=z(N, P, 7), nav_types=z(N, P, dt=torch.int64), view_lens=torch.ones(N, dtype=torch.int64, device=dev),
                     gmap_step_ids=z(N, Gmax, dt=torch.int64), gmap_pos_fts=z(N, Gmax, 7), gmap_masks=z(N, Gmax, dt=torch.bool),
                     gmap_pair_dists=z(N, Gmax, Gmax), gmap_visited_masks=z(N, Gmax, dt=torch.bool), vp_pos_fts=z(N, P + 1, 14),
-                    vp_masks=z(N, P + 1, dt=torch.bool), vp_nav_masks=z(N, P + 1, dt=torch.bool), target=torch.full((N,), -100, dtype=torch.int64, device=dev))
+                    vp_masks=z(N, P + 1, dt=torch.bool), vp_nav_masks=z(N, P + 1, dt=torch.bool), pano_masks=z(N, P, dt=torch.bool), target=torch.full((N,), -100, dtype=torch.int64, device=dev))
         full["gmap_masks"][:, 0] = True                        # a map always holds its [STOP] node: no all-masked softmax row before the host wrote a step
         full["vp_masks"][:, 0] = True
+        full["pano_masks"][:, 0] = True
         self.src, self.bw = z(N, Gmax, dt=torch.int32) - 1, z(N, P + 1, dt=torch.uint8)
         self.idx = torch.full((T, B, Gmax), self.ZERO, dtype=torch.int64, device=dev)
         full["gmap_vpids"] = full["vp_cand_vpids"] = None      # the fusion plan is given as tensors (fuse_plan)
@@ -70,6 +71,7 @@ class DuetEpisodeBuffers:
             self._put(st[k], np.asarray(s[k], dtype=np.float32) if st[k].dtype == torch.float32 else np.asarray(s[k]))
         lens = np.asarray(s["view_lens"])
         self._put(st["vp_masks"], np.arange(P + 1)[None, :] < (lens + 1)[:, None])
+        self._put(st["pano_masks"], np.arange(P)[None, :] < lens[:, None])
         self._put(st["vp_nav_masks"], np.concatenate([np.ones((B, 1), bool), np.asarray(s["nav_types"]) == 1], 1))
         off = np.full((B, Gmax), self.ZERO, np.int64)
         for b, srcs in enumerate(s["node_src"]):

@@ -130,11 +130,12 @@ def _taped_inputs(et):
             gmap_pair_dists=pdp, gmap_visited_masks=pad2(s["gmap_visited_masks"], G),
             gmap_vpids=[list(v) + [None] * (Gmax - len(v)) for v in s["gmap_vpids"]],
             vp_pos_fts=s["vp_pos_fts"], vp_masks=torch.arange(P + 1, device=dev)[None, :] < (plen + 1)[:, None],
+            pano_masks=torch.arange(P, device=dev)[None, :] < plen[:, None],
             vp_nav_masks=torch.cat([ones, s["nav_types"] == 1], 1), vp_cand_vpids=s["vp_cand_vpids"], target=s["target"]))
     idx = torch.from_numpy(off).to(dev)                                                  # rows of the flattened [T * B * (P + 1) + 1, H] bank
     cat = lambda k: torch.cat([st[k] for st in steps], 0).contiguous()
     full = {k: cat(k) for k in ("view_img_fts", "loc_fts", "nav_types", "view_lens", "gmap_step_ids", "gmap_pos_fts", "gmap_masks",
-                                "gmap_pair_dists", "gmap_visited_masks", "vp_pos_fts", "vp_masks", "vp_nav_masks", "target")}
+                                "gmap_pair_dists", "gmap_visited_masks", "vp_pos_fts", "vp_masks", "vp_nav_masks", "pano_masks", "target")}
     full["gmap_vpids"] = [v for st in steps for v in st["gmap_vpids"]]
     full["vp_cand_vpids"] = [v for st in steps for v in st["vp_cand_vpids"]]
     et._taped = (steps, full, idx, Gmax, P, ZERO)
@@ -205,7 +206,8 @@ class TapedEpisode:
         model, tape, B, st = self.model, self.tape, self.B, self.steps[t]
         with tape.record("panorama", t):
             pano, pmask = model("panorama", {"view_img_fts": st["view_img_fts"], "obj_img_fts": None, "loc_fts": st["loc_fts"],
-                                             "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": None})
+                                             "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": None,
+                                             "pano_masks": st["pano_masks"]})
         with torch.no_grad():
             self.bank4[t, :, 0] = ops.seq_mean(pano, st["view_lens"])                 # masked mean, agent.py:468-469
             self.bank4[t, :, 1:] = pano
@@ -225,7 +227,8 @@ class TapedEpisode:
         H = self.txt.shape[-1]
         with ctx_pano:
             pano_all, pmask_all = model("panorama", {"view_img_fts": full["view_img_fts"], "obj_img_fts": None, "loc_fts": full["loc_fts"],
-                                                     "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None})
+                                                     "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None,
+                                                     "pano_masks": full["pano_masks"]})
         avg_all = ops.seq_mean(pano_all, full["view_lens"])                                     # [T * B, H]
         rows = F.pad(torch.cat([avg_all.unsqueeze(1), pano_all], 1).reshape(ZERO, H), (0, 0, 0, 1))   # the full bank, with autograd
         gmap_all = rows.index_select(0, self.idx.reshape(-1)).view(T * B, Gmax, H)              # step t's nodes only point at steps <= t

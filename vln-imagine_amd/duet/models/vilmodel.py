@@ -241,7 +241,9 @@ class GlocalTextPathNavCMT(nn.Module):
             x = layer(x, km)
         return x if self.lang_encoder.update_lang_bert else x.detach()
 
-    def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens):
+    def forward_panorama_per_step(self, view_img_fts, obj_img_fts, loc_fts, nav_types, view_lens, obj_lens, pano_masks=None):
+        """pano_masks (optional, bool [B, S]): gen_seq_masks(view_lens + obj_lens) made by the caller - static episode buffers hand it over so
+        that a captured step contains no length -> mask conversion of its own (duet.buckets)."""
         dt, ie = self.compute_dtype, self.img_embeddings
         B, S, _ = view_img_fts.shape
         ti = ops.layer_norm(ops.linear(view_img_fts, ie.img_linear.weight, ie.img_linear.bias, out_dtype=dt),
@@ -270,7 +272,7 @@ class GlocalTextPathNavCMT(nn.Module):
                 (self.embeddings.token_type_embeddings.weight[1], "bcast", None)]
         x = ops.sum_layer_norm(srcs, ie.layer_norm.weight, ie.layer_norm.bias, B * S, dt, HID_EPS).view(B, S, -1)
         x = ops.dropout(x, self.config.hidden_dropout_prob, self.training)
-        masks = torch.arange(S, device=x.device)[None, :] < pano_lens[:, None]          # gen_seq_masks
+        masks = pano_masks if pano_masks is not None else torch.arange(S, device=x.device)[None, :] < pano_lens[:, None]   # gen_seq_masks
         if ie.pano_encoder is not None:
             x = ie.pano_encoder(x, masks)
         return x, masks
@@ -420,7 +422,7 @@ class GlocalTextPathNavCMT(nn.Module):
                 noun_phrase_segs=batch.get("noun_phrase_segs"), obs_instr_ids=batch.get("obs_instr_ids"))
         if mode == "panorama":
             return self.forward_panorama_per_step(batch["view_img_fts"], batch.get("obj_img_fts"), batch["loc_fts"],
-                                                  batch["nav_types"], batch["view_lens"], batch.get("obj_lens"))
+                                                  batch["nav_types"], batch["view_lens"], batch.get("obj_lens"), batch.get("pano_masks"))
         if mode == "navigation":
             return self.forward_navigation_per_step(
                 batch["txt_embeds"], batch["txt_masks"], batch["gmap_img_embeds"], batch["gmap_step_ids"],
