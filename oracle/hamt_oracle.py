@@ -87,6 +87,12 @@ def lxrt_layer(sd, p, lang, lang_mask, visn, visn_mask):   # R:423-445
     return l3, v3
 
 
+def lxrt_layer_no_lang_ca(sd, p, lang, lang_mask, visn, visn_mask):   # R:385-421 with self.no_lang_ca: the vision stream only
+    v1 = x_attention(sd, p + ".visual_attention", visn, lang, lang_mask)
+    v2 = bert_attention(sd, p + ".visn_self_att", v1, visn_mask)
+    return ffn(sd, p + ".visn_inter", p + ".visn_output", v2)
+
+
 def lxrt_layer_probs(sd, p, lang, lang_mask, visn, visn_mask):
     """The four visualisation maps of a layer (R:391,393,438,439): cross-attention pair on its inputs, self-attention pair on the
     cross-attention outputs."""
@@ -218,7 +224,15 @@ class HamtOracle:
             x = self.bert_embeddings(kw["txt_ids"])
             for i in range(cfg.num_l_layers):
                 x = bert_layer(sd, f"encoder.layer.{i}", x, m)
-            return x.detach() if cfg.fix_lang_embedding else x
+            if cfg.fix_lang_embedding:
+                x = x.detach()
+            if cfg.no_lang_ca:                       # R:1022-1029: every x-layer's language self-attention + FFN on the SAME text states
+                outs = [x]                           # (the loop never feeds one layer's output to the next)
+                for i in range(cfg.num_x_layers):
+                    p = f"encoder.x_layers.{i}"
+                    outs.append(ffn(sd, p + ".lang_inter", p + ".lang_output", bert_attention(sd, p + ".lang_self_att", x, m)))
+                return outs
+            return x
         if mode == "history":                        # R:1033-1038
             h = self.history_embeddings(kw.get("hist_img_feats"), kw.get("hist_ang_feats"),
                                         kw.get("ob_step_ids"), kw.get("hist_pano_img_feats"),
@@ -234,9 +248,17 @@ class HamtOracle:
         assert mode == "visual"                      # R:1056-1205
         hist, txt = kw["hist_embeds"], kw["txt_embeds"]
         hm, om, tm = ext_mask(kw["hist_masks"]), ext_mask(kw["ob_masks"]), ext_mask(kw["txt_masks"])
+        for i in range(cfg.num_h_layers):            # R:1064-1067 temporal history transformer
+            hist = bert_layer(sd, f"encoder.h_layers.{i}", hist, hm)
         ob = self.image_embeddings(kw["ob_img_feats"], kw["ob_ang_feats"], kw["ob_nav_types"])
+        for i in range(cfg.num_r_layers):            # R:1079-1081
+            ob = bert_layer(sd, f"encoder.r_layers.{i}", ob, om)
         if cfg.fix_obs_embedding:
             ob = ob.detach()
+        txt_list = txt if isinstance(txt, list) else None     # no_lang_ca: [text, x-layer 0's text states, ...] (R:1097-1100)
+        if txt_list is not None:
+            assert not (cfg.imagine_enc_pano and cfg.concat_imagine_with == "language"), "R:1110 concatenates a list: the reference raises"
+            txt = txt_list[0]
         nh, nt, no = hist.shape[1], txt.shape[1], ob.shape[1]
         visn, vm = torch.cat([hist, ob], 1), torch.cat([hm, om], -1)
         lang, lm = txt, tm
@@ -252,12 +274,18 @@ class HamtOracle:
             if kw.get("return_cross_attention_probs"):   # R:1128-1153
                 lq, vq, ls, vs = lxrt_layer_probs(sd, f"encoder.x_layers.{i}", lang, lm, visn, vm)
                 cross_probs.append((lq, vq)); self_probs.append((ls, vs))
-            lang, visn = lxrt_layer(sd, f"encoder.x_layers.{i}", lang, lm, visn, vm)
+            if cfg.no_lang_ca:                       # R:1118-1127 / 1157-1164 with R:385-421 under the flag: layer i reads entry i of the
+                lang = txt_list[i]                   # list, only the vision stream is updated, the language input is returned unchanged
+                visn = lxrt_layer_no_lang_ca(sd, f"encoder.x_layers.{i}", lang, lm, visn, vm)
+            else:
+                lang, visn = lxrt_layer(sd, f"encoder.x_layers.{i}", lang, lm, visn, vm)
         hist_o, ob_o, txt_o = visn[:, :nh], visn[:, nh:nh + no], lang[:, :nt]
         if cfg.imagine_enc_pano:
             img_o = visn[:, nh + no:] if cfg.concat_imagine_with == "visual" else lang[:, nt:]
         tok = cfg.act_pred_token                     # R:1190-1199
-        if tok == "ob_txt":
+        if cfg.no_lang_ca:                           # R:1187-1188
+            f = ob_o
+        elif tok == "ob_txt":
             f = ob_o * txt_o[:, :1]
         elif tok == "ob":
             f = ob_o

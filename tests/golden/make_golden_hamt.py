@@ -7,6 +7,10 @@ imported as-is (never copied); three harness shims from SURVEY.md section 8(c):
   2. config = transformers.BertConfig() + the attributes vlnbert_init.py:43-76 sets.
   3. image_proj.dropout -> clone-identity so backward through the in-place aux head
      is defined in eval mode (vilmodel_cmt.py:781).
+  4. (variant c1_no_lang_ca only) LXRTXLayer.self_att returns `(lang_input,)` under no_lang_ca (:402) and
+     LXRTXLayer.forward then indexes element [1] of it for a visualisation softmax (:438): the reference raises
+     IndexError for every no_lang_ca model. The shim appends a dummy second element to that tuple; nothing else
+     of the reference changes (the softmax of the dummy is discarded, :443-444).
 Weights and inputs come from vln_imagine_amd.synth closed forms, so the fixtures hold
 only outputs (logits, losses, small embeddings, probes of large tensors, gradient
 norms + leading elements).
@@ -29,7 +33,7 @@ import models.vilmodel_cmt as REF  # noqa: E402  (the reference)
 from vln_imagine_amd import synth  # noqa: E402
 from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode  # noqa: E402
 from vln_imagine_amd.hamt.config import hamt_config_dict  # noqa: E402
-from tests.golden.variants import HAMT_VARIANTS as VARIANTS, HAMT_C1, HAMT_EP  # noqa: E402
+from tests.golden.variants import HAMT_VARIANTS as VARIANTS, HAMT_C1, HAMT_EP, hamt_variant_run_kw  # noqa: E402
 
 _orig_init = REF.NavCMT.init_weights
 
@@ -43,6 +47,19 @@ def _guarded(self):
 
 
 REF.NavCMT.init_weights = _guarded
+
+
+_orig_self_att = REF.LXRTXLayer.self_att
+
+
+def _self_att_padded(self, lang_input, lang_attention_mask, visn_input, visn_attention_mask):      # shim 4
+    lang_out, visn_out = _orig_self_att(self, lang_input, lang_attention_mask, visn_input, visn_attention_mask)
+    if self.no_lang_ca and len(lang_out) == 1:
+        lang_out = (lang_out[0], torch.zeros(1))
+    return lang_out, visn_out
+
+
+REF.LXRTXLayer.self_att = _self_att_padded
 
 
 class _CloneIdentity(torch.nn.Module):
@@ -65,23 +82,25 @@ def build_reference(cfgd):
     return m
 
 
-def run_variant(name, over, epkw):
+def run_variant(name, over, epkw, *_):
     cfgd = hamt_config_dict(**{**HAMT_C1, **over})
     model = build_reference(cfgd)
     kw = dict(HAMT_EP)
     kw.update(epkw)
     ep = synth.HamtEpisode(**kw)
     et = EpisodeTensors(ep, "cpu")
-    out = run_episode(model, et, bypass=cfgd["bypass_imag_encoder"], use_aux=True)
+    out = run_episode(model, et, bypass=cfgd["bypass_imag_encoder"], **{"use_aux": True, **hamt_variant_run_kw(name)})
     out["loss"].backward()
     g = {}
     g["loss"] = out["loss"].detach().numpy()
     g["ml_loss"] = out["ml_loss"].detach().numpy()
-    g["aux"] = out["aux"].detach().numpy() if torch.is_tensor(out["aux"]) else np.float32(out["aux"])
+    g["aux"] = out["aux"].detach().numpy() if torch.is_tensor(out["aux"]) else np.float32(out["aux"] or 0.0)
     g["imagine_embeds"] = out["imagine_embeds"].detach().numpy()
     g["hist_cls"] = out["hist_cls"].detach().numpy()
-    for k, v in synth.probe(out["txt_embeds"].detach().numpy()).items():
-        g[f"txt_embeds.{k}"] = v
+    txt_list = out["txt_embeds"] if isinstance(out["txt_embeds"], list) else [out["txt_embeds"]]     # no_lang_ca: one per layer + the input
+    for i, te in enumerate(txt_list):
+        for k, v in synth.probe(te.detach().numpy()).items():
+            g[f"txt_embeds.{k}" if i == 0 else f"txt_embeds{i}.{k}"] = v
     for t in range(ep.T):
         g[f"logits{t}"] = out["logits"][t].detach().numpy()
         g[f"state{t}"] = out["states"][t].detach().numpy()
@@ -116,7 +135,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
     only = sys.argv[1:]
-    for name, (over, epkw) in VARIANTS.items():
+    for name, v in VARIANTS.items():
         if only and name not in only:
             continue
-        run_variant(name, over, epkw)
+        run_variant(name, *v)

@@ -15,17 +15,33 @@ HAMT_VARIANTS = {
     "c1_T3_dense": (dict(), dict(T=3, ragged=False)),
     # the released depth (run_r2r.bash: 9 language, 4 cross-modal, 2 history-panorama layers), made by the reference itself at B = 2
     "c2_depth": (dict(num_l_layers=9, num_x_layers=4, num_h_pano_layers=2), dict(B=2)),
+    # round 4: hot-path flags that had product code but no golden
+    # temporal history transformer + observation transformer in front of the cross-modal layers (vilmodel_cmt.py:458-473,1064-1067,1079-1082)
+    "c1_hr_layers": (dict(num_h_layers=1, num_r_layers=1), dict()),
+    "c1_fix_obs": (dict(fix_obs_embedding=True), dict()),                                           # :1082
+    "c1_fix_imagine": (dict(fix_imagine_embeds=True, bypass_imag_encoder=False), dict()),           # :1046 (an encoder with parameters to freeze)
+    # no_lang_ca (scripts/run_reverie.sh:27; :1022-1030,1118-1145): `language` returns a LIST, so the reference cannot run its alignment head
+    # (use_aux=False) nor concatenate imaginations to the language stream (:1110 cats a list) - imaginations go to the visual stream.
+    # The reference itself raises IndexError at :438 under this flag (a visualisation softmax indexes the 1-tuple of :402); the golden is
+    # made with the one-line harness shim documented in make_golden_hamt.py.
+    "c1_no_lang_ca": (dict(no_lang_ca=True, concat_imagine_with="visual"), dict(), dict(use_aux=False)),
 }
 HAMT_C1 = dict(num_l_layers=2, num_x_layers=2, num_h_pano_layers=2)
 HAMT_EP = dict(tag="golden", B=4, L=80, V=37, I=4, T=2, ragged=True)
 
 
 def hamt_variant_setup(name):
-    over, epkw = HAMT_VARIANTS[name]
+    over, epkw = HAMT_VARIANTS[name][:2]
     cfg = HamtConfig(**{**HAMT_C1, **over})
     kw = dict(HAMT_EP)
     kw.update(epkw)
     return cfg, synth.HamtEpisode(**kw)
+
+
+def hamt_variant_run_kw(name):
+    """Extra keyword arguments of hamt.episode.run_episode for a variant (third tuple entry; {} for most)."""
+    v = HAMT_VARIANTS[name]
+    return dict(v[2]) if len(v) > 2 else {}
 
 # ---- DUET -----------------------------------------------------------------------------------------
 from vln_imagine_amd.duet.config import DuetConfig  # noqa: E402
@@ -42,6 +58,10 @@ DUET_VARIANTS = {
                                 fix_lang_inside_cosine_model=False), dict(I=1, O=5, obj_feat=2048)),
     # the released depth (run_r2r.sh:42-44: 9 language, 2 panorama, 4 + 4 cross-modal layers), made by the reference itself at B = 2
     "c2_depth": (dict(num_l_layers=9, num_pano_layers=2, num_x_layers=4), dict(B=2)),
+    # round 4: the requires_grad freezes of vilmodel.py:1059-1073. fix_local_branch touches self.og_head, which exists only with object
+    # features (:1039-1040), so that variant is a REVERIE configuration
+    "c1_fix_pano": (dict(fix_pano_embedding=True), dict()),
+    "c1_fix_local": (dict(fix_local_branch=True, dataset="reverie", obj_feat_size=768), dict(I=1, O=5)),
 }
 DUET_C1 = dict(num_l_layers=2, num_pano_layers=2, num_x_layers=2)
 DUET_EP = dict(tag="golden", B=4, L=80, V=36, I=4, T=2, ragged=True)

@@ -263,3 +263,61 @@ def test_stepped_inference_graphs_give_the_eager_forward(want_states):
                 assert torch.equal(torch.isfinite(a), fin) and torch.allclose(a[fin], b[fin], atol=2e-5), (T, ep.L, t)
                 if want_states:
                     assert torch.allclose(g.state(t), ref["states"][t], atol=2e-5), (T, ep.L, t)
+
+
+def test_history_lengths_changed_mid_rollout_on_episode_tensors():
+    """A sampled rollout on plain EpisodeTensors (no static buffers): the caller ends samples early with et.put_hist_lens(t, lens) before
+    step t (writing et.hist_lens_dev alone used to be silently ignored). The lagging tape then gives the logits of the
+    step-by-step run on an episode that was BUILT with those lengths."""
+    import copy
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.episode import TapedEpisode
+    cfg = HamtConfig(**HAMT_C1)
+    model = build_product(cfg)
+    ep = synth.HamtEpisode(tag="lens", B=4, L=64, V=31, I=I, T=4, ragged=False)
+    new_lens = [list(l) for l in ep.hist_lens]
+    for t in range(2, ep.T):                          # samples 1 and 3 end after step 1: their history stops growing (model_HAMT.py:62-63)
+        new_lens[t][1] = new_lens[t][3] = 2
+    ep2 = copy.copy(ep)
+    ep2.hist_lens = new_lens
+    with torch.no_grad():
+        ref = run_episode(model, EpisodeTensors(ep2, "cuda"), criterion=ops.cross_entropy_sum)
+    et = EpisodeTensors(ep, "cuda")
+    te = TapedEpisode(model, et, criterion=ops.cross_entropy_sum, lag_history=True)
+    te.begin()
+    for t in range(ep.T):
+        et.put_hist_lens(t, new_lens[t])              # known only now in a real rollout
+        lg, _ = te.step(t)
+        fin = torch.isfinite(ref["logits"][t])
+        assert torch.equal(torch.isfinite(lg), fin) and torch.allclose(lg[fin], ref["logits"][t][fin], atol=2e-5), t
+    out = te.finish()
+    assert abs(float(out["loss"].detach()) - float(ref["loss"])) <= 1e-5 * max(1.0, abs(float(ref["loss"])))
+
+
+def test_history_mask_computed_inside_the_captured_steps():
+    """Regression test for the round-3 anomaly (with `arange < lengths[t]` computed INSIDE a step's graph some capture
+    sequences were seen replaying step 0's mask at later steps). The forward-only stepped graphs with mask_in_graph=True, five captures
+    in one process sharing the model, three episodes through each: every step's logits are the eager rollout's."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.buckets import EpisodeBuffers, SteppedInferenceGraphs
+    cfg = HamtConfig(**HAMT_C1)
+    L, V = 64, 31
+    model = build_product(cfg)
+    for cap, T in enumerate((2, 3, 3, 4, 3)):
+        eps = [synth.HamtEpisode(tag=f"ing{T}_{i}", B=B, L=L - 5 * i, V=V - 2 * i, I=I, T=T, ragged=True) for i in range(3)]
+        bufs = EpisodeBuffers(B, L, V, I, T, "cuda").load(eps[0])
+        g = SteppedInferenceGraphs(model, bufs, want_states=bool(cap & 1), mask_in_graph=True)
+        for ep in eps:
+            with torch.no_grad():
+                ref = run_episode(model, EpisodeBuffers(B, L, V, I, T, "cuda").load(ep), use_aux=False, criterion=ops.cross_entropy_sum)
+            bufs.load(ep, steps=False)
+            g.begin()
+            for t in range(T):
+                bufs.put_hist_lens(t, ep.hist_lens[t])
+                bufs.put_step(t, ep.steps[t], keys=EpisodeBuffers.OBS_KEYS)
+                if t > 0:
+                    bufs.put_step(t - 1, ep.steps[t - 1], keys=EpisodeBuffers.HIST_KEYS)
+                g.step(t)
+                a, b = g.logits(t), ref["logits"][t]
+                fin = torch.isfinite(b)
+                assert torch.equal(torch.isfinite(a), fin) and torch.allclose(a[fin], b[fin], atol=2e-5), (cap, T, ep.L, t)

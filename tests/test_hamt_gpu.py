@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.golden.variants import HAMT_VARIANTS, hamt_variant_setup
+from tests.golden.variants import HAMT_VARIANTS, hamt_variant_run_kw, hamt_variant_setup
 from vln_imagine_amd import synth
 from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
 from vln_imagine_amd.hamt.spec import param_shapes
@@ -38,11 +38,16 @@ def test_product_fp32_matches_reference_golden(name, golden_dir):
     g = np.load(os.path.join(golden_dir, f"hamt_{name}.npz"))
     cfg, ep = hamt_variant_setup(name)
     model = build_product(cfg)
-    out = run_episode(model, EpisodeTensors(ep, "cuda"), bypass=cfg.bypass_imag_encoder, criterion=ops.cross_entropy_sum)
+    out = run_episode(model, EpisodeTensors(ep, "cuda"), bypass=cfg.bypass_imag_encoder, criterion=ops.cross_entropy_sum,
+                      **hamt_variant_run_kw(name))
     out["loss"].backward()
     c = lambda t: t.detach().float().cpu().numpy()
     _close(out["loss"].item(), g["loss"], TOL, "loss")
-    _close(out["aux"].item(), g["aux"], TOL, "aux")
+    _close(out["aux"].item() if torch.is_tensor(out["aux"]) else 0.0, g["aux"], TOL, "aux")
+    txt_list = out["txt_embeds"] if isinstance(out["txt_embeds"], list) else [out["txt_embeds"]]
+    for i, te in enumerate(txt_list):              # no_lang_ca: the per-layer text states of the `language` call (vilmodel_cmt.py:1022-1029)
+        key = "txt_embeds.samples" if i == 0 else f"txt_embeds{i}.samples"
+        _close(synth.probe(c(te))["samples"], g[key], TOL, key)
     _close(c(out["imagine_embeds"]), g["imagine_embeds"], TOL, "imagine_embeds")
     _close(c(out["hist_cls"]), g["hist_cls"], TOL, "hist_cls")
     for t in range(ep.T):

@@ -21,7 +21,7 @@ def frozen_names(cfg, names):
             fr.add(n)
         if (cfg.fix_pano_embedding or cfg.fix_local_branch) and n.startswith("img_embeddings."):
             fr.add(n)
-        if cfg.fix_local_branch and (n.startswith("local_encoder.") or n.startswith("local_sap_head.")):
+        if cfg.fix_local_branch and (n.startswith("local_encoder.") or n.startswith("local_sap_head.") or n.startswith("og_head.")):
             fr.add(n)
     return fr
 

@@ -12,7 +12,7 @@ from vln_imagine_amd.hamt.config import HamtConfig
 from vln_imagine_amd.hamt.episode import EpisodeTensors, run_episode
 from vln_imagine_amd.hamt.spec import param_shapes
 
-from tests.golden.variants import HAMT_VARIANTS, hamt_variant_setup
+from tests.golden.variants import HAMT_VARIANTS, hamt_variant_run_kw, hamt_variant_setup
 
 TOL = 2e-5   # oracle vs reference, fp32 CPU both; gate for product is 1e-4
 
@@ -34,10 +34,14 @@ def test_oracle_matches_reference_golden(name, golden_dir):
     assert set(shapes) == set(g["grad_names"].tolist())          # state_dict ABI
     sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.fill_state_dict(shapes.items()).items()}
     torch.set_num_threads(8)
-    out = run_episode(HamtOracle(cfg, sd), EpisodeTensors(ep), bypass=cfg.bypass_imag_encoder)
+    out = run_episode(HamtOracle(cfg, sd), EpisodeTensors(ep), bypass=cfg.bypass_imag_encoder, **hamt_variant_run_kw(name))
     out["loss"].backward()
     _close(out["loss"].item(), g["loss"], what="loss")
-    _close(out["aux"].item(), g["aux"], what="aux")
+    _close(out["aux"].item() if torch.is_tensor(out["aux"]) else 0.0, g["aux"], what="aux")
+    txt_list = out["txt_embeds"] if isinstance(out["txt_embeds"], list) else [out["txt_embeds"]]
+    for i, te in enumerate(txt_list):              # no_lang_ca: the per-layer text states of the `language` call
+        key = "txt_embeds.samples" if i == 0 else f"txt_embeds{i}.samples"
+        _close(synth.probe(te.detach().numpy())["samples"], g[key], what=key)
     _close(out["imagine_embeds"].detach(), g["imagine_embeds"], what="imagine_embeds")
     _close(out["hist_cls"].detach(), g["hist_cls"], what="hist_cls")
     for t in range(ep.T):

@@ -74,21 +74,27 @@ def test_tape_is_reused_across_episodes_and_rejects_other_shapes():
     assert torch.isfinite(o["loss"]).item() and tape.bufs["visual"][0].shape[0] == rows0 // ep.B * (ep.B + 1)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_taped_episode_with_dropout_equals_the_batched_pass_computed_with_its_seeds(dtype):
+@pytest.mark.parametrize("dtype,feat_dropout", [(torch.float32, 0.0), (torch.bfloat16, 0.0), (torch.float32, 0.4)])
+def test_taped_episode_with_dropout_equals_the_batched_pass_computed_with_its_seeds(dtype, feat_dropout):
     """train(): every step's launch draws the window of the episode-wide mask that belongs to its rows (seed shifted by t x elements x
     hash multiplier), so (a) the batched call COMPUTED with the unshifted seeds reproduces the steps' logits, and (b) the ghost pass's
-    backward - which regenerates masks from the unshifted seeds over T x B samples - gives that computed pass's gradients."""
+    backward - which regenerates masks from the unshifted seeds over T x B samples - gives that computed pass's gradients.
+    feat_dropout 0.4: the wrapper's feature dropout (VLNBertCMT.drop_env, model_HAMT.py:20-63) applied by the driver with tape seeds."""
     from vln_imagine_amd import ops
     cfg, ep = hamt_variant_setup("c1_T3_dense")
     et = EpisodeTensors(ep, "cuda")
     m1, m2 = build_product(cfg, dtype).train(), build_product(cfg, dtype).train()
     torch.manual_seed(7); ops.reseed(1234)            # torch's generator: the dropouts outside the tape (language / imagine / aux head)
-    o1 = run_episode_taped(m1, et, criterion=ops.cross_entropy_sum)
+    o1 = run_episode_taped(m1, et, criterion=ops.cross_entropy_sum, feat_dropout=feat_dropout)
     o1["loss"].backward()
     torch.manual_seed(7); ops.reseed(1234)
-    o2 = run_episode_taped(m2, et, criterion=ops.cross_entropy_sum, ghost_compute=True)
+    o2 = run_episode_taped(m2, et, criterion=ops.cross_entropy_sum, ghost_compute=True, feat_dropout=feat_dropout)
     o2["loss"].backward()
+    if feat_dropout:                                  # the feature dropout is really on: the same seeds without it give other logits
+        m4 = build_product(cfg, dtype).train()
+        torch.manual_seed(7); ops.reseed(1234)
+        o4 = run_episode_taped(m4, et, criterion=ops.cross_entropy_sum)
+        assert abs(o4["loss"].item() - o1["loss"].item()) > 1e-3
     tol = 2e-5 if dtype == torch.float32 else 2e-2
     for t in range(ep.T):
         a, b, c = o1["logits"][t], o2["logits"][t], o2["step_logits"][t]
@@ -156,7 +162,8 @@ def test_duet_taped_episode_equals_stepwise_fp32(variant):
     _grads_close(m1, m2, 5e-5, variant)
 
 
-def test_duet_taped_bf16_with_dropout_is_consistent_with_its_computed_batch():
+@pytest.mark.parametrize("feat_dropout", [0.0, 0.4])
+def test_duet_taped_bf16_with_dropout_is_consistent_with_its_computed_batch(feat_dropout):
     from tests.golden.variants import duet_variant_setup
     from tests.test_duet_gpu import build_product as build_duet
     from vln_imagine_amd import ops
@@ -165,10 +172,10 @@ def test_duet_taped_bf16_with_dropout_is_consistent_with_its_computed_batch():
     et = DuetEpisodeTensors(ep, "cuda")
     m1, m2 = build_duet(cfg).train(), build_duet(cfg).train()
     torch.manual_seed(3); ops.reseed(99)
-    o1 = run_duet_taped(m1, et, criterion=ops.cross_entropy_sum)
+    o1 = run_duet_taped(m1, et, criterion=ops.cross_entropy_sum, feat_dropout=feat_dropout)
     o1["loss"].backward()
     torch.manual_seed(3); ops.reseed(99)
-    o2 = run_duet_taped(m2, et, criterion=ops.cross_entropy_sum, ghost_compute=True)
+    o2 = run_duet_taped(m2, et, criterion=ops.cross_entropy_sum, ghost_compute=True, feat_dropout=feat_dropout)
     o2["loss"].backward()
     for t in range(ep.T):
         a, b, c = o1["fused"][t], o2["fused"][t], o2["step_logits"][t]

@@ -164,13 +164,21 @@ class TapedEpisode:
     Step t reads step t's slices of the padded inputs only (`_taped_inputs`: static buffers when `et` is a duet.buckets.DuetEpisodeBuffers, which
     a rollout fills as it goes), finish() all of them."""
 
-    def __init__(self, model, et, tape=None, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, ghost_compute=False):
+    def __init__(self, model, et, tape=None, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, ghost_compute=False,
+                 feat_dropout=0.0):
         from vln_imagine_amd import ops
         self.model, self.et, self.B, self.T = model, et, et.B, et.T
+        # the wrapper's feature dropout on the panorama image features (VLNBert.drop_env, model.py:20): the drivers call the model itself,
+        # so it is applied here with the tape's counter-based masks (step, ghost pass and batched backward see the same mask)
+        self.feat_dropout = float(feat_dropout)
         self.tape = tape if tape is not None else ops.EpisodeTape(et.T)
         assert self.tape.T >= et.T
         self.use_aux, self.train_ml, self.cosine_weight, self.criterion, self.ghost_compute = use_aux, train_ml, cosine_weight, criterion, ghost_compute
         self.step_logits = []
+
+    def _drop(self, x):
+        from vln_imagine_amd import ops
+        return ops.dropout(x, self.feat_dropout, self.model.training) if self.feat_dropout > 0.0 else x
 
     def _language(self):
         model, et, B = self.model, self.et, self.B
@@ -205,7 +213,7 @@ class TapedEpisode:
         from vln_imagine_amd import ops
         model, tape, B, st = self.model, self.tape, self.B, self.steps[t]
         with tape.record("panorama", t):
-            pano, pmask = model("panorama", {"view_img_fts": st["view_img_fts"], "obj_img_fts": None, "loc_fts": st["loc_fts"],
+            pano, pmask = model("panorama", {"view_img_fts": self._drop(st["view_img_fts"]), "obj_img_fts": None, "loc_fts": st["loc_fts"],
                                              "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": None,
                                              "pano_masks": st["pano_masks"]})
         with torch.no_grad():
@@ -226,7 +234,7 @@ class TapedEpisode:
         kv_g, kv_l, lm = self.kv_g, self.kv_l, self.lm
         H = self.txt.shape[-1]
         with ctx_pano:
-            pano_all, pmask_all = model("panorama", {"view_img_fts": full["view_img_fts"], "obj_img_fts": None, "loc_fts": full["loc_fts"],
+            pano_all, pmask_all = model("panorama", {"view_img_fts": self._drop(full["view_img_fts"]), "obj_img_fts": None, "loc_fts": full["loc_fts"],
                                                      "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None,
                                                      "pano_masks": full["pano_masks"]})
         avg_all = ops.seq_mean(pano_all, full["view_lens"])                                     # [T * B, H]
@@ -252,9 +260,9 @@ class TapedEpisode:
 
 
 def run_episode_taped(model, et, tape=None, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
-                      ghost_compute=False):
+                      ghost_compute=False, feat_dropout=0.0):
     """One episode through TapedEpisode: begin, T steps (`on_step(t, fused_logits)` may pick the next viewpoint), finish."""
-    te = TapedEpisode(model, et, tape, use_aux, train_ml, cosine_weight, criterion, ghost_compute)
+    te = TapedEpisode(model, et, tape, use_aux, train_ml, cosine_weight, criterion, ghost_compute, feat_dropout)
     te.begin()
     for t in range(et.T):
         lg = te.step(t)

@@ -199,8 +199,8 @@ class GlocalTextPathNavCMT(nn.Module):
         if c.fix_pano_embedding or c.fix_local_branch:
             for p in self.img_embeddings.parameters():
                 p.requires_grad = False
-        if c.fix_local_branch:
-            for m in (self.local_encoder, self.local_sap_head):
+        if c.fix_local_branch:                       # reference :1066-1073 (self.og_head exists with object features only; the reference
+            for m in (self.local_encoder, self.local_sap_head, self.og_head):      # raises AttributeError here without them, and so does this)
                 for p in m.parameters():
                     p.requires_grad = False
         self.compute_dtype = torch.bfloat16 if os.environ.get("VLNI_DTYPE", "fp32").lower() in ("bf16", "bfloat16") \

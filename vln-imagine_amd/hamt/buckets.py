@@ -258,9 +258,11 @@ class SteppedInferenceGraphs:
         g.begin(); [g.step(t), g.logits(t) ...]
     """
 
-    def __init__(self, model, bufs, bypass=True, want_states=False):
+    def __init__(self, model, bufs, bypass=True, want_states=False, mask_in_graph=False, debug=None):
         self.model, self.bufs, self.T = model, bufs, bufs.T
         self._logits, self._states = {}, {}
+        self._ar = torch.arange(bufs.T, device=bufs.device)
+        mask_in_graph = mask_in_graph or int(os.environ.get("VLNI_MASK_IN_GRAPH", "0"))
         B, T, dev = bufs.B, bufs.T, bufs.device
         st = {}
 
@@ -281,7 +283,13 @@ class SteppedInferenceGraphs:
                     st["hb"][:, t] = model("history", hist_img_feats=s[t - 1]["hist_img_feats"], hist_ang_feats=s[t - 1]["hist_ang_feats"],
                                            ob_step_ids=bufs.step_ids[t - 1], hist_pano_img_feats=s[t - 1]["hist_pano_img_feats"],
                                            hist_pano_ang_feats=s[t - 1]["hist_pano_ang_feats"])
-                hm = bufs.hist_mask_T[t]                            # [B, T] static, written by the host with the lengths (put_hist_lens)
+                if mask_in_graph:                                   # the mask from the lengths INSIDE the step's graph (model_HAMT.py:63)
+                    ar = torch.arange(T, device=dev) if mask_in_graph == 2 else self._ar
+                    hm = ar[None, :] < bufs.hist_lens_dev[t][:, None]
+                else:
+                    hm = bufs.hist_mask_T[t]                        # [B, T] static, written by the host with the lengths (put_hist_lens)
+                if debug is not None:
+                    debug[("hm", t)] = hm
                 lg, txt_o, hist_o, _ = model("visual", txt_embeds=st["txt"], txt_masks=bufs.txt_masks, hist_embeds=st["hb"], hist_masks=hm,
                                              ob_img_feats=s[t]["ob_img_feats"], ob_ang_feats=s[t]["ob_ang_feats"], ob_nav_types=s[t]["ob_nav_types"],
                                              ob_masks=s[t]["ob_masks"], imagine_embeds=st["img"], imagine_masks=bufs.imagine_masks)

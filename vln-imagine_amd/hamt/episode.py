@@ -9,9 +9,13 @@ ignore_index -100) and :746-752 (loss = ml * train_ml / B + cosine_weight * aux)
 product model, so all three are driven by the very same code.
 """
 import contextlib
+import os
 
 import torch
 import torch.nn.functional as F
+
+
+_MASK_IN_GRAPH = int(os.environ.get("VLNI_MASK_IN_GRAPH", "0"))       # tools/stale_mask_repro.py (round-3 anomaly hunt)
 
 
 class EpisodeTensors:
@@ -39,6 +43,16 @@ class EpisodeTensors:
         # history length before each step, [T, B] (model_HAMT.py:62-63), resident: a captured step must not copy host data
         self.hist_lens_dev = torch.tensor(ep.hist_lens, device=dev)
         self.hist_mask_T = torch.arange(ep.T, device=dev)[None, None, :] < self.hist_lens_dev[:, :, None]      # [T, B, T]
+
+    def put_hist_lens(t_self, t, lens):
+        """History length of every sample before step t (model_HAMT.py:62-63) - what a sampled rollout calls once step t - 1's action is
+        known. Lengths and BOTH mask forms are rewritten together (the padded [T, B, T] one is what the taped / graphed drivers read)."""
+        self = t_self
+        lens = torch.as_tensor(lens, dtype=torch.int64)
+        dev = self.hist_lens_dev.device
+        self.hist_lens_dev[t].copy_(lens)
+        self.hist_masks[t] = (torch.arange(t + 1)[None, :] < lens[:, None]).to(dev)
+        self.hist_mask_T[t].copy_(torch.arange(self.T)[None, :] < lens[:, None])
 
     def full(self, k):
         """Step inputs `k` of all T steps as ONE [T*B, ...] tensor (step t = rows [t B, (t + 1) B)), built once."""
@@ -170,14 +184,19 @@ class TapedEpisode:
       launches that fill a fifth of the chip) runs on a second stream beside step t's `visual` call - both read features and h_0 .. h_{t-1}
       only - and its ghost pass is recorded on that stream, so autograd runs the history encoder's batched backward there too.
     lag_history=True (sampled rollouts: the history features of step t exist only after the action was chosen from step t's logits):
-      `history` of step t - 1 opens step t, the last one opens finish(); et.hist_lens_dev[t] is read inside step t, so the caller may
-      write it (and step t's observation / step t - 1's history features) any time before step t.
+      `history` of step t - 1 opens step t, the last one opens finish(); step t reads the static mask et.hist_mask_T[t] (and finish() all of
+      et.hist_mask_T), so the caller writes step t's history lengths with et.put_hist_lens(t, lens) - never et.hist_lens_dev alone - and step
+      t's observation / step t - 1's history features any time before step t.
+    feat_dropout: the wrapper's feature dropout (VLNBertCMT.drop_env, model_HAMT.py:20,38,44-47,63) on ob / hist / hist-pano image features.
+      The drivers call NavCMT directly, so it is applied HERE, with the tape's counter-based masks: the step, the ghost pass and the batched
+      backward see the same mask (an nn.Dropout inside a recorded step would draw another one in the ghost pass).
     ghost_compute=True (tests): the batched pass COMPUTES with the recorded dropout seeds instead of reusing the steps' buffers."""
 
     def __init__(self, model, et, tape=None, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum,
-                 ghost_compute=False, overlap_history=True, lag_history=False, want_states=False):
+                 ghost_compute=False, overlap_history=True, lag_history=False, want_states=False, feat_dropout=0.0):
         from vln_imagine_amd import ops
         self.model, self.et, self.B, self.T = model, et, et.B, et.T
+        self.feat_dropout, self._ops = float(feat_dropout), ops
         self.tape = tape if tape is not None else ops.EpisodeTape(et.T)
         assert self.tape.T >= et.T
         self.bypass, self.use_aux, self.train_ml, self.cosine_weight, self.criterion = bypass, use_aux, train_ml, cosine_weight, criterion
@@ -185,12 +204,16 @@ class TapedEpisode:
         self.overlap = overlap_history and not lag_history
         self.step_logits = []
 
+    def _drop(self, x):
+        """drop_env on a feature tensor (inside a tape context: ops.dropout then uses the tape's seeds)."""
+        return self._ops.dropout(x, self.feat_dropout, self.model.training) if self.feat_dropout > 0.0 else x
+
     def _history(self, t):
         f, B = self.et.full, self.B
         sl = slice(t * B, (t + 1) * B)
         with self.tape.record("history", t):
-            return self.model("history", hist_img_feats=f("hist_img_feats")[sl], hist_ang_feats=f("hist_ang_feats")[sl],
-                              ob_step_ids=self.et.step_ids[t], hist_pano_img_feats=f("hist_pano_img_feats")[sl],
+            return self.model("history", hist_img_feats=self._drop(f("hist_img_feats")[sl]), hist_ang_feats=f("hist_ang_feats")[sl],
+                              ob_step_ids=self.et.step_ids[t], hist_pano_img_feats=self._drop(f("hist_pano_img_feats")[sl]),
                               hist_pano_ang_feats=f("hist_pano_ang_feats")[sl])
 
     def begin(self):
@@ -200,7 +223,10 @@ class TapedEpisode:
         tape.reset()
         self.step_logits = []
         self.txt = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
-        img = model("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None if self.bypass else et.imagine_masks)
+        imf = et.imagine_feats                                 # outside the tape (one call per episode): torch's own dropout
+        if self.feat_dropout > 0.0:
+            imf = F.dropout(imf, self.feat_dropout, model.training)
+        img = model("imagine", imagine_pano_img_feats=imf, imagine_masks=None if self.bypass else et.imagine_masks)
         self.aux = None
         if self.use_aux:
             self.aux, img = model("align_with_contrastive_loss", align_txt_embeds=self.txt, txt_masks=et.txt_masks, align_imagine_embeds=img,
@@ -220,8 +246,7 @@ class TapedEpisode:
         with torch.no_grad():
             hb[:, :, 0] = cls
         if not self.lag:
-            lens = et.hist_lens_dev[:T]                                                        # [T, B] history length before step t
-            self.valid = et.hist_mask_T if hasattr(et, "hist_mask_T") else self.ar[None, None, :] < lens[:, :, None]   # [step t, sample b, entry j]
+            self.valid = et.hist_mask_T                                                        # [step t, sample b, entry j]: entry j < history length before step t
             self.hm_full = self.valid.reshape(T * B, T).contiguous()
         for k in ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats", "ob_img_feats", "ob_ang_feats",
                   "ob_nav_types", "ob_masks", "target"):
@@ -243,7 +268,10 @@ class TapedEpisode:
                 with torch.no_grad():
                     hb[t:, :, t] = h
             # step t's mask over the T padded entries: a static tensor the host wrote with the lengths where the episode lives in static buffers
-            hm = et.hist_mask_T[t] if hasattr(et, "hist_mask_T") else self.ar[None, :] < et.hist_lens_dev[t][:, None]
+            if _MASK_IN_GRAPH:                                # (anomaly hunt only, tools/stale_mask_repro.py)
+                hm = (torch.arange(T, device=self.ar.device) if _MASK_IN_GRAPH == 2 else self.ar)[None, :] < et.hist_lens_dev[t][:, None]
+            else:
+                hm = et.hist_mask_T[t]
         else:
             hm = self.hm_full[sl]
             if side is not None:
@@ -253,7 +281,7 @@ class TapedEpisode:
         with tape.record("visual", t):
             lg, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=self.txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm,
-                ob_img_feats=f("ob_img_feats")[sl], ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
+                ob_img_feats=self._drop(f("ob_img_feats")[sl]), ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
                 ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=et.imagine_masks)
         self.step_logits.append(lg)
         state = txt_o[:, 0] * hist_o[:, 0] if self.want_states else None                      # model_HAMT.py:86
@@ -273,7 +301,7 @@ class TapedEpisode:
         f, main, side, ar = et.full, self.main, self.side, self.ar
         if self.lag:
             self._history(T - 1)                     # consumed by no step; run so that the batched backward reads defined activations
-            valid = et.hist_mask_T if hasattr(et, "hist_mask_T") else ar[None, None, :] < et.hist_lens_dev[:T][:, :, None]
+            valid = et.hist_mask_T if not _MASK_IN_GRAPH else ar[None, None, :] < et.hist_lens_dev[:T][:, :, None]
             hm_full = valid.reshape(T * B, T).contiguous()
         else:
             valid, hm_full = self.valid, self.hm_full
@@ -281,8 +309,8 @@ class TapedEpisode:
             side.wait_stream(main)
         with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
             with tape.ghost("history", compute=self.ghost_compute):
-                h_all = model("history", hist_img_feats=f("hist_img_feats"), hist_ang_feats=f("hist_ang_feats"),
-                              ob_step_ids=ar.repeat_interleave(B), hist_pano_img_feats=f("hist_pano_img_feats"),
+                h_all = model("history", hist_img_feats=self._drop(f("hist_img_feats")), hist_ang_feats=f("hist_ang_feats"),
+                              ob_step_ids=ar.repeat_interleave(B), hist_pano_img_feats=self._drop(f("hist_pano_img_feats")),
                               hist_pano_ang_feats=f("hist_pano_ang_feats"))
         if side is not None:
             main.wait_stream(side)
@@ -296,7 +324,7 @@ class TapedEpisode:
         with tape.ghost("visual", compute=self.ghost_compute):
             logits, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=rep(self.txt), txt_masks=rep(et.txt_masks), hist_embeds=hist.reshape(T * B, T, H), hist_masks=hm_full,
-                ob_img_feats=f("ob_img_feats"), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
+                ob_img_feats=self._drop(f("ob_img_feats")), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
                 ob_masks=f("ob_masks"), imagine_embeds=rep(self.img), imagine_masks=rep(et.imagine_masks))
         ml_loss = self.criterion(logits, f("target"))
         loss = ml_loss * self.train_ml / B
@@ -307,10 +335,10 @@ class TapedEpisode:
 
 
 def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
-                      ghost_compute=False, overlap_history=True, lag_history=False):
+                      ghost_compute=False, overlap_history=True, lag_history=False, feat_dropout=0.0):
     """One episode through TapedEpisode: begin, T steps (`on_step(t, logits, state)` may choose the action), finish."""
     te = TapedEpisode(model, et, tape, bypass, use_aux, train_ml, cosine_weight, criterion, ghost_compute, overlap_history, lag_history,
-                      want_states=on_step is not None)
+                      want_states=on_step is not None, feat_dropout=feat_dropout)
     te.begin()
     for t in range(et.T):
         lg, state = te.step(t)

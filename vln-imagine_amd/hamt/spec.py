@@ -71,6 +71,10 @@ def param_shapes(cfg):
                 _bert_layer(d, f"{p}.pano_encoder.layer.{i}", h, ff)
     for i in range(cfg.num_l_layers):
         _bert_layer(d, f"encoder.layer.{i}", h, ff)
+    for i in range(cfg.num_h_layers):               # registration order of LxmertEncoder (:458-473): layer, h_layers, r_layers, x_layers
+        _bert_layer(d, f"encoder.h_layers.{i}", h, ff)
+    for i in range(cfg.num_r_layers):
+        _bert_layer(d, f"encoder.r_layers.{i}", h, ff)
     for i in range(cfg.num_x_layers):
         p = f"encoder.x_layers.{i}"
         for side in ("lang", "visn"):
