@@ -89,7 +89,12 @@ def run_variant(name, over, epkw, *_):
     kw.update(epkw)
     ep = synth.HamtEpisode(**kw)
     et = EpisodeTensors(ep, "cpu")
+    kink = []                      # pre-activations of the action head's ReLU on rows that reach the loss: a value within float32 rounding of
+    h = model.next_action.net[1].register_forward_hook(lambda m, i, o: kink.append(i[0].detach()))     # zero makes the gradient ill-defined
     out = run_episode(model, et, bypass=cfgd["bypass_imag_encoder"], **{"use_aux": True, **hamt_variant_run_kw(name)})
+    h.remove()
+    margin = min(float(z[torch.isfinite(lg)].abs().min()) for z, lg in zip(kink, out["logits"]))
+    assert margin > 2e-6, f"{name}: an action-head ReLU input is {margin:.1e} from zero on a scored row - pick another episode tag (variants.py)"
     out["loss"].backward()
     g = {}
     g["loss"] = out["loss"].detach().numpy()
@@ -127,7 +132,7 @@ def run_variant(name, over, epkw, *_):
                           f"variant={name}", f"cfg={sorted(over.items())}", f"ep={sorted(kw.items())}"])
     path = os.path.join(ROOT, "tests", "golden", f"hamt_{name}.npz")
     np.savez_compressed(path, **g)
-    print(f"{name}: loss={float(g['loss']):.6f} aux={float(g['aux']):.6f} "
+    print(f"{name}: relu margin {margin:.1e} loss={float(g['loss']):.6f} aux={float(g['aux']):.6f} "
           f"logit0[0,:3]={g['logits0'][0, :3]} -> {os.path.getsize(path)/1024:.0f} KiB")
 
 

@@ -631,8 +631,10 @@ def test_attention_dual_launch_equals_two_launches(ops, with_bias, p_drop):
                 continue
             if x.dtype == torch.float32:            # dbias: float atomics over heads, order-dependent in the last bits
                 assert (x - y).abs().max().item() <= 1e-5 * max(1.0, y.abs().max().item())
-            else:
-                assert torch.equal(x, y)
+            elif max(S0, K0, S1, K1) <= 96 or min(max(S0, K0), max(S1, K1)) > 96:
+                assert torch.equal(x, y)            # both launch forms run the same kernel body
+            else:                                   # one problem beyond 96 rows: the dual launch runs both on the chunked kernel, the single
+                assert (x.float() - y.float()).abs().max().item() <= 2.0 ** -6 * y.float().abs().max().item()   # launches split (roles / chunked)
 
 
 def test_float16_kernels_are_the_bfloat16_kernels_with_the_f16_mfma(ops):

@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 from vln_imagine_amd import ops  # noqa: E402
 
-dt, B, H = torch.bfloat16, 64, 768
+dt, B, H = torch.bfloat16, int(os.environ.get("B", "64")), 768        # B=384: the episode-batched backward of the bench (T x B)
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(dt)
 
 
