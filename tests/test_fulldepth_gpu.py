@@ -64,9 +64,13 @@ def test_fp32_full_depth_fwd_bwd_matches_cpu_oracle(family, B):
     assert r["params_compared"] > 100
 
 
-# measured on MI355X (this test's own print), x 2:        loss_abs, logit_max_abs, grad_rel_l2, worst single parameter
-BF16_BOUNDS = {"hamt": (5e-4, 0.07, 0.18, 0.3), "duet": (5e-4, 0.04, 0.17, 0.27)}   # measured: 2.3e-4 / 0.033 / 0.089 / 0.147; 0.9 - 2.4e-4 / 0.0155 - 0.0195 / 0.083 - 0.085 / 0.127 - 0.134 (rounds 2 - 3)
-F16_BOUNDS = {"hamt": (6e-5, 0.009, 0.054, 0.11), "duet": (1e-4, 0.0052, 0.055, 0.1)}   # measured (S = 2^14): 2.7e-5 / 0.0044 / 0.027 / 0.052; 4.6e-5 / 0.0025 / 0.027 / 0.046
+# bounds = 1.3 x the largest value this test has printed on MI355X over rounds 2 - 4 (loss: 2 x - it is a difference of two sums of B x T terms
+# and moves by an order of magnitude with the kernels the autotune happens to pick):   loss_abs, logit_max_abs, grad_rel_l2, worst single parameter
+# measured, round 4: hamt bf16 2.4e-6 / 0.0295 / 0.0858 / 0.184 (encoder.x_layers.1.lang_self_att.self.key.weight: a gradient that is small by
+# softmax shift invariance), duet bf16 3.3e-5 / 0.0196 / 0.0831 / 0.134; rounds 2 - 3: 2.3e-4 / 0.033 / 0.089 / 0.147 and 0.9 - 2.4e-4 / 0.0155 - 0.0195 / 0.083 - 0.085 / 0.127 - 0.134
+BF16_BOUNDS = {"hamt": (5e-4, 0.043, 0.116, 0.24), "duet": (5e-4, 0.026, 0.11, 0.175)}
+# float16 with the trainer's loss scale S = 2^14, round 4: 5.9e-5 / 0.0041 / 0.0281 / 0.050 and 4.5e-5 / 0.0025 / 0.0271 / 0.041 (round 3: 2.7e-5 / 0.0044 / 0.027 / 0.052; 4.6e-5 / 0.0025 / 0.027 / 0.046)
+F16_BOUNDS = {"hamt": (1.2e-4, 0.0057, 0.037, 0.068), "duet": (1e-4, 0.0033, 0.036, 0.06)}
 
 
 @pytest.mark.parametrize("family,B,low", [("hamt", 64, torch.bfloat16), ("duet", 32, torch.bfloat16), ("hamt", 64, torch.float16),

@@ -25,7 +25,14 @@ def _err(a, b):
     return (a.double() - b.double()).abs().max().item()
 
 
-TOL = {torch.float32: 1e-4, torch.bfloat16: 6e-2, torch.float16: 8e-3}       # float16: 11 bits of mantissa (8x finer than bfloat16)
+# max |error| allowed, in units of max(1, max |reference|): float32 = the parity gate's 1e-4; the 16-bit paths are compared with float64 math on the
+# SAME 16-bit inputs, so what is left is output rounding (2^-9 bfloat16, 2^-12 float16 relative) plus the 16-bit intermediates of the fused chains
+TOL = {torch.float32: 1e-4, torch.bfloat16: 1.5e-2, torch.float16: 2e-3}
+
+
+def _chk(a, ref, t, what=""):
+    e, lim = _err(a, ref), t * max(1.0, ref.abs().max().item())
+    assert e < lim, (what, e, lim)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
@@ -101,8 +108,8 @@ def test_layernorm(ops, dtype, rows, H, eps):
     y, mean, rstd = ops.ln_fwd(x, g, b, eps)
     dx, dg, db = ops.ln_bwd(dy, x, g, mean, rstd)
     t = TOL[dtype]
-    assert _err(y, yr) < t
-    assert _err(dx, xr.grad) < t
+    _chk(y, yr, t, "y")
+    _chk(dx, xr.grad, t, "dx")
     assert _err(dg, gr.grad) < t * max(1.0, gr.grad.abs().max().item())
     assert _err(db, br.grad) < t * max(1.0, br.grad.abs().max().item())
 
@@ -137,19 +144,19 @@ def test_attention_fwd_bwd(ops, dtype, B, Sq, Sk, use_bias):
     br = bias.double().clone().requires_grad_(True) if use_bias else None
     ref = _attn_ref(qr, kr, vr, kmask, br, B, Sq, Sk)
     t = TOL[dtype]
-    assert _err(out, ref) < t, ("fwd", _err(out, ref))
+    _chk(out, ref, t, "fwd")
     dout = _rand((B * Sq, H), dtype, 15)
     ref.backward(dout.double())
     dq_buf = torch.zeros_like(qkv_q)
     dk_buf = torch.zeros_like(qkv_k)
     dbias = torch.zeros_like(bias) if use_bias else None
     ops.attn_bwd(q, k, v, out, dout, lse, dq_buf[:, :H], dk_buf[:, H:2 * H], dk_buf[:, 2 * H:], B, Sq, Sk, kmask, bias, dbias)
-    assert _err(dq_buf[:, :H], qr.grad) < t, ("dq", _err(dq_buf[:, :H], qr.grad))
-    assert _err(dk_buf[:, H:2 * H], kr.grad) < t, ("dk", _err(dk_buf[:, H:2 * H], kr.grad))
-    assert _err(dk_buf[:, 2 * H:], vr.grad) < t, ("dv", _err(dk_buf[:, 2 * H:], vr.grad))
+    _chk(dq_buf[:, :H], qr.grad, t, "dq")
+    _chk(dk_buf[:, H:2 * H], kr.grad, t, "dk")
+    _chk(dk_buf[:, 2 * H:], vr.grad, t, "dv")
     assert float(dq_buf[:, H:].abs().max()) == 0.0 and float(dk_buf[:, :H].abs().max()) == 0.0   # nothing outside the slices
     if use_bias:
-        assert _err(dbias, br.grad) < t * 5, ("dbias", _err(dbias, br.grad))
+        _chk(dbias, br.grad, t * 5, "dbias")
 
 
 @pytest.mark.parametrize("B,Sq,Sk", [(2, 45, 150), (2, 70, 200), (1, 130, 256), (2, 37, 129)])
@@ -252,7 +259,7 @@ def test_blocks_against_torch(ops, dtype):
         out_r = out_r if isinstance(out_r, tuple) else (out_r,)
         t = TOL[dtype]
         for a_, r_ in zip(out_p, out_r):
-            assert _err(a_, r_) < t, ("fwd", _err(a_, r_))
+            _chk(a_, r_, t, "fwd")
         torch.manual_seed(1)
         ws = [torch.randn_like(r_) for r_ in out_r]
         sum((a_.double() * w).sum() for a_, w in zip(out_p, ws)).backward()
@@ -262,11 +269,16 @@ def test_blocks_against_torch(ops, dtype):
             p.grad = None
         sum((r_ * w).sum() for r_, w in zip(out_r, ws)).backward()
         gr = [p.grad.clone() for p in params if p.grad is not None]
-        scale = 30.0 if dtype == torch.bfloat16 else 1.0
+        scale = 4.0 if dtype == torch.bfloat16 else 1.0      # a chain of 16-bit intermediates (measured: <= 2.6 x the single-op bound)
         for a_, r_ in zip(gx, [x.grad for x in xs_r]):
             assert _err(a_, r_) < t * scale * max(1.0, r_.abs().max().item()), ("dx", _err(a_, r_))
         assert len(gp) == len(gr)
         for a_, r_ in zip(gp, gr):
+            if dtype != torch.float32 and r_.abs().max().item() < 1e-9:
+                # the key bias: softmax is shift-invariant, the exact gradient is 0 and the 16-bit one is what is left when B x S rounded dK rows
+                # are summed - rounding noise of that sum (measured 0.06), not a fraction of the (zero) reference
+                assert _err(a_, r_) < 0.1, ("dparam with a zero reference", _err(a_, r_))
+                continue
             assert _err(a_, r_) < t * scale * max(1.0, r_.abs().max().item()), ("dparam", _err(a_, r_), r_.abs().max().item())
 
     run(lambda x: ops.self_att_block(x, aml, P), lambda x: ref_att(x, x, aml, att), [lang])
@@ -749,3 +761,81 @@ def test_bias_residual_layernorm_entry_points(ops, dtype, eps):
               y.data_ptr(), H, 0, 0, mean.data_ptr(), rstd.data_ptr(), rows, H, st)
     ref2 = torch.nn.functional.layer_norm(x0.double(), (H,), gamma.double(), beta.double(), eps)
     assert (y.double() - ref2).abs().max().item() <= tol * max(1.0, ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("variant", [14, 15, 32])
+def test_timed_gemm_kernels_against_float64_at_bench_shapes(ops, variant, dtype):
+    """The kernels bench.py times - persistent 128 x 128 (14), 256 x 256 8-phase (15), 256 x 128 with loader waves (32) - held to float64 math
+    DIRECTLY (not through bit-identity with variant 1) at the bench's own launches: one step's two streams (5504 + 2752 rows, a dual
+    launch) and the episode-batched backward (49536 rows), N in {768, 2304, 3072}, K in {768, 3072}, every epilogue kind the step uses.
+    Bound: TOL x max |reference| (16-bit output rounding + the 16-bit epilogue operands)."""
+    t = TOL[dtype]
+    rows = {14: ((5504, 2752),), 15: ((5504, 2752), (33024, 16512)), 32: ((5504, 2752), (33024, 16512))}[variant]
+    for (M0, M1) in rows:
+        for (N, K) in ((768, 768), (2304, 768), (3072, 768), (768, 3072), (768, 2304)):
+            a = (_rand((M0, K), dtype, 61, 0.5), _rand((M1, K), dtype, 62, 0.5))
+            b = (_rand((N, K), dtype, 63, 0.05), _rand((N, K), dtype, 64, 0.05))
+            bias = (_rand((N,), torch.float32, 65, 0.1), _rand((N,), torch.float32, 66, 0.1))
+            res = (_rand((M0, N), dtype, 67, 0.5), _rand((M1, N), dtype, 68, 0.5))
+            zsrc = (_rand((M0, N), dtype, 69, 1.0), _rand((M1, N), dtype, 70, 1.0))
+            lin = [x.double() @ w.double().t() for x, w in zip(a, b)]
+            kinds = {"bias": dict(bias=bias), "bias + residual": dict(bias=bias, residual=res),
+                     "bias + GELU + stored pre-activation": dict(bias=bias, act=1, want_z=True),
+                     "GELU' of a stored pre-activation (dgrad)": dict(dact_src=zsrc, dact=1), "residual (dgrad)": dict(residual=res)}
+            for kind, kw in kinds.items():
+                want_z = kw.pop("want_z", False)
+                z = tuple(torch.empty_like(r) for r in res) if want_z else (None, None)
+                saved = (ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS)
+                try:
+                    ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS = True, (variant,), 1 << 30, 1 << 30
+                    ops._GEMM_BEST.clear()
+                    outs = ops.gemm_nt2(a, b, preact=z, **kw)
+                finally:
+                    ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS = saved
+                    ops._GEMM_BEST.clear()
+                for i in range(2):
+                    pre = lin[i] + (kw["bias"][i].double() if "bias" in kw else 0.0)
+                    ref = pre
+                    if kw.get("act") == 1:
+                        ref = torch.nn.functional.gelu(pre)
+                    if kw.get("dact") == 1:
+                        zz = zsrc[i].double().requires_grad_(True)
+                        ref = pre * torch.autograd.grad(torch.nn.functional.gelu(zz).sum(), zz)[0]
+                    if "residual" in kw:
+                        ref = ref + res[i].double()
+                    _chk(outs[i], ref, t, (variant, M0, N, K, kind, i))
+                    if want_z:
+                        _chk(z[i], pre, t, (variant, M0, N, K, kind + " (z)", i))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_ring_weight_gradient_against_float64_at_bench_shapes(ops, dtype):
+    """gemm_tn_ring_kernel (variant 7, what the flush picks for the episode-long reductions) against float64: 49536 rows as the two
+    segments of a shared cross-attention weight, N x K in {2304, 3072, 768} x 768 and 768 x 3072, partial slabs + the batched reduction."""
+    import ctypes
+    import numpy as np
+    from vln_imagine_amd import _lib
+    st = torch.cuda.current_stream().cuda_stream
+    Ms = [33024, 16512]
+    for (N, K, split) in ((2304, 768, 9), (3072, 768, 7), (768, 768, 28), (768, 3072, 7)):
+        dd = [_rand((m, N), dtype, 71 + i, 0.1) for i, m in enumerate(Ms)]
+        xx = [_rand((m, K), dtype, 81 + i, 0.5) for i, m in enumerate(Ms)]
+        ref = sum(d.double().t() @ x.double() for d, x in zip(dd, xx))
+        refb = sum(d.double().sum(0) for d in dd)
+        n, nmt = len(Ms), sum((m + 63) // 64 for m in Ms)
+        eff, per = ops._eff_split(nmt, split)
+        part = torch.empty((eff * (N * K + N),), device="cuda")
+        gw, gb = torch.zeros(N, K, device="cuda"), torch.zeros(N, device="cuda")
+        pa = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dd]); pb = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xx])
+        pm = (ctypes.c_int * n)(*Ms)
+        cpart = part.data_ptr() + 4 * eff * N * K
+        _lib.call("vlni_gemm_tn_h16_grouped_part", ops._DT[dtype], n, pa, pb, pm, N, K, part.data_ptr(), N * K, N, K, cpart, split, 7, st)
+        arr = np.zeros((2,), ops._PART_DT)
+        arr[0] = (gw.data_ptr(), part.data_ptr(), N * K // 4, N * K // 4, eff, 0)
+        arr[1] = (gb.data_ptr(), cpart, N // 4, N // 4, eff, -(-(N * K // 4) // 1024))
+        tab = torch.from_numpy(arr.view(np.uint8)).cuda()
+        _lib.call("vlni_reduce_parts", tab.data_ptr(), 2, int(arr[1]["blk0"]) + -(-(N // 4) // 1024), st)
+        # float32 accumulation of 49.5 k products of 16-bit inputs: no 16-bit rounding of the output at all
+        _chk(gw, ref, 2e-5, ("dW", N, K))
+        _chk(gb, refb, 2e-5, ("db", N, K))
