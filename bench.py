@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402   (importing torch does not initialise the GPU)
 import torch.distributed as dist  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0              # HBM3E, same guide ("HBM ~8 TB/s"; ~6.3 TB/s is what a streaming kernel reaches)
 MFMA_BF16_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 MFMA_F32_PEAK_TFLOPS = 157.3
 
@@ -258,6 +259,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip time-batched / train-mode / shipped-freeze / T=1 / fp32 extra lines")
     ap.add_argument("--no-parity", action="store_true", help="skip the bf16-vs-fp32 error report")
+    ap.add_argument("--dump-tune", default=None, help="write the kernel choices of this run (GEMM pipeline per shape, weight-gradient variant x split) to a file")
+    ap.add_argument("--load-tune", default=None, help="start from the kernel choices of another run (--dump-tune): the counter passes (--no-graph) then "
+                                                      "launch the very kernels the timed, graph-replayed run used")
     args = ap.parse_args()
     if args.batch is None:
         args.batch = 32 if args.model == "duet" else 64
@@ -432,6 +436,13 @@ def main():
             rccl["exchange"] = trainer.exchange_report()
         return dt / steps, launch, float(loss.detach()), eager
 
+    if args.load_tune:
+        import pickle
+        with open(args.load_tune, "rb") as fh:
+            tn = pickle.load(fh)
+        ops._GEMM_BEST.update(tn["gemm"]); ops._TN_BEST.update(tn["tn"]); ops._TNB_BEST.update(tn["tnb"])
+        log(f"kernel choices loaded from {args.load_tune}: {len(tn['gemm'])} GEMM shapes, {len(tn['tn']) + len(tn['tnb'])} weight-gradient classes")
+
     # ---- the metric's workload -------------------------------------------------------------------------------------------
     w = Workload(args.model, args, shipped, dev, dtype, tag=f"bench{rank}")
     if args.model == "hamt":
@@ -443,11 +454,49 @@ def main():
     sec, launch, last_loss, eager_step = measure(w, trainer, args.steps, args.warmup, mode=args.mode, graph=args.graph)
     ms = sec * 1e3
     eps = args.batch * world / sec
+    if args.dump_tune and rank == 0:
+        import pickle
+        with open(args.dump_tune, "wb") as fh:
+            pickle.dump({"gemm": dict(ops._GEMM_BEST), "tn": dict(ops._TN_BEST), "tnb": dict(ops._TNB_BEST)}, fh)
 
     # ---- roofline of the dominant kernel family (instrumented pass, not part of the timed region) -----------------------------
-    roof = None
-    if not args.no_roofline:           # EVERY rank runs the instrumented step (it contains the gradient all-reduce)
-        rec, epi = [], [0.0]
+    def roofline_of(w, sec, eager_step, family, with_ceiling=True):
+        """One instrumented (eager, HIP-event-timed) step of workload `w` -> the `roofline` object of its forward / dgrad GEMM family, plus the
+        weight-gradient and attention families of the same step. Not part of any timed region."""
+        ms = sec * 1e3
+        from vln_imagine_amd import _lib
+        rec, epi, fam = [], [0.0], []
+        orig_call = _lib.call
+        FAM = ("vlni_gemm_tn_h16_grouped_part", "vlni_gemm_tn_h16_grouped_v", "vlni_reduce_parts", "vlni_attn_bwd_dual", "vlni_attn_bwd", "vlni_attn_fwd_dual",
+               "vlni_attn_fwd")
+
+        def timed_call(name, *a_):              # the other kernel families of the step, by entry point (algorithmic work from the call's own arguments)
+            if name not in FAM:
+                return orig_call(name, *a_)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r_ = orig_call(name, *a_)
+            e1.record()
+            es_ = 2
+            if name.startswith("vlni_gemm_tn"):                     # (dtype, nseg, A, B, M[], lda/N, ldb/K, ...): 2 sum(M) N K flop
+                n_, pm_ = a_[1], a_[4]
+                work = 2.0 * sum(pm_[i] for i in range(n_)) * a_[9] * a_[10]
+            elif name == "vlni_reduce_parts":
+                work = 0.0
+            elif name.endswith("_dual"):                            # (..., B, nh, Sq[2], Sk[2], ...): bytes of q, k, v, out (+ dout, dq, dk, dv)
+                off = 21 if "bwd" in name else 12
+                B_, nh_, sq_, sk_ = a_[off], a_[off + 1], a_[off + 2], a_[off + 3]
+                per = 4 if "bwd" in name else 2
+                work = float(sum(B_ * (per * sq_[i] + per * sk_[i]) * nh_ * 64 * es_ for i in range(2)))
+            else:
+                off = 21 if "bwd" in name else 12
+                B_, nh_, sq_, sk_ = a_[off], a_[off + 1], a_[off + 2], a_[off + 3]
+                per = 4 if "bwd" in name else 2
+                work = float(B_ * (per * sq_ + per * sk_) * nh_ * 64 * es_)
+            fam.append((name, work, e0, e1))
+            return r_
+
+        orig, orig2 = ops.gemm_nt, ops.gemm_nt2
         orig, orig2 = ops.gemm_nt, ops.gemm_nt2
 
         def _epi_bytes(k):              # tensors the fused epilogue reads / writes besides C: residual, GELU' source, pre-activation
@@ -485,7 +534,7 @@ def main():
             epi[0] += _epi_bytes(k)
             return r
 
-        ops.gemm_nt, ops.gemm_nt2 = timed, timed2
+        ops.gemm_nt, ops.gemm_nt2, _lib.call = timed, timed2, timed_call
         try:
             # keep the stream busy while the host enqueues the step, so that each event pair brackets the kernel alone and not
             # the host's gap between recording the event and launching (otherwise the average reads ~35 % above rocprof's)
@@ -493,7 +542,7 @@ def main():
             eager_step()
             torch.cuda.synchronize()
         finally:
-            ops.gemm_nt, ops.gemm_nt2 = orig, orig2
+            ops.gemm_nt, ops.gemm_nt2, _lib.call = orig, orig2, orig_call
         log("instrumented roofline step done")
         tot_f = sum(r[0] for r in rec)
         raw_ms = sum(r[1].elapsed_time(r[2]) for r in rec)
@@ -519,7 +568,7 @@ def main():
         traffic, traffic_src = None, None
         try:      # HBM bytes per launch: separate rocprofv3 --pmc passes of this command (never collected inside a timed run)
             pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
-                         if f.endswith("_pmc_traffic.json") and ("duet" in f) == (args.model == "duet"))
+                         if f.endswith("_pmc_traffic.json") and ("duet" in f) == (family == "duet"))
             if pmc and args.dtype == "bf16" and args.mode == "taped" and args.train_mode:      # collected on the default workloads only
                 traffic = round(json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["bytes_per_launch"])
                 traffic_src = f"profiles/{pmc[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
@@ -529,6 +578,8 @@ def main():
         # timed dtype, random operands - a reference measurement only, the product path never calls it
         ceiling, ceiling_at = None, None
         try:
+            if not with_ceiling:
+                raise StopIteration
             cd = torch.float32 if args.dtype == "fp32" else dtype
             for n_ in ((2048, 4096) if args.dtype == "fp32" else (4096, 8192)):
                 xa, xb = torch.randn(n_, n_, device=dev).to(cd), torch.randn(n_, n_, device=dev).to(cd)
@@ -544,12 +595,30 @@ def main():
                 if ceiling is None or tf > ceiling:
                     ceiling, ceiling_at = tf, n_
                 del xa, xb
+        except StopIteration:
+            pass
         except Exception as e:                                  # never lets the reference measurement break the line
             log(f"large-GEMM ceiling not measured ({type(e).__name__}: {e})")
         alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec)
+        def fam_sum(prefixes):
+            sel = [f_ for f_ in fam if f_[0].startswith(prefixes)]
+            t_ = sum(max(f_[2].elapsed_time(f_[3]) - pair_ms, 1e-4) for f_ in sel)
+            return len(sel), sum(f_[1] for f_ in sel), t_
+        families = {}
+        n_, f_, t_ = fam_sum(("vlni_gemm_tn",))
+        nr_, _, tr_ = fam_sum(("vlni_reduce_parts",))
+        if n_:
+            families["weight_gradients"] = {"bound": "mfma", "launches": n_, "ms": round(t_, 3), "achieved": round(f_ / (t_ * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
+                                            "frac": round(f_ / (t_ * 1e-3) / 1e12 / peak, 4), "partial_reduction_ms": round(tr_, 3)}
+        for key_, pre_ in (("attention_bwd", ("vlni_attn_bwd",)), ("attention_fwd", ("vlni_attn_fwd",))):
+            n_, by_, t_ = fam_sum(pre_)
+            if n_:
+                families[key_] = {"bound": "hbm", "launches": n_, "ms": round(t_, 3), "achieved": round(by_ / (t_ * 1e-3) / 1e9, 1), "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                  "frac": round(by_ / (t_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "bytes": "q, k, v, out read/written once" + (" + dout read, dq, dk, dv written" if "bwd" in key_ else "")}
         roof = {"bound": "mfma", "kernel": "gemm_nt_* / gemm_nn_* <%s>" % {"bf16": "__bf16", "fp16": "_Float16", "fp32": "float"}[args.dtype],
                 "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic_source": traffic_src, "traffic_ratio": round(traffic / (alg / len(rec)), 3) if traffic else None,
                 "algorithmic_bytes_per_launch": round(alg / len(rec)),
                 "algorithmic_bytes_per_launch_with_epilogue": round((alg + epi[0]) / len(rec)),
                 "launches_per_step": len(rec), "avg_launch_us": round(tot_ms * 1e3 / len(rec), 2),
@@ -562,7 +631,13 @@ def main():
                 "measured_large_gemm_tflops": ceiling,
                 "frac_of_measured_large_gemm": round(ach / ceiling, 4) if ceiling else None,
                 "measured_large_gemm": f"torch.matmul(a, b.T) (vendor library), {ceiling_at}^3 {args.dtype}, random operands, best of 4096^3 / 8192^3 "
-                                       f"(fp32: 2048^3 / 4096^3), this box"}
+                                       f"(fp32: 2048^3 / 4096^3), this box" if with_ceiling else None,
+                "families": families or None}
+        return roof
+
+    roof = None
+    if not args.no_roofline:           # EVERY rank runs the instrumented step (it contains the gradient all-reduce)
+        roof = roofline_of(w, sec, eager_step, args.model)
 
     # ---- error of the timed path against the fp32 parity path (same model, same weights, B = 8 slice, fwd + bwd) -------------
     parity = None
@@ -751,6 +826,32 @@ def main():
             s_, _, _, _ = measure(ws_, tr2, k_extra, 2, mode=args.mode, graph=args.graph, what="freeze=shipped")
             extras["freeze_shipped"] = line(s_, ws_.flops, "the released run's freeze: language stack (and HAMT history encoder) forward only")
             tr2.close()
+
+    # BASELINE.json configs[3] (DUET, batch 32, one GPU) beside the metric's HAMT line, so that the driver's own `bench.py --gpus 1` times it:
+    # the same taped step (step-by-step forward, one episode-batched backward, hipGraph replay), its GEMM family against the same peak
+    if world == 1 and not forced and not args.no_extras and args.model == "hamt" and args.dtype == "bf16" and not shipped:
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        wd = Workload("duet", args, False, dev, dtype, batch=32, tag=f"bench{rank}")
+        if args.train_mode:
+            wd.model.train()
+        trd = FlatTrainer(wd.model, lr=1e-5, grad_comm_dtype=comm)
+        trainer = trd                                        # measure()'s closures read `trainer`
+        kd = max(3, min(args.steps, 20))
+        s_, launch_d, _, eager_d = measure(wd, trd, kd, 3, mode="taped", graph=args.graph, what="duet_b32")
+        e_ = {"value": round(32 / s_, 2), "unit": "episodes/s", "ms_per_step": round(s_ * 1e3, 3), "ms_per_step_median": median_ms.get("duet_b32"),
+              "steps": kd, "step_algorithmic_tflops": round(wd.flops / s_ / 1e12, 2), "launch": launch_d,
+              "workload": f"{wd.label}, batch 32, {args.L} text, 36 views, {args.I} imaginations, T={args.T}, freeze=none, "
+                          + ("train mode: in-kernel dropout p=0.1" if args.train_mode else "eval") + ", episode tape",
+              "note": "BASELINE.json configs[3]; `python bench.py --model duet` is the full line (roofline traffic, CPU baseline, extras)"}
+        if not args.no_roofline:
+            rd = roofline_of(wd, s_, eager_d, "duet", with_ceiling=False)
+            e_["roofline"] = {k_: rd[k_] for k_ in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_ratio", "launches_per_step",
+                                                     "avg_launch_us", "gemm_share_of_step", "step_frac_of_peak", "families")}
+        extras["duet_b32"] = e_
+        trd.close()
+        del wd, trd
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
