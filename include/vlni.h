@@ -35,8 +35,10 @@ int vlni_set_dropout_seed_base(const unsigned* device_ptr);
 /* C[M,N] = epi(alpha * A[M,K] * B[N,K]^T): replaces nn.Linear forward (R:101-103,145,174,187,327-329,
  * 536-537, 956-960; D:598-655 MLP), its dgrad (B = transposed weight shadow) and, with
  * atomic_f32 + split_k, its wgrad (A = dY^T, B = X^T; C float32, accumulated with atomics).
- * epi: + bias[N] -> (store preact) -> (* act'(dact_src): 1 gelu', 2 relu') -> act (1 gelu-erf R:27-33,
- * 2 relu) -> + residual -> C.   K, lda, ldb multiples of 16 bytes; A, B 16-byte aligned. */
+ * epi: + bias[N] -> (store preact) -> (* act'(dact_src): 1 gelu', 2 relu'; 3: * dact_src itself) -> act (1 gelu-erf R:27-33,
+ * 2 relu, 3 gelu-erf with GELU'(pre) stored to `preact` instead of pre: the FFN forward of the 16-bit paths, whose dgrad then
+ * runs dact = 3, one multiply instead of three transcendentals per element) -> + residual -> C.
+ * K, lda, ldb multiples of 16 bytes; A, B 16-byte aligned. */
 int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                  const float* bias, int act, const void* residual, long ldr, void* preact, long ldp,
                  const void* dact_src, long ldd, int dact, float alpha, int split_k, int atomic_f32, void* stream);

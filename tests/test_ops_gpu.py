@@ -78,6 +78,15 @@ def test_gemm_epilogues(ops, dtype):
     assert _err(out2, ref2) < TOL[dtype] * 3
     out3 = ops.gemm_nt(a, b, bias=bias, act=2)
     assert _err(out3, torch.relu(zr)) < TOL[dtype] * 3
+    # act 3: GELU with GELU'(pre) stored in place of pre; dact 3: multiply by a stored derivative (the FFN pair of the 16-bit paths)
+    g = torch.empty((M, N), dtype=dtype, device="cuda")
+    out4 = ops.gemm_nt(a, b, bias=bias, act=3, residual=res, preact=g)
+    zz = zr.clone().requires_grad_(True)
+    gref = torch.autograd.grad(torch.nn.functional.gelu(zz).sum(), zz)[0]
+    _chk(out4, ref, TOL[dtype], "act 3 output")
+    _chk(g, gref, TOL[dtype], "act 3 stored derivative")
+    out5 = ops.gemm_nt(a, b, dact_src=g, dact=3, residual=res)
+    _chk(out5, (a.double() @ b.double().t()) * g.double() + res.double(), TOL[dtype], "dact 3")
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
@@ -782,7 +791,9 @@ def test_timed_gemm_kernels_against_float64_at_bench_shapes(ops, variant, dtype)
             lin = [x.double() @ w.double().t() for x, w in zip(a, b)]
             kinds = {"bias": dict(bias=bias), "bias + residual": dict(bias=bias, residual=res),
                      "bias + GELU + stored pre-activation": dict(bias=bias, act=1, want_z=True),
-                     "GELU' of a stored pre-activation (dgrad)": dict(dact_src=zsrc, dact=1), "residual (dgrad)": dict(residual=res)}
+                     "bias + GELU + stored GELU' (act 3)": dict(bias=bias, act=3, want_z=True),
+                     "GELU' of a stored pre-activation (dgrad)": dict(dact_src=zsrc, dact=1), "stored derivative (dgrad, dact 3)": dict(dact_src=zsrc, dact=3),
+                     "residual (dgrad)": dict(residual=res)}
             for kind, kw in kinds.items():
                 want_z = kw.pop("want_z", False)
                 z = tuple(torch.empty_like(r) for r in res) if want_z else (None, None)
@@ -797,16 +808,22 @@ def test_timed_gemm_kernels_against_float64_at_bench_shapes(ops, variant, dtype)
                 for i in range(2):
                     pre = lin[i] + (kw["bias"][i].double() if "bias" in kw else 0.0)
                     ref = pre
-                    if kw.get("act") == 1:
+                    stored = pre
+                    if kw.get("act") in (1, 3):
                         ref = torch.nn.functional.gelu(pre)
+                    if kw.get("act") == 3:
+                        zz = pre.clone().requires_grad_(True)
+                        stored = torch.autograd.grad(torch.nn.functional.gelu(zz).sum(), zz)[0]
                     if kw.get("dact") == 1:
                         zz = zsrc[i].double().requires_grad_(True)
                         ref = pre * torch.autograd.grad(torch.nn.functional.gelu(zz).sum(), zz)[0]
+                    if kw.get("dact") == 3:
+                        ref = pre * zsrc[i].double()
                     if "residual" in kw:
                         ref = ref + res[i].double()
                     _chk(outs[i], ref, t, (variant, M0, N, K, kind, i))
                     if want_z:
-                        _chk(z[i], pre, t, (variant, M0, N, K, kind + " (z)", i))
+                        _chk(z[i], stored, t, (variant, M0, N, K, kind + " (z)", i))
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

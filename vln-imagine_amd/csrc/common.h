@@ -127,6 +127,21 @@ template <typename T> __device__ __forceinline__ float gelu_grad_t(float x) {
   }
 }
 
+// GELU and GELU' of one pre-activation together (act == 3: the forward epilogue stores GELU'(z) where act == 1 stores z, and the dgrad epilogue's
+// dact == 3 is then ONE multiply by the stored value instead of GELU' of z - three transcendentals per element of a 256 x 256 tile's
+// epilogue that nothing hides). The two share Phi(x).
+template <typename T> __device__ __forceinline__ float gelu_with_grad_t(float x, float& grad) {
+  if constexpr (sizeof(T) == 2) {
+    const float cdf = phi_cdf16(x);
+    grad = cdf + (x * 0.3989422804014327f) * __builtin_amdgcn_exp2f(x * x * -0.72134752044f);
+    return x * cdf;
+  } else {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    grad = cdf + x * (0.3989422804014327f * __expf(-0.5f * x * x));
+    return x * cdf;
+  }
+}
+
 // Counter-based dropout: keep(seed, idx) is a pure function, so the backward pass regenerates the forward mask from
 // (seed, element index) instead of storing it. idx = row * row_length + col of the tensor the mask applies to.
 __host__ __device__ __forceinline__ unsigned drop_hash(unsigned idx, unsigned seed) {

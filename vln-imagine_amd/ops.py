@@ -330,6 +330,16 @@ def _arr(ctype, vals):
     return (ctype * 2)(*vals)
 
 
+GELU_STORE_GRAD = os.environ.get("VLNI_GELU_STORE_GRAD", "1") == "1"
+
+
+def _gelu_codes(dtype):
+    """(act, dact) of an FFN's two fused epilogues. 16-bit paths: the forward stores GELU'(z) where it would store z (act 3) and the dgrad epilogue
+    multiplies by that tensor (dact 3) - GELU' cost the episode-long FFN dgrad launches 40 % (three transcendentals per element in a 256 x 256
+    tile's epilogue that no other block hides). float32 (the parity path) keeps z and erf."""
+    return (3, 3) if (GELU_STORE_GRAD and dtype in H16) else (1, 1)
+
+
 def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None, None), dact_src=(None, None), dact=0,
              drop=None):
     """Two GEMMs with the same (N, K) and epilogue kind in ONE launch: out_i = epi(a_i @ b_i^T), i = 0, 1.
@@ -1182,8 +1192,8 @@ class _FfnBlock(torch.autograd.Function):
         shp = x.shape
         x2 = _rows(_chk(x, "x"))
         dt = x.dtype
-        z = _new((x2.shape[0], w1.shape[0]), dt, x.device)
-        a = gemm_nt(x2, _w((w1,), dt), bias=b1, act=1, preact=z)
+        z = _new((x2.shape[0], w1.shape[0]), dt, x.device)           # z, or GELU'(z) on the 16-bit paths (_gelu_codes)
+        a = gemm_nt(x2, _w((w1,), dt), bias=b1, act=_gelu_codes(dt)[0], preact=z)
         pre = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2, drop=(drop[1], drop[2]))
         y, mean, rstd = ln_fwd(pre, g, b, eps)
         ctx.save_for_backward(x2, z, a, pre, mean, rstd)
@@ -1202,7 +1212,7 @@ class _FfnBlock(torch.autograd.Function):
         dw1 = db1 = dw2 = db2 = None
         if wparams:
             (dw2,), (db2,) = _wb_grad_to((w2,), (b2,), dpm, a)
-        dz = gemm_nt(dpm, _w((w2,), dt, True), dact_src=z, dact=1)       # GELU' fused in the dgrad epilogue
+        dz = gemm_nt(dpm, _w((w2,), dt, True), dact_src=z, dact=_gelu_codes(dt)[1])       # GELU' fused in the dgrad epilogue
         if wparams:
             (dw1,), (db1,) = _wb_grad_to((w1,), (b1,), dz, x2)
         dx = gemm_nt(dz, _w((w1,), dt, True), residual=dpre).view(ctx.shp) if ng[0] else None
@@ -1395,7 +1405,7 @@ class _DualFfnBlock(torch.autograd.Function):
         FF = P0[0].shape[0]
         z0 = _new((a0.shape[0], FF), dt, x0.device)
         z1 = _new((a1.shape[0], FF), dt, x0.device)
-        h0, h1 = gemm_nt2((a0, a1), (_w((P0[0],), dt), _w((P1[0],), dt)), bias=(P0[1], P1[1]), act=1, preact=(z0, z1))
+        h0, h1 = gemm_nt2((a0, a1), (_w((P0[0],), dt), _w((P1[0],), dt)), bias=(P0[1], P1[1]), act=_gelu_codes(dt)[0], preact=(z0, z1))
         ph = max(drop0[1], drop1[1])
         pre0, pre1 = gemm_nt2((h0, h1), (_w((P0[2],), dt), _w((P1[2],), dt)), bias=(P0[3], P1[3]), residual=(a0, a1),
                               drop=(ph, (drop0[2], drop1[2])))
@@ -1419,7 +1429,7 @@ class _DualFfnBlock(torch.autograd.Function):
             (g0[2],), (g0[3],) = _wb_grad_to((P0[2],), (P0[3],), dm0, h0)
         if w1:
             (g1[2],), (g1[3],) = _wb_grad_to((P1[2],), (P1[3],), dm1, h1)
-        dz0, dz1 = gemm_nt2((dm0, dm1), (_w((P0[2],), dt, True), _w((P1[2],), dt, True)), dact_src=(z0, z1), dact=1)
+        dz0, dz1 = gemm_nt2((dm0, dm1), (_w((P0[2],), dt, True), _w((P1[2],), dt, True)), dact_src=(z0, z1), dact=_gelu_codes(dt)[1])
         if w0:
             (g0[0],), (g0[1],) = _wb_grad_to((P0[0],), (P0[1],), dz0, a0)
         if w1:
@@ -1593,7 +1603,7 @@ class _PreNormFfnBlock(torch.autograd.Function):
         _, ph, sd = drop
         xn, mean, rstd = ln_fwd(x2, g, b, eps)
         z = _new((x2.shape[0], w1.shape[0]), dt, x.device)
-        a = gemm_nt(xn, _w((w1,), dt), bias=b1, act=1, preact=z, drop=(ph, sd))
+        a = gemm_nt(xn, _w((w1,), dt), bias=b1, act=_gelu_codes(dt)[0], preact=z, drop=(ph, sd))
         y = gemm_nt(a, _w((w2,), dt), bias=b2, residual=x2, drop=(ph, sd + 1))
         ctx.save_for_backward(x2, xn, z, a, mean, rstd)
         ctx.P, ctx.shp, ctx.drop = (g, b, w1, b1, w2, b2), shp, drop
@@ -1612,7 +1622,7 @@ class _PreNormFfnBlock(torch.autograd.Function):
         dw1 = db1 = dw2 = db2 = None
         if wparams:
             (dw2,), (db2,) = _wb_grad_to((w2,), (b2,), dym, a)
-        dz = gemm_nt(dym, _w((w2,), dt, True), dact_src=z, dact=1, drop=(ph, sd))
+        dz = gemm_nt(dym, _w((w2,), dt, True), dact_src=z, dact=_gelu_codes(dt)[1], drop=(ph, sd))
         if wparams:
             (dw1,), (db1,) = _wb_grad_to((w1,), (b1,), dz, xn)
         dxn = gemm_nt(dz, _w((w1,), dt, True))
