@@ -153,10 +153,13 @@ def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2,
     hist_masks = (torch.arange(T, device=dev)[None, :] <= torch.arange(T, device=dev)[:, None])    # [t, entry]
     hist_masks = hist_masks.unsqueeze(1).expand(T, B, T).reshape(T * B, T)
     rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+    kw = {}
+    if hasattr(model, "language_side") and not isinstance(txt, list):      # product model: the episode's language side built once (see TapedEpisode)
+        kw["lang_side"] = model.language_side(txt, et.txt_masks, img, et.imagine_masks).repeat(T)
     logits, txt_o, hist_o, ob_o = model(
         "visual", txt_embeds=rep(txt), txt_masks=rep(et.txt_masks), hist_embeds=hist, hist_masks=hist_masks,
         ob_img_feats=cat("ob_img_feats"), ob_ang_feats=cat("ob_ang_feats"), ob_nav_types=cat("ob_nav_types"),
-        ob_masks=cat("ob_masks"), imagine_embeds=rep(img), imagine_masks=rep(et.imagine_masks))
+        ob_masks=cat("ob_masks"), imagine_embeds=rep(img), imagine_masks=rep(et.imagine_masks), **kw)
     ml_loss = criterion(logits, cat("target"))
     loss = ml_loss * train_ml / B
     if use_aux and torch.is_tensor(aux):
@@ -233,6 +236,8 @@ class TapedEpisode:
                                   imagine_masks=et.imagine_masks, sub_instr_segs=ep.sub_instr_segs,
                                   sub_instr_imag_flag=ep.sub_instr_imag_flag, noun_phrase_segs=ep.noun_phrase_segs)
         self.img = img
+        # the language stream of every `visual` call of the episode, incl. the first cross-modal layer's language Q / K / V: once, with autograd
+        self.ls = None if isinstance(self.txt, list) else model.language_side(self.txt, et.txt_masks, img, et.imagine_masks)
         self.cls = cls = model("history").expand(B, -1)                                        # [B, H]
         H, dt = cls.shape[-1], cls.dtype
         self.ar = torch.arange(T, device=dev)
@@ -282,7 +287,7 @@ class TapedEpisode:
             lg, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=self.txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm,
                 ob_img_feats=self._drop(f("ob_img_feats")[sl]), ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
-                ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=et.imagine_masks)
+                ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=et.imagine_masks, lang_side=self.ls)
         self.step_logits.append(lg)
         state = txt_o[:, 0] * hist_o[:, 0] if self.want_states else None                      # model_HAMT.py:86
         if not self.lag:
@@ -325,7 +330,8 @@ class TapedEpisode:
             logits, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=rep(self.txt), txt_masks=rep(et.txt_masks), hist_embeds=hist.reshape(T * B, T, H), hist_masks=hm_full,
                 ob_img_feats=self._drop(f("ob_img_feats")), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
-                ob_masks=f("ob_masks"), imagine_embeds=rep(self.img), imagine_masks=rep(et.imagine_masks))
+                ob_masks=f("ob_masks"), imagine_embeds=rep(self.img), imagine_masks=rep(et.imagine_masks),
+                lang_side=self.ls.repeat(T) if self.ls is not None else None)
         ml_loss = self.criterion(logits, f("target"))
         loss = ml_loss * self.train_ml / B
         if self.use_aux and torch.is_tensor(self.aux):

@@ -1284,6 +1284,96 @@ class _XAttPairBlock(torch.autograd.Function):
         return dl, dv, None, None, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
 
 
+class _QkvProj(torch.autograd.Function):
+    """qkv = x [Wq;Wk;Wv]^T + [bq;bk;bv] as its own node: the language stream that enters the FIRST cross-modal layer is the same at every step
+    of an episode (r2r/agent_cmt.py:498-606 passes the same txt_embeds / imagine_embeds), and LXRTXLayer.cross_att projects the PRE-update
+    inputs with shared weights (vilmodel_cmt.py:385-397) - so its Q / K / V are projected once per episode, autograd sums their gradient over
+    the steps, and dgrad / wgrad of that projection run once on B x Sl rows instead of T times (HAMT side)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv):
+        x2 = _rows(_chk(x, "x"))
+        dt = x.dtype
+        qkv = gemm_nt(x2, _w((wq, wk, wv), dt), bias=_w((bq, bk, bv), torch.float32))
+        ctx.save_for_backward(x2)
+        ctx.P, ctx.shp = (wq, bq, wk, bk, wv, bv), x.shape
+        return qkv
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        (x2,) = ctx.saved_tensors
+        wq, bq, wk, bk, wv, bv = ctx.P
+        ng = ctx.needs_input_grad
+        dqkv = dqkv.contiguous()
+        dwq = dwk = dwv = dbq = dbk = dbv = None
+        if any(ng[1:]):
+            (dwq, dwk, dwv), (dbq, dbk, dbv) = _wb_grad_to((wq, wk, wv), (bq, bk, bv), dqkv, x2)
+        dx = gemm_nt(dqkv, _w((wq, wk, wv), x2.dtype, True)).view(ctx.shp) if ng[0] else None
+        return dx, dwq, dbq, dwk, dbk, dwv, dbv
+
+
+class _XAttPairGivenQBlock(torch.autograd.Function):
+    """_XAttPairBlock with the language stream's packed Q / K / V handed in (ops.qkv_proj of the same `lang`): only the vision stream is
+    projected here. Gradients: d ql goes back to the projection node (summed over the episode's steps by autograd), d lang is the residual path
+    only, the packed weight's gradient gets the vision rows here and the language rows in _QkvProj."""
+
+    @staticmethod
+    def forward(ctx, lang, ql, visn, mask_l, mask_v, eps, drop, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
+        B, Sl, H = lang.shape
+        pa, ph, sd = drop
+        Sv = visn.shape[1]
+        l2, v2 = _rows(_chk(lang, "lang")), _rows(_chk(visn, "visn"))
+        dt = lang.dtype
+        assert ql.shape == (B * Sl, 3 * H) and ql.dtype == dt
+        wqkv, bqkv, wo_c = _w((wq, wk, wv), dt), _w((bq, bk, bv), torch.float32), _w((wo,), dt)
+        qv = gemm_nt(v2, wqkv, bias=bqkv)
+        (cl, lse_l), (cv, lse_v) = attn_fwd2((ql[:, :H], qv[:, :H]), (qv[:, H:2 * H], ql[:, H:2 * H]), (qv[:, 2 * H:], ql[:, 2 * H:]), B,
+                                             (Sl, Sv), (Sv, Sl), (mask_v, mask_l), drop=(pa, (sd, sd + 1)))
+        pre_l, pre_v = gemm_nt2((cl, cv), (wo_c, wo_c), bias=(bo, bo), residual=(l2, v2), drop=(ph, (sd + 2, sd + 3)))
+        (yl, mean_l, rstd_l), (yv, mean_v, rstd_v) = ln_fwd2((pre_l, pre_v), (g, g), (b, b), eps)
+        ctx.save_for_backward(v2, ql, qv, cl, cv, lse_l, lse_v, pre_l, pre_v, mean_l, rstd_l, mean_v, rstd_v, mask_l, mask_v)
+        ctx.P = (wq, bq, wk, bk, wv, bv, wo, bo, g, b)
+        ctx.dims, ctx.drop = (B, Sl, Sv, H), drop
+        return yl.view(B, Sl, H), yv.view(B, Sv, H)
+
+    @staticmethod
+    def backward(ctx, dyl, dyv):
+        (v2, ql, qv, cl, cv, lse_l, lse_v, pre_l, pre_v, mean_l, rstd_l, mean_v, rstd_v, mask_l, mask_v) = ctx.saved_tensors
+        wq, bq, wk, bk, wv, bv, wo, bo, g, b = ctx.P
+        B, Sl, Sv, H = ctx.dims
+        dt = v2.dtype
+        ng = ctx.needs_input_grad
+        pa, ph, sd = ctx.drop
+        wparams = any(ng[7:])
+        direct = wparams and _direct(wq, bq, wk, bk, wv, bv, wo, bo, g, b)
+        dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = dg = db = None
+        if direct or not wparams:
+            (dpl, _, _, dml), (dpv, _, _, dmv) = _ln_bwd_to2((_rows(dyl), _rows(dyv)), (pre_l, pre_v), (g, g), (b, b), (mean_l, mean_v),
+                                                             (rstd_l, rstd_v), (wparams, wparams), drop=(ph, (sd + 2, sd + 3)))
+        else:
+            dpl, dg, db, dml = ln_bwd(_rows(dyl), pre_l, g, mean_l, rstd_l, drop=(ph, sd + 2))
+            dpv, dg, db, dmv = ln_bwd(_rows(dyv), pre_v, g, mean_v, rstd_v, dg, db, drop=(ph, sd + 3))
+        if direct:
+            _wb_grad_to((wo,), (bo,), dml, cl); _wb_grad_to((wo,), (bo,), dmv, cv)
+        elif wparams:
+            dwo = wgrad(dmv, cv, wgrad(dml, cl))
+            dbo = colsum(dmv, colsum(dml))
+        wot = _w((wo,), dt, True)
+        dcl, dcv = gemm_nt2((dml, dmv), (wot, wot))
+        dql, dqv = torch.empty_like(ql), torch.empty_like(qv)
+        attn_bwd2((ql[:, :H], qv[:, :H]), (qv[:, H:2 * H], ql[:, H:2 * H]), (qv[:, 2 * H:], ql[:, 2 * H:]), (cl, cv), (dcl, dcv),
+                  (lse_l, lse_v), (dql[:, :H], dqv[:, :H]), (dqv[:, H:2 * H], dql[:, H:2 * H]), (dqv[:, 2 * H:], dql[:, 2 * H:]),
+                  B, (Sl, Sv), (Sv, Sl), (mask_v, mask_l), drop=(pa, (sd, sd + 1)))
+        if direct:
+            _wb_grad_to((wq, wk, wv), (bq, bk, bv), dqv, v2)
+        elif wparams:
+            dwq, dwk, dwv = _split_rows(wgrad(dqv, v2), (H, H, H))
+            dbq, dbk, dbv = _split_rows(colsum(dqv), (H, H, H))
+        dv = gemm_nt(dqv, _w((wq, wk, wv), dt, True), residual=dpv).view(B, Sv, H) if ng[2] else None
+        dl = dpl.view(B, Sl, H) if ng[0] else None
+        return dl, (dql if ng[1] else None), dv, None, None, None, None, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, dg, db
+
+
 class _DualSelfAttBlock(torch.autograd.Function):
     """Two independent BertAttention blocks (language and vision streams of an LXRT layer, vilmodel_cmt.py:399-407) whose
     projections run as dual-problem GEMM launches: y_i = LN_i(dense_i(attn(x_i Wq_i, x_i Wk_i, x_i Wv_i)) + x_i)."""
@@ -2116,6 +2206,15 @@ def dual_ffn_block(x0, x1, p0, p1, eps=1e-12, drop0=NO_DROP, drop1=NO_DROP):
 
 def xatt_pair_block(lang, visn, mask_l, mask_v, p, eps=1e-12, drop=NO_DROP):
     return _XAttPairBlock.apply(lang, visn, mask_l, mask_v, eps, drop, *p)
+
+
+def qkv_proj(x, p):
+    """Packed Q / K / V projection of one stream; p = (wq,bq,wk,bk,wv,bv,wo,bo,g,b) of the attention holder. [B*S, 3H]."""
+    return _QkvProj.apply(x, *p[:6])
+
+
+def xatt_pair_given_q_block(lang, lang_qkv, visn, mask_l, mask_v, p, eps=1e-12, drop=NO_DROP):
+    return _XAttPairGivenQBlock.apply(lang, lang_qkv, visn, mask_l, mask_v, eps, drop, *p)
 
 
 def xatt_block(x, c_in, mask_c, p, eps=1e-12, drop=NO_DROP):
