@@ -18,8 +18,8 @@ def load(d):
 
 
 def fam(name):
-    for k in ("gemm_p8h", "gemm_p8", "gemm_pk", "gemm_nt_big", "gemm_nt_glds", "gemm_nt_kernel", "gemm_nn_glds", "gemm_tn_ring", "gemm_tn_big", "gemm_tn_glds", "gemm_tn_bf16", "reduce_parts", "attn_bwd_bf16",
-              "attn_fwd_bf16", "ln_bwd", "ln_fwd", "adamw"):
+    for k in ("gemm_p8h", "gemm_p8", "gemm_pk", "gemm_nt_big", "gemm_nt_glds", "gemm_nt_kernel", "gemm_nn_glds", "gemm_tn_ring", "gemm_tn_big", "gemm_tn_glds", "gemm_tn_bf16", "reduce_parts", "attn_bwd",
+              "attn_fwd", "ln_bwd", "ln_fwd", "adamw"):
         if k in name:
             return k
     return None
