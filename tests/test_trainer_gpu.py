@@ -263,3 +263,41 @@ def test_float16_training_with_dynamic_loss_scaling_tracks_float32():
         assert d.mean().item() < 2e-5 and d.max().item() < 1e-3, (d.mean().item(), d.max().item())     # 3 steps at lr 1e-4
     finally:
         t16.close()
+
+
+def test_embedding_rows_no_token_touches_are_the_one_documented_deviation_from_torch_adamw():
+    """the fused step leaves an ELEMENT alone while its g, m and v are all exactly zero (that is how it tells a parameter torch would
+    skip for grad None - an unused head, embeddings behind a detach - from a live one, without a per-parameter flag). For the word-embedding table the
+    rule also catches the rows no token of any batch so far has touched: torch.optim.AdamW decays those too, by (1 - lr wd) per step. This test pins
+    the size of that deviation (exactly the missing decay, lr x wd x steps x |w| = 3e-5 |w| here; 1e-7 |w| per step at the reference's lr 1e-5) and
+    that touched rows follow torch."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_language")
+    et = EpisodeTensors(ep, "cuda")
+    ref, m = build_product(cfg), build_product(cfg)
+    w0 = m.embeddings.word_embeddings.weight.detach().clone()
+    wd, steps = 0.01, 3
+    opt = torch.optim.AdamW(ref.parameters(), lr=LR, weight_decay=wd)
+    tr = FlatTrainer(m, lr=LR)
+    try:
+        for _ in range(steps):
+            opt.zero_grad(set_to_none=True)
+            run_episode(ref, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+            torch.nn.utils.clip_grad_norm_([p for p in ref.parameters() if p.grad is not None], 40.0)
+            opt.step()
+            tr.zero_grad()
+            run_episode(m, et, criterion=ops.cross_entropy_sum)["loss"].backward()
+            tr.step()
+        used = torch.zeros(w0.shape[0], dtype=torch.bool, device="cuda")
+        used[et.txt_ids.reshape(-1)] = True
+        assert int((~used).sum()) > 1000 and int(used.sum()) > 10
+        wp, wt = m.embeddings.word_embeddings.weight.detach(), ref.embeddings.word_embeddings.weight.detach()
+        assert torch.equal(wp[~used], w0[~used])                                               # untouched rows: left alone here ...
+        decay = (1.0 - LR * wd) ** steps
+        assert torch.allclose(wt[~used], w0[~used] * decay, rtol=0, atol=1e-7)                 # ... decayed by torch: the whole deviation
+        dev = (wp[~used] - wt[~used]).abs().max().item()
+        assert dev <= 1.01 * (1.0 - decay) * w0[~used].abs().max().item()
+        assert (wp[used] - wt[used]).abs().max().item() < 4 * 2 * LR                            # touched rows: torch's update (Adam on rounding noise: a few lr)
+    finally:
+        tr.close()

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void seqmean_fwd_kernel(const T* __restrict__ 
                                                           int S, int H) {
   const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;      // grid (B, ceil(H / 256)): 3x the blocks of one-per-sample
   if (c >= H) return;
-  const int n = lens ? (int)lens[b] : S;
+  const int n = lens ? min(max((int)lens[b], 1), S) : S;             // clamped: see seqmean_bwd_kernel
   const T* xp = x + (long)b * S * H + c;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int s = 0;
@@ -210,7 +210,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void seqmean_bwd_kernel(const T* __restrict__ dout, T* __restrict__ dx, const long* __restrict__ lens, int B,
                                                           int S, int H) {
   const int b = blockIdx.x;
-  const int n = lens ? (int)lens[b] : S;
+  const int n = lens ? min(max((int)lens[b], 1), S) : S;             // a device-side length is not validated by the host: 0 would divide by zero, > S read past the rows
   const float inv = 1.0f / n;
   for (int c = threadIdx.x; c < H; c += 256) {
     const float g = DT<T>::ld(dout + (long)b * H + c) * inv;

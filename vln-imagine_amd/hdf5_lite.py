@@ -66,6 +66,8 @@ class Hdf5File:
 
     def _name(self, heap_data, off):
         e = self.buf.find(b"\0", heap_data + off)
+        if e < 0:
+            raise ValueError("hdf5_lite: a link name in the local heap has no terminator (truncated or corrupt file)")
         return self.buf[heap_data + off:e].decode()
 
     def _walk_group(self, addr, heap_data):

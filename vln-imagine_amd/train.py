@@ -194,8 +194,10 @@ class FlatTrainer:
                     self.params.append(p)
                     n += (p.numel() + 7) // 8 * 8     # slots aligned to 16 bytes in the 16-bit mirror too (32 B in float32)
                 self._units.append((u0, n - u0))
+            # which parameters the MODEL had trainable at construction: set_group(trainable=True) switches only those back on (a group declared
+            # trainable=False also lists parameters the model froze itself - fix_lang_embedding, update_lang_bert=False - and those stay frozen)
             self.groups.append({"name": g.get("name", f"group{gi}"), "params": plist, "listed": listed, "lr": float(g.get("lr", lr)),
-                                "trainable": on, "end": n})
+                                "trainable": on, "end": n, "model_trainable": {id(p) for p in plist if p.requires_grad}})
         self._off = offs
         self.n = n
         dev = self.params[0].device
@@ -245,6 +247,7 @@ class FlatTrainer:
         if _exchange():
             # leave a few CUs' worth of every one-round weight-gradient launch to the collective's own kernels: a launch sized for all 256
             # CUs gives RCCL no CU until one of its (100+ us) tiles retires. Costs the flush ~3 % where a launch is exactly one round.
+            self._reserve_before = ops.RESERVE_CUS
             ops.RESERVE_CUS = int(os.environ.get("VLNI_RESERVE_CUS", "8"))
         ops.SHADOWS.set_arena(self.flat_p, self.flat_b)
 
@@ -285,7 +288,7 @@ class FlatTrainer:
             g["trainable"] = bool(trainable)
             self.grp_lr[len(self.groups) + k] = 1.0 if trainable else 0.0
             for p in g["params"]:
-                p.requires_grad_(bool(trainable))
+                p.requires_grad_(bool(trainable) and id(p) in g["model_trainable"])
             ops.SHADOWS.invalidate()          # shadows of frozen parameters are cached as never-stale
             self.graph_epoch += 1             # the autograd graph changed: a captured step has to be captured again
 
@@ -449,6 +452,9 @@ class FlatTrainer:
         if ops.SHADOWS.arena is not None and ops.SHADOWS.arena[0] is self.flat_p:
             ops.SHADOWS.set_arena(None, None)
         ops.set_seed_base(None)
+        if hasattr(self, "_reserve_before"):   # the CU reservation for a gradient exchange was this trainer's: back to what it found
+            ops.RESERVE_CUS = self._reserve_before
+            del self._reserve_before
 
     def set_defer(self, on):
         """Deferred (grouped, one launch per parameter and episode) vs immediate weight-gradient GEMMs."""
