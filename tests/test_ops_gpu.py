@@ -856,3 +856,50 @@ def test_ring_weight_gradient_against_float64_at_bench_shapes(ops, dtype):
         # float32 accumulation of 49.5 k products of 16-bit inputs: no 16-bit rounding of the output at all
         _chk(gw, ref, 2e-5, ("dW", N, K))
         _chk(gb, refb, 2e-5, ("db", N, K))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_attention_resident_backward_tile_edges(ops, dtype, p_drop):
+    """The resident attention backward (<= 96 queries and keys: LDS-DMA staging, one 32 x 32 score tile per wave, independent output tiles)
+    at the edges of its tiling - exactly 32 / 64 / 96 rows, one row past a tile, a single query or key, 1 to 9 score tiles, blocks of 1 to 6
+    waves - with attention-probability dropout (the library's own mask, exported by vlni_dropout) and an additive bias, against float64."""
+    from vln_imagine_amd import _lib
+    H, nh, B = 768, 12, 2
+    t = TOL[dtype]
+    for (Sq, Sk, use_bias) in ((96, 96, False), (32, 32, True), (33, 31, False), (64, 65, True), (1, 96, False), (96, 1, False), (17, 49, True),
+                               (65, 33, False), (86, 43, False), (43, 86, True)):
+        qkv_q, qkv_k = _rand((B * Sq, 3 * H), dtype, 101, 0.7), _rand((B * Sk, 3 * H), dtype, 102, 0.7)
+        lens = torch.tensor([Sk, max(1, Sk - 3)])
+        kmask = ((torch.arange(Sk)[None, :] >= lens[:, None]).float() * -10000.0).cuda()
+        bias = _rand((B, Sq, Sk), torch.float32, 103, 0.5) if use_bias else None
+        q, k, v = qkv_q[:, :H], qkv_k[:, H:2 * H], qkv_k[:, 2 * H:]
+        seed = 4242
+        out, lse = ops.attn_fwd(q, k, v, B, Sq, Sk, kmask, bias, drop=(p_drop, seed))
+        qr, kr, vr = (x.double().clone().requires_grad_(True) for x in (q, k, v))
+        br = bias.double().clone().requires_grad_(True) if use_bias else None
+        qq, kk, vv = (x.view(B, -1, nh, 64).transpose(1, 2) for x in (qr, kr, vr))
+        s = qq @ kk.transpose(-1, -2) / 8.0 + kmask.double()[:, None, None, :]
+        if use_bias:
+            s = s + br[:, None]
+        pr = torch.softmax(s, -1)
+        if p_drop > 0:
+            m = torch.empty((B, nh, Sq, Sk), dtype=torch.float32, device="cuda")      # mask(seed, ((b nh + h) Sq + q) Sk + key)
+            _lib.call("vlni_dropout", 0, 0, m.data_ptr(), m.numel(), p_drop, seed, torch.cuda.current_stream().cuda_stream)
+            pr = pr * m.double()
+        ref = (pr @ vv).transpose(1, 2).reshape(B * Sq, H)
+        _chk(out, ref, t, ("fwd", Sq, Sk))
+        dout = _rand((B * Sq, H), dtype, 104)
+        ref.backward(dout.double())
+        dq_buf, dk_buf = torch.zeros_like(qkv_q), torch.zeros_like(qkv_k)
+        dbias = torch.zeros_like(bias) if use_bias else None
+        ops.attn_bwd(q, k, v, out, dout, lse, dq_buf[:, :H], dk_buf[:, H:2 * H], dk_buf[:, 2 * H:], B, Sq, Sk, kmask, bias, dbias, drop=(p_drop, seed))
+        # a single key: P = 1, so dS = P (dP - delta) is EXACTLY zero and dK with it; the kernels take delta = <dO, O> from the 16-bit O, so what they
+        # return for dK is the rounding of O summed over the queries - noise against a zero reference, not a fraction of it (same in the chunked kernel)
+        tk = t * 4 if Sk == 1 else t
+        _chk(dq_buf[:, :H], qr.grad, tk, ("dq", Sq, Sk))
+        _chk(dk_buf[:, H:2 * H], kr.grad, tk, ("dk", Sq, Sk))
+        _chk(dk_buf[:, 2 * H:], vr.grad, t, ("dv", Sq, Sk))
+        assert float(dq_buf[:, H:].abs().max()) == 0.0 and float(dk_buf[:, :H].abs().max()) == 0.0      # nothing outside the slices
+        if use_bias:
+            _chk(dbias, br.grad, t * 5, ("dbias", Sq, Sk))
