@@ -518,7 +518,8 @@ def main():
             e0.record()
             r = orig(a, b, *p, **k)
             e1.record()
-            rec.append((2.0 * a.shape[0] * _n_of(b) * a.shape[1], e0, e1, (a.shape[0], _n_of(b), a.shape[1])))
+            rec.append((2.0 * a.shape[0] * _n_of(b) * a.shape[1], e0, e1, (a.shape[0], _n_of(b), a.shape[1]),
+                        ("nn" if isinstance(b, (ops.WT, ops.KN)) else "nt") + f" act{k.get('act', 0)} dact{k.get('dact', 0)}"))
             epi[0] += _epi_bytes(k)
             return r
 
@@ -530,7 +531,8 @@ def main():
             r = orig2(a, b, *p, **k)
             e1.record()
             rows = a[0].shape[0] + a[1].shape[0]
-            rec.append((2.0 * rows * _n_of(b[0]) * a[0].shape[1], e0, e1, (rows, _n_of(b[0]), a[0].shape[1])))
+            rec.append((2.0 * rows * _n_of(b[0]) * a[0].shape[1], e0, e1, (rows, _n_of(b[0]), a[0].shape[1]),
+                        ("nn" if isinstance(b[0], (ops.WT, ops.KN)) else "nt") + f" act{k.get('act', 0)} dact{k.get('dact', 0)} dual {a[0].shape[0]}+{a[1].shape[0]}"))
             epi[0] += _epi_bytes(k)
             return r
 
@@ -559,11 +561,12 @@ def main():
         tot_ms = sum(max(r[1].elapsed_time(r[2]) - pair_ms, 1e-4) for r in rec)
         if os.environ.get("VLNI_GEMM_BREAKDOWN"):
             agg = {}
-            for f, e0, e1, shp in rec:
-                a_ = agg.setdefault(shp, [0, 0.0, 0.0])
-                a_[0] += 1; a_[1] += e0.elapsed_time(e1); a_[2] += f
-            for shp, (n, ms_, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
-                log(f"gemm M={shp[0]:6d} N={shp[1]:5d} K={shp[2]:5d}: {n:4d} calls {ms_:7.2f} ms {f / ms_ / 1e9:7.1f} TF/s")
+            for f, e0, e1, shp, kind in rec:
+                a_ = agg.setdefault((shp, kind), [0, 0.0, 0.0])
+                a_[0] += 1; a_[1] += max(e0.elapsed_time(e1) - pair_ms, 1e-4); a_[2] += f
+            for (shp, kind), (n, ms_, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ["VLNI_GEMM_BREAKDOWN"])]:
+                log(f"gemm M={shp[0]:6d} N={shp[1]:5d} K={shp[2]:5d} {kind:34s}: {n:4d} calls {ms_:7.3f} ms {ms_ / n * 1e3:7.1f} us each {f / ms_ / 1e9:7.1f} TF/s"
+                    f"  over 0.32 of peak: {ms_ - f / (0.32 * peak * 1e9):6.3f} ms")
         ach = tot_f / (tot_ms * 1e-3) / 1e12
         traffic, traffic_src = None, None
         try:      # HBM bytes per launch: separate rocprofv3 --pmc passes of this command (never collected inside a timed run)
@@ -599,7 +602,7 @@ def main():
             pass
         except Exception as e:                                  # never lets the reference measurement break the line
             log(f"large-GEMM ceiling not measured ({type(e).__name__}: {e})")
-        alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_) in rec)
+        alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_), _ in rec)
         def fam_sum(prefixes):
             sel = [f_ for f_ in fam if f_[0].startswith(prefixes)]
             t_ = sum(max(f_[2].elapsed_time(f_[3]) - pair_ms, 1e-4) for f_ in sel)

@@ -23,7 +23,7 @@ else:
     cfg = HamtConfig()
     model = NavCMT(cfg)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.fill_state_dict(param_shapes(cfg).items()).items()})
-    model = model.cuda().eval().set_compute_dtype(torch.bfloat16)
+    model = (model.cuda().train() if "--train" in sys.argv else model.cuda().eval()).set_compute_dtype(torch.bfloat16)
     et = EpisodeTensors(synth.HamtEpisode(tag="hp", B=8, L=80, V=37, I=6, T=6, ragged=False), "cuda")
 tr = FlatTrainer(model)
 TAPE = ops.EpisodeTape(6) if "--taped" in sys.argv else None      # --taped: the episode-tape drivers (what bench.py times)

@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 
 _MASK_IN_GRAPH = int(os.environ.get("VLNI_MASK_IN_GRAPH", "0"))       # tools/stale_mask_repro.py (round-3 anomaly hunt)
+_OVERLAP_HISTORY = os.environ.get("VLNI_OVERLAP_HISTORY", "1") != "0"  # A/B switch: the history encoder of step t on a side stream
 
 
 class EpisodeTensors:
@@ -204,7 +205,7 @@ class TapedEpisode:
         assert self.tape.T >= et.T
         self.bypass, self.use_aux, self.train_ml, self.cosine_weight, self.criterion = bypass, use_aux, train_ml, cosine_weight, criterion
         self.ghost_compute, self.lag, self.want_states = ghost_compute, lag_history, want_states
-        self.overlap = overlap_history and not lag_history
+        self.overlap = overlap_history and not lag_history and _OVERLAP_HISTORY
         self.step_logits = []
 
     def _drop(self, x):
