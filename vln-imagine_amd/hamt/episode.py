@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 
 _MASK_IN_GRAPH = int(os.environ.get("VLNI_MASK_IN_GRAPH", "0"))       # tools/stale_mask_repro.py (round-3 anomaly hunt)
+_EPISODE_MASKS = os.environ.get("VLNI_EPISODE_MASKS", "1") != "0"     # A/B switch: mask forms of all steps once per episode
 _OVERLAP_HISTORY = os.environ.get("VLNI_OVERLAP_HISTORY", "1") != "0"  # A/B switch: the history encoder of step t on a side stream
 
 
@@ -257,6 +258,12 @@ class TapedEpisode:
         for k in ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats", "ob_img_feats", "ob_ang_feats",
                   "ob_nav_types", "ob_masks", "target"):
             et.full(k)                                         # built (once) on the main stream before any side-stream reader
+        # teacher forcing knows the masks of all T steps here: their additive / boolean forms once per episode, not once per step
+        self.vm_full = self.nav0_full = self.validf = None
+        if not self.lag and dev.type == "cuda" and _EPISODE_MASKS:
+            self.vm_full = self._ops.additive_mask(torch.cat([self.hm_full, et.full("ob_masks")], 1))      # [T B, T + V]
+            self.nav0_full = et.full("ob_nav_types") == 0
+            self.validf = self.valid.to(dt)
         self.main = torch.cuda.current_stream() if dev.type == "cuda" else None
         self.side = None
         if self.overlap and self.main is not None:
@@ -288,7 +295,9 @@ class TapedEpisode:
             lg, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=self.txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm,
                 ob_img_feats=self._drop(f("ob_img_feats")[sl]), ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
-                ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=et.imagine_masks, lang_side=self.ls)
+                ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=et.imagine_masks, lang_side=self.ls,
+                vis_mask_add=self.vm_full[sl] if self.vm_full is not None else None,
+                ob_is_nav0=self.nav0_full[sl] if self.nav0_full is not None else None)
         self.step_logits.append(lg)
         state = txt_o[:, 0] * hist_o[:, 0] if self.want_states else None                      # model_HAMT.py:86
         if not self.lag:
@@ -298,7 +307,10 @@ class TapedEpisode:
                 h = self._history(t)
             if t + 1 < T:
                 with torch.no_grad():
-                    hb[t + 1:, :, t + 1] = h * self.valid[t + 1:, :, t + 1, None].to(h.dtype)
+                    if self.validf is not None and h.dtype == hb.dtype:
+                        torch.mul(h.unsqueeze(0), self.validf[t + 1:, :, t + 1, None], out=hb[t + 1:, :, t + 1])      # one launch
+                    else:
+                        hb[t + 1:, :, t + 1] = h * self.valid[t + 1:, :, t + 1, None].to(h.dtype)
         return lg, state
 
     def finish(self):
@@ -332,7 +344,8 @@ class TapedEpisode:
                 "visual", txt_embeds=rep(self.txt), txt_masks=rep(et.txt_masks), hist_embeds=hist.reshape(T * B, T, H), hist_masks=hm_full,
                 ob_img_feats=self._drop(f("ob_img_feats")), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
                 ob_masks=f("ob_masks"), imagine_embeds=rep(self.img), imagine_masks=rep(et.imagine_masks),
-                lang_side=self.ls.repeat(T) if self.ls is not None else None)
+                lang_side=self.ls.repeat(T) if self.ls is not None else None,
+                vis_mask_add=self.vm_full if not self.lag else None, ob_is_nav0=self.nav0_full if not self.lag else None)
         ml_loss = self.criterion(logits, f("target"))
         loss = ml_loss * self.train_ml / B
         if self.use_aux and torch.is_tensor(self.aux):

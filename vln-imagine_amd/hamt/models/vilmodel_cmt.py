@@ -598,7 +598,10 @@ class NavCMT(nn.Module):
                 ob_img_feats=None, ob_ang_feats=None, ob_nav_types=None, ob_masks=None, imagine_pano_img_feats=None,
                 imagine_masks=None, imagine_embeds=None, align_txt_embeds=None, align_imagine_embeds=None,
                 sub_instr_segs=None, sub_instr_imag_flag=None, noun_phrase_segs=None, obs_instr_ids=None,
-                return_cross_attention_probs=False, lang_side=None):
+                return_cross_attention_probs=False, lang_side=None, vis_mask_add=None, ob_is_nav0=None):
+        """`visual` extras of the episode drivers (all optional, values a plain call computes itself): lang_side = language_side(...);
+        vis_mask_add = additive_mask(cat([hist_masks, ob_masks], 1)) and ob_is_nav0 = (ob_nav_types == 0), which a driver that knows
+        the masks of all T steps builds once per episode instead of once per step."""
         c, dt = self.config, self.compute_dtype
         if mode == "language":
             B, L = txt_ids.shape
@@ -658,7 +661,10 @@ class NavCMT(nn.Module):
         nh, no = hist.shape[1], ob.shape[1]
         txt_list = txt_embeds if isinstance(txt_embeds, list) else None
         visn = torch.cat([hist, ob], 1)
-        vm = ops.additive_mask(torch.cat([hist_masks, ob_masks], 1))              # one conversion for the concatenated stream (:1059-1061)
+        if vis_mask_add is not None:
+            vm = vis_mask_add
+        else:
+            vm = ops.additive_mask(torch.cat([hist_masks, ob_masks], 1))          # one conversion for the concatenated stream (:1059-1061)
         img_side = c.concat_imagine_with if c.imagine_enc_pano else None
         if c.imagine_enc_pano:
             assert imagine_embeds is not None
@@ -708,7 +714,7 @@ class NavCMT(nn.Module):
             f = ob_o * (txt_o[:, :1] + img_o.float().mean(1, keepdim=True).to(dt))
         else:
             raise ValueError(f"act_pred_token {tok!r}")
-        act_logits = self.next_action(f.contiguous(), ob_nav_types == 0)
+        act_logits = self.next_action(f.contiguous(), ob_is_nav0 if ob_is_nav0 is not None else ob_nav_types == 0)
         if return_cross_attention_probs:
             return act_logits, txt_o, hist_o, ob_o, cross_probs, self_probs
         return act_logits, txt_o, hist_o, ob_o
