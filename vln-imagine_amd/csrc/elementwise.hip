@@ -52,6 +52,35 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const TrEntry* _
   const int r0 = (t / e.tiles_c) * 64, c0 = (t % e.tiles_c) * 64;
   const S* src = (const S*)e.src;
   S* dst = (S*)e.dst;
+  if constexpr (sizeof(S) == 2) {
+    // full 16-bit tiles with 16-byte aligned rows: 16-byte global accesses on both sides (the scalar path moves 2 bytes per lane: 2.2 TB/s
+    // over all weight shadows of a step), 2-byte LDS accesses in between (row pitch 66 elements = 33 words: the 8 rows a lane gathers and
+    // the 8 columns of a wave fall in different banks)
+    const bool vec = r0 + 64 <= e.R && r0 + 64 <= e.Rpad && c0 + 64 <= e.C && (e.lds & 7) == 0 && (e.ldd & 7) == 0
+                     && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0;
+    if (vec) {
+      typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+      unsigned short (*t16)[66] = (unsigned short (*)[66])tile;
+      const int q = threadIdx.x & 7, rr = threadIdx.x >> 3;            // 8 lanes per 128-byte row piece, 32 rows per pass
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = rr + h * 32;
+        const u16x8 v = *(const u16x8*)((const unsigned short*)src + (long)(r0 + r) * e.lds + c0 + q * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t16[r][q * 8 + j] = v[j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = rr + h * 32;
+        u16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = t16[q * 8 + j][c];
+        *(u16x8*)((unsigned short*)dst + (long)(c0 + c) * e.ldd + r0 + q * 8) = v;
+      }
+      return;
+    }
+  }
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int r = r0 + i, c = c0 + tx;
