@@ -70,7 +70,10 @@ def test_fp32_full_depth_fwd_bwd_matches_cpu_oracle(family, B):
 # softmax shift invariance), duet bf16 3.3e-5 / 0.0196 / 0.0831 / 0.134; rounds 2 - 3: 2.3e-4 / 0.033 / 0.089 / 0.147 and 0.9 - 2.4e-4 / 0.0155 - 0.0195 / 0.083 - 0.085 / 0.127 - 0.134
 BF16_BOUNDS = {"hamt": (5e-4, 0.043, 0.116, 0.24), "duet": (5e-4, 0.026, 0.11, 0.175)}
 # float16 with the trainer's loss scale S = 2^14, round 4: 5.9e-5 / 0.0041 / 0.0281 / 0.050 and 4.5e-5 / 0.0025 / 0.0271 / 0.041 (round 3: 2.7e-5 / 0.0044 / 0.027 / 0.052; 4.6e-5 / 0.0025 / 0.027 / 0.046)
-F16_BOUNDS = {"hamt": (1.2e-4, 0.0057, 0.037, 0.068), "duet": (1e-4, 0.0033, 0.036, 0.06)}
+# HAMT's worst single parameter after the attention forward moved to base-2 exponentials: 8.0e-5 / 0.0035 / 0.0278 / 0.0753, now on
+# encoder.x_layers.1.lang_self_att.self.query.weight (the same shift-invariant projection whose KEY weight is bfloat16's worst at 0.18); with the
+# previous forward kernel in the same build: 0.0289 / 0.048 on next_action.net.0.bias - every other figure moved by < 4 %, the whole gradient improved
+F16_BOUNDS = {"hamt": (1.2e-4, 0.0057, 0.037, 0.098), "duet": (1e-4, 0.0033, 0.036, 0.06)}
 
 
 @pytest.mark.parametrize("family,B,low", [("hamt", 64, torch.bfloat16), ("duet", 32, torch.bfloat16), ("hamt", 64, torch.float16),
