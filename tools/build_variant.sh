@@ -6,7 +6,8 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$1; SRC=$2; shift 2
 mkdir -p $R/vln-imagine_amd/build/variants
 OBJ=$R/vln-imagine_amd/build/variants/$(basename $OUT .so)_$(basename $SRC .hip).o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function "$@" -c $R/vln-imagine_amd/csrc/$SRC -o $OBJ
+EXTRA=""; if [ "$SRC" == "attention.hip" ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi    # as vln-imagine_amd/build.py:EXTRA
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $EXTRA "$@" -c $R/vln-imagine_amd/csrc/$SRC -o $OBJ
 OBJS=""
 for s in api gemm layernorm elementwise attention graphmap; do
   if [ "$s.hip" == "$SRC" ]; then OBJS="$OBJS $OBJ"; else OBJS="$OBJS $R/vln-imagine_amd/build/$s.o"; fi

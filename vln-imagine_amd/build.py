@@ -11,6 +11,9 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvlni.so")
 SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "attention.hip", "graphmap.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# per-source flags. attention.hip: MFMA results in VGPRs - with the accumulators in AGPRs every softmax operation on a score tile is an
+# accvgpr read + write around it (448 of the forward kernel's 1872 VALU instructions, 144 registers instead of 113: -16 % per launch)
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 if os.environ.get("VLNI_DIAG") == "1":       # stamped / timing-only kernel builds + vlni_debug_pk_stamps (tools/gemm_stamps.py); never the default
     FLAGS.append("-DVLNI_DIAG")
 
@@ -31,12 +34,12 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src] + hdrs):
+        if force or _stale(obj, [src] + hdrs + [os.path.abspath(__file__)]):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
