@@ -64,7 +64,9 @@ def run(nn, N, K, kind):
     res = (rnd(M0, N), rnd(M1, N))
     z = (rnd(M0, N, s=1.0), rnd(M1, N, s=1.0))
     kw = {"plain": dict(bias=bias), "res": dict(bias=bias, residual=res), "gelu": dict(bias=bias, act=1, preact=z),
-          "dact": dict(dact_src=z, dact=1), "dres": dict(residual=res)}[kind]
+          "dact": dict(dact_src=z, dact=1), "dres": dict(residual=res),
+          # the kinds a 16-bit training step launches (round 4): GELU + stored GELU', multiply by the stored derivative, residual + dropout
+          "gelu3": dict(bias=bias, act=3, preact=z), "dact3": dict(dact_src=z, dact=3), "resdrop": dict(bias=bias, residual=res, drop=(0.1, (11, 12)))}[kind]
     variants = NN_VARIANTS if nn else NT_VARIANTS
     best = {v: 1e9 for v in variants}
     saved = (ops.GEMM_VARIANTS, ops.NN_VARIANTS)
@@ -94,7 +96,7 @@ def run(nn, N, K, kind):
     wm = w[0] if nn else w[0].t()
     us_lib = time_call(lambda: torch.matmul(acat, wm))
     tag = "NN" if nn else "NT"
-    print(f"{tag} rows {M0}+{M1} N={N:4d} K={K:4d} {kind:5s} " + " ".join(f"v{v}:{best[v]:6.1f}us/{fl / best[v] / 1e6:4.0f}TF" for v in variants)
+    print(f"{tag} rows {M0}+{M1} N={N:4d} K={K:4d} {kind:7s} " + " ".join(f"v{v}:{best[v]:6.1f}us/{fl / best[v] / 1e6:4.0f}TF" for v in variants)
           + extra + f" | hipblaslt(plain) {us_lib:6.1f}us/{fl / us_lib / 1e6:4.0f}TF", flush=True)
     return fl, min(best.values()), {v: best[v] for v in variants}
 
@@ -108,8 +110,10 @@ def main():
         for kind in ("plain", "dact", "dres"):
             run(True, N, K, kind)
         return
-    for nn, N, K, kind, count in ((False, 2304, 768, "plain", 2), (False, 768, 768, "res", 2), (False, 3072, 768, "gelu", 1), (False, 768, 3072, "res", 1),
-                                  (True, 3072, 768, "dact", 1), (True, 768, 3072, "dres", 1), (True, 768, 2304, "dres", 2), (True, 768, 768, "plain", 2)):
+    K3 = os.environ.get("STEP_KINDS", "0") == "1"             # the epilogue kinds of the 16-bit train-mode step instead of the round-3 ones
+    for nn, N, K, kind, count in ((False, 2304, 768, "plain", 2), (False, 768, 768, "resdrop" if K3 else "res", 2), (False, 3072, 768, "gelu3" if K3 else "gelu", 1),
+                                  (False, 768, 3072, "resdrop" if K3 else "res", 1),
+                                  (True, 3072, 768, "dact3" if K3 else "dact", 1), (True, 768, 3072, "dres", 1), (True, 768, 2304, "dres", 2), (True, 768, 768, "plain", 2)):
         fl, us, per = run(nn, N, K, kind)
         for v, t in per.items():
             key = ("NN" if nn else "NT", v)
