@@ -73,7 +73,10 @@ BF16_BOUNDS = {"hamt": (5e-4, 0.043, 0.116, 0.24), "duet": (5e-4, 0.026, 0.11, 0
 # HAMT's worst single parameter after the attention forward moved to base-2 exponentials: 8.0e-5 / 0.0035 / 0.0278 / 0.0753, now on
 # encoder.x_layers.1.lang_self_att.self.query.weight (the same shift-invariant projection whose KEY weight is bfloat16's worst at 0.18); with the
 # previous forward kernel in the same build: 0.0289 / 0.048 on next_action.net.0.bias - every other figure moved by < 4 %, the whole gradient improved
-F16_BOUNDS = {"hamt": (1.2e-4, 0.0057, 0.037, 0.098), "duet": (1e-4, 0.0033, 0.036, 0.06)}
+# DUET's worst single parameter after the GEMM kernels became one instantiation per epilogue kind (other fused-multiply-add contractions, other autotune
+# winners): 5.3e-5 / 0.0020 / 0.0298 / 0.0703 on global_encoder.sprel_linear.weight - ONE number, the sum of every attention-bias gradient of the
+# episode (it was 0.041 - 0.046 on other parameters; whole-gradient error unchanged)
+F16_BOUNDS = {"hamt": (1.2e-4, 0.0057, 0.037, 0.098), "duet": (1e-4, 0.0033, 0.039, 0.092)}
 
 
 @pytest.mark.parametrize("family,B,low", [("hamt", 64, torch.bfloat16), ("duet", 32, torch.bfloat16), ("hamt", 64, torch.float16),
