@@ -903,3 +903,40 @@ def test_attention_resident_backward_tile_edges(ops, dtype, p_drop):
         assert float(dq_buf[:, H:].abs().max()) == 0.0 and float(dk_buf[:, :H].abs().max()) == 0.0      # nothing outside the slices
         if use_bias:
             _chk(dbias, br.grad, t * 5, ("dbias", Sq, Sk))
+
+
+@pytest.mark.parametrize("variant", [5, 11, 14, 15, 32])
+def test_dual_launch_with_mixed_epilogue_operands_takes_the_generic_kernel(ops, variant):
+    """The persistent / large-tile kernels are instantiated per epilogue KIND and the launcher picks one for BOTH problems of a dual launch
+    (epi_kind): problems that differ in what they carry - a residual or a bias on one stream only - must fall to the generic instantiation
+    and still be right; so must dropout without a residual (no kind of its own)."""
+    dtype, t = torch.bfloat16, TOL[torch.bfloat16]
+    M0, M1, N, K = 1300, 1100, 768, 768
+    a = (_rand((M0, K), dtype, 81, 0.5), _rand((M1, K), dtype, 82, 0.5))
+    b = (_rand((N, K), dtype, 83, 0.05), _rand((N, K), dtype, 84, 0.05))
+    bias = (_rand((N,), torch.float32, 85, 0.1), _rand((N,), torch.float32, 86, 0.1))
+    res = (_rand((M0, N), dtype, 87, 0.5), _rand((M1, N), dtype, 88, 0.5))
+    lin = [x.double() @ w.double().t() for x, w in zip(a, b)]
+    cases = {"residual on problem 0 only": (dict(bias=bias, residual=(res[0], None)), [lin[0] + bias[0].double() + res[0].double(), lin[1] + bias[1].double()]),
+             "residual on problem 1 only": (dict(bias=bias, residual=(None, res[1])), [lin[0] + bias[0].double(), lin[1] + bias[1].double() + res[1].double()]),
+             "bias on problem 1 only": (dict(bias=(None, bias[1]), residual=res), [lin[0] + res[0].double(), lin[1] + bias[1].double() + res[1].double()])}
+    saved = (ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS)
+    try:
+        ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS = True, (variant,), 1 << 30, 1 << 30
+        for what, (kw, refs) in cases.items():
+            ops._GEMM_BEST.clear()
+            outs = ops.gemm_nt2(a, b, **kw)
+            for i in range(2):
+                _chk(outs[i], refs[i], t, (variant, what, i))
+        # dropout without a residual: every kept element is the plain result / (1 - p), the rest exactly zero, about p of them
+        ops._GEMM_BEST.clear()
+        outs = ops.gemm_nt2(a, b, bias=bias, drop=(0.25, (7, 8)))
+        for i in range(2):
+            ref = (lin[i] + bias[i].double()) / 0.75
+            o = outs[i].double()
+            kept = o != 0
+            assert 0.70 < kept.double().mean().item() < 0.80, (variant, i, kept.double().mean().item())
+            assert ((o - ref).abs()[kept]).max().item() < t * max(1.0, ref.abs().max().item()), (variant, i)
+    finally:
+        ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS = saved
+        ops._GEMM_BEST.clear()
