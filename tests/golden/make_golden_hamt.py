@@ -100,7 +100,8 @@ def run_variant(name, over, epkw, *_):
     g["loss"] = out["loss"].detach().numpy()
     g["ml_loss"] = out["ml_loss"].detach().numpy()
     g["aux"] = out["aux"].detach().numpy() if torch.is_tensor(out["aux"]) else np.float32(out["aux"] or 0.0)
-    g["imagine_embeds"] = out["imagine_embeds"].detach().numpy()
+    if out["imagine_embeds"] is not None:             # None for imagine_enc_pano=False
+        g["imagine_embeds"] = out["imagine_embeds"].detach().numpy()
     g["hist_cls"] = out["hist_cls"].detach().numpy()
     txt_list = out["txt_embeds"] if isinstance(out["txt_embeds"], list) else [out["txt_embeds"]]     # no_lang_ca: one per layer + the input
     for i, te in enumerate(txt_list):

@@ -27,6 +27,13 @@ HAMT_VARIANTS = {
     # (episode tag: with the default one an action-head ReLU input of a scored row is 8.8e-7 - product and reference land on opposite sides of
     # the kink in float32 and every gradient moves by 7 %; make_golden_hamt.py now asserts a margin)
     "c1_no_lang_ca": (dict(no_lang_ca=True, concat_imagine_with="visual"), dict(tag="golden_nlca"), dict(use_aux=False)),
+    # round 5: the remaining hot-path flags with product code and no golden (missing 4)
+    # the paper's no-imagination baseline: no imagine / alignment modules, `visual` without imagination tokens (vilmodel_cmt.py:975-996,1099-1116,1173)
+    "c1_no_imagine": (dict(imagine_enc_pano=False), dict(), dict(use_aux=False, use_imagine=False)),
+    # history tokens without the panorama encoder (:564-566,603-614)
+    "c1_no_hist_pano": (dict(hist_enc_pano=False), dict()),
+    # 2048-d view features (ResNet-152 stores: run_r2r.bash features=...; :524,551,566,648): K = 2048 projections, imagination features stay 768-d
+    "c1_feat2048": (dict(image_feat_size=2048), dict(feat=2048, imag_feat=768)),
 }
 HAMT_C1 = dict(num_l_layers=2, num_x_layers=2, num_h_pano_layers=2)
 HAMT_EP = dict(tag="golden", B=4, L=80, V=37, I=4, T=2, ragged=True)

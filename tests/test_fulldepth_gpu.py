@@ -82,10 +82,16 @@ F16_BOUNDS = {"hamt": (1.2e-4, 0.0057, 0.037, 0.098), "duet": (1e-4, 0.0033, 0.0
 @pytest.mark.parametrize("family,B,low", [("hamt", 64, torch.bfloat16), ("duet", 32, torch.bfloat16), ("hamt", 64, torch.float16),
                                           ("duet", 32, torch.float16)])
 def test_bf16_timed_path_tracks_fp32_at_bench_shapes(family, B, low):
-    """fwd + bwd, the bench's batch and depth, kernels chosen by the autotune exactly as in bench.py (FlatTrainer: direct gradient
-    accumulation + deferred grouped weight gradients, the ring / partial-slab kernels)."""
+    """fwd + bwd, the bench's batch and depth, THE PROGRAM bench.py TIMES: the taped episode (step-by-step forward, one episode-batched
+    backward) captured by FlatTrainer.capture and REPLAYED, kernels chosen by the autotune during the warm-up steps (direct gradient
+    accumulation + deferred grouped weight gradients, the ring / partial-slab kernels) - against the float32 step-by-step run, which the
+    reference's goldens pin directly (tests/test_hamt_gpu.py, tests/test_duet_gpu.py). lr = 0: the replayed optimizer step leaves the weights."""
     from vln_imagine_amd import ops
     from vln_imagine_amd.train import FlatTrainer
+    if family == "hamt":
+        from vln_imagine_amd.hamt.episode import run_episode_taped as run_taped
+    else:
+        from vln_imagine_amd.duet.episode import run_episode_taped as run_taped
     assert ops.AUTOTUNE
     cfg, ep, ET, run, key = (_hamt if family == "hamt" else _duet)(B, 2, "full16")
     et = ET(ep, "cuda")
@@ -96,23 +102,34 @@ def test_bf16_timed_path_tracks_fp32_at_bench_shapes(family, B, low):
     # float16 needs the loss scale (activation gradients of the deep layers are below its 6e-5 normal range): the backward runs on
     # S * loss, exactly as a training step does, and the arena is divided by S before the comparison
     S = 16384.0 if low == torch.float16 else 1.0
-    tr = FlatTrainer(m16, loss_scale=S)
+    tr = FlatTrainer(m16, lr=0.0, weight_decay=0.0, loss_scale=S)
     try:
         before = set(ops._GEMM_BEST.values())
-        for _ in range(2):                       # second pass: every launch runs its cached autotune winner
-            tr.zero_grad()
-            o16 = run(m16, et, criterion=ops.cross_entropy_sum)
-            (o16["loss"] * tr.loss_scale).backward()
-            tr.flush()
+        tape, stash = ops.EpisodeTape(ep.T), {}
+
+        def fwd_bwd():
+            o = run_taped(m16, et, tape=tape, criterion=ops.cross_entropy_sum)
+            (o["loss"] * tr.loss_scale).backward()
+            stash["out"] = o
+            return o["loss"]
+
+        step = tr.capture(fwd_bwd, warmup=2)     # second warm-up step: every launch runs its cached autotune winner, as the capture does
+        step()
+        torch.cuda.synchronize()
+        o16 = stash["out"]
         tr.flat_g.mul_(1.0 / S)
+        if family == "duet":                     # maps padded to the episode's largest: the step's own columns (the rest is -inf)
+            o16 = dict(o16, fused=[a[:, :b.shape[1]] for a, b in zip(o16["fused"], o32["fused"])])
         r = compare_runs(o16, o32, dict(m16.named_parameters()), dict(m32.named_parameters()), key)
         picked = sorted(set(ops._GEMM_BEST.values()) | before)
-        print(f"\n[{family} {str(low)[6:]} vs fp32 HIP, full depth, B={B}] {r}\n  GEMM variants the autotune picked: {picked}; wgrad choices: {sorted(set(ops._TN_BEST.values()))}")
+        print(f"\n[{family} {str(low)[6:]} taped + graph replay vs fp32 stepwise, full depth, B={B}] {r}\n  GEMM variants the autotune picked: {picked}; wgrad choices: {sorted(set(ops._TN_BEST.values()))}")
         la, lg, gr, gw = (BF16_BOUNDS if low == torch.bfloat16 else F16_BOUNDS)[family]
         assert r["loss_abs"] <= la and r["logit_max_abs"] <= lg and r["grad_rel_l2"] <= gr and r["grad_worst_param_rel_l2"] <= gw, r
         assert 32 in picked or family == "duet", picked        # the 256 x 128 loader-wave kernel ran (the step's 8 k-row launches)
     finally:
         tr.close()
+        ops.set_seed_base(None)
+        ops._WQ.clear()
 
 
 @pytest.mark.parametrize("family", ["duet", "hamt"])

@@ -32,30 +32,7 @@ def _close(a, b, tol, what):
     return err
 
 
-@pytest.mark.parametrize("name", list(HAMT_VARIANTS))
-def test_product_fp32_matches_reference_golden(name, golden_dir):
-    from vln_imagine_amd import ops
-    g = np.load(os.path.join(golden_dir, f"hamt_{name}.npz"))
-    cfg, ep = hamt_variant_setup(name)
-    model = build_product(cfg)
-    out = run_episode(model, EpisodeTensors(ep, "cuda"), bypass=cfg.bypass_imag_encoder, criterion=ops.cross_entropy_sum,
-                      **hamt_variant_run_kw(name))
-    out["loss"].backward()
-    c = lambda t: t.detach().float().cpu().numpy()
-    _close(out["loss"].item(), g["loss"], TOL, "loss")
-    _close(out["aux"].item() if torch.is_tensor(out["aux"]) else 0.0, g["aux"], TOL, "aux")
-    txt_list = out["txt_embeds"] if isinstance(out["txt_embeds"], list) else [out["txt_embeds"]]
-    for i, te in enumerate(txt_list):              # no_lang_ca: the per-layer text states of the `language` call (vilmodel_cmt.py:1022-1029)
-        key = "txt_embeds.samples" if i == 0 else f"txt_embeds{i}.samples"
-        _close(synth.probe(c(te))["samples"], g[key], TOL, key)
-    _close(c(out["imagine_embeds"]), g["imagine_embeds"], TOL, "imagine_embeds")
-    _close(c(out["hist_cls"]), g["hist_cls"], TOL, "hist_cls")
-    for t in range(ep.T):
-        _close(c(out["logits"][t]), g[f"logits{t}"], TOL, f"logits{t}")
-        _close(c(out["states"][t]), g[f"state{t}"], TOL, f"state{t}")
-        _close(c(out["hist"][t]), g[f"hist{t}"], TOL, f"hist{t}")
-        for nm in ("txt_o", "ob_o", "hist_o"):
-            _close(synth.probe(c(out[nm][t]))["samples"], g[f"{nm}{t}.samples"], TOL, f"{nm}{t}")
+def _check_grads_against_golden(model, g):
     params = dict(model.named_parameters())
     for i, n in enumerate(g["grad_names"].tolist()):
         gr = params[n].grad
@@ -68,6 +45,98 @@ def test_product_fp32_matches_reference_golden(name, golden_dir):
         assert abs(nrm - ref_norm) <= max(2e-4 * ref_norm, 2e-5), (n, nrm, ref_norm)   # 2e-5 abs: scalar grads that sum thousands of cancelling terms
         head = gr.reshape(-1)[:8].cpu().numpy()
         _close(head, g["grad_heads"][i][:head.size], 2e-4, f"grad {n}")
+
+
+# The drivers of an episode, each held to the reference's fixtures DIRECTLY (the timed drivers were only compared with the
+# stepwise HIP run). stepwise = the reference agent's own call pattern (T calls, one backward: r2r/agent_cmt.py:806-832); taped = step-by-step
+# forward into episode-wide buffers + ONE episode-batched backward (what bench.py times); time_batched = forward batched over time as well;
+# graph = the taped step captured by FlatTrainer.capture and REPLAYED (the program bench.py times, at lr = 0 so the weights stay put).
+DRIVERS = ("stepwise", "taped", "time_batched", "graph")
+# no_lang_ca hands a LIST of per-layer text states to `visual` (vilmodel_cmt.py:1022-1030): the batched drivers repeat one tensor over time
+_BATCHED_UNSUPPORTED = {"c1_no_lang_ca"}
+
+
+def run_driver(driver, model, et, cfg, name):
+    """-> (result dict with loss / aux / logits / hist [/ states], trainer or None). The caller runs nothing else: backward is done."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.hamt.episode import run_episode_taped, run_episode_time_batched
+    kw = dict(bypass=cfg.bypass_imag_encoder, criterion=ops.cross_entropy_sum, **hamt_variant_run_kw(name))
+    if driver == "stepwise":
+        out = run_episode(model, et, **kw)
+        out["loss"].backward()
+        return out, None
+    if driver == "time_batched":
+        out = run_episode_time_batched(model, et, **kw)
+        out["loss"].backward()
+        return out, None
+    states = []
+    on_step = lambda t, lg, st: states.append(st.clone())
+    if driver == "taped":
+        out = run_episode_taped(model, et, on_step=on_step, **kw)
+        out["loss"].backward()
+        out["states"] = states
+        return out, None
+    from vln_imagine_amd.train import FlatTrainer
+    tr = FlatTrainer(model, lr=0.0, weight_decay=0.0)
+    tape, stash = ops.EpisodeTape(et.T), {}
+
+    def fwd_bwd():
+        states.clear()
+        o = run_episode_taped(model, et, tape=tape, on_step=on_step, **kw)
+        o["loss"].backward()
+        stash["out"] = o
+        return o["loss"]
+
+    step = tr.capture(fwd_bwd, warmup=1)
+    step()                                            # a REPLAY of the captured step: its outputs and gradients are what is checked
+    torch.cuda.synchronize()
+    out = stash["out"]
+    out["states"] = list(states)
+    return out, tr
+
+
+@pytest.mark.parametrize("driver", DRIVERS)
+@pytest.mark.parametrize("name", list(HAMT_VARIANTS))
+def test_product_fp32_matches_reference_golden(name, driver, golden_dir):
+    from vln_imagine_amd import ops
+    if driver != "stepwise" and name in _BATCHED_UNSUPPORTED:
+        pytest.skip("no_lang_ca: `language` returns per-layer text states, which only the step-by-step driver feeds")
+    g = np.load(os.path.join(golden_dir, f"hamt_{name}.npz"))
+    cfg, ep = hamt_variant_setup(name)
+    model = build_product(cfg)
+    tr = None
+    try:
+        out, tr = run_driver(driver, model, EpisodeTensors(ep, "cuda"), cfg, name)
+        c = lambda t: t.detach().float().cpu().numpy()
+        _close(out["loss"].item(), g["loss"], TOL, "loss")
+        _close(out["aux"].item() if torch.is_tensor(out["aux"]) else 0.0, g["aux"], TOL, "aux")
+        txt_list = out["txt_embeds"] if isinstance(out["txt_embeds"], list) else [out["txt_embeds"]]
+        for i, te in enumerate(txt_list):              # no_lang_ca: the per-layer text states of the `language` call (vilmodel_cmt.py:1022-1029)
+            key = "txt_embeds.samples" if i == 0 else f"txt_embeds{i}.samples"
+            _close(synth.probe(c(te))["samples"], g[key], TOL, key)
+        if "imagine_embeds" in g.files:                # absent for imagine_enc_pano=False
+            _close(c(out["imagine_embeds"]), g["imagine_embeds"], TOL, "imagine_embeds")
+        else:
+            assert out["imagine_embeds"] is None
+        if "hist_cls" in out:
+            _close(c(out["hist_cls"]), g["hist_cls"], TOL, "hist_cls")
+        for t in range(ep.T):
+            _close(c(out["logits"][t]), g[f"logits{t}"], TOL, f"logits{t}")
+            _close(c(out["hist"][t]), g[f"hist{t}"], TOL, f"hist{t}")
+            if "states" in out:
+                _close(c(out["states"][t]), g[f"state{t}"], TOL, f"state{t}")
+            for nm in ("txt_o", "ob_o", "hist_o"):
+                if nm in out:
+                    _close(synth.probe(c(out[nm][t]))["samples"], g[f"{nm}{t}.samples"], TOL, f"{nm}{t}")
+        if driver in ("taped", "graph"):               # what the agent read during the rollout are the batched tensor's rows
+            for t in range(ep.T):
+                _close(c(out["step_logits"][t]), g[f"logits{t}"], TOL, f"step_logits{t}")
+        _check_grads_against_golden(model, g)
+    finally:
+        if tr is not None:
+            tr.close()
+        ops.set_seed_base(None)
+        ops._WQ.clear()
 
 
 def test_product_fp32_matches_oracle_config2_shape():
@@ -369,3 +438,63 @@ def test_attention_probabilities_for_visualisation(dtype, golden_dir):
             assert list(p.shape) == g[f"{name}{l}.shape"].tolist() and p.dtype == torch.float32
             assert (p.sum(-1) - 1).abs().max().item() < 1e-5
             assert np.abs(sample(p) - g[f"{name}{l}.sample"]).max() <= tol, (name, l)
+
+
+def test_language_side_cache_follows_the_projection_weights():
+    """The per-episode language-side cache also holds x-layer 0's language Q / K / V, which depend on PARAMETERS. A caller
+    that keeps the same frozen / detached text tensors over two training steps (fix_lang_embedding, update_lang_bert=False) must get the
+    projections of the CURRENT weights, and the second backward must not walk a consumed graph - both for an in-place parameter update that
+    moves version counters and for the fused AdamW step, which rewrites the arena through raw pointers."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    cfg, ep = hamt_variant_setup("c1_shipped")
+    et = EpisodeTensors(ep, "cuda")
+    s0 = et.steps[0]
+
+    def visual(model, txt, img):
+        hist = model("history").expand(et.B, -1).unsqueeze(1)
+        return model("visual", txt_embeds=txt, txt_masks=et.txt_masks, hist_embeds=hist, hist_masks=et.hist_masks[0],
+                     ob_img_feats=s0["ob_img_feats"], ob_ang_feats=s0["ob_ang_feats"], ob_nav_types=s0["ob_nav_types"],
+                     ob_masks=s0["ob_masks"], imagine_embeds=img, imagine_masks=et.imagine_masks)[0]
+
+    def fresh_logits(model, txt, img):
+        ref = build_product(cfg)
+        ref.load_state_dict(model.state_dict())
+        with torch.no_grad():
+            return visual(ref, txt, img)
+
+    def loss_of(lg):
+        return lg[torch.isfinite(lg)].sum()
+
+    m = build_product(cfg)
+    with torch.no_grad():
+        txt = m("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
+        img = m("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None)
+    # (1) version counters move
+    loss_of(visual(m, txt, img)).backward()
+    with torch.no_grad():
+        m.encoder.x_layers[0].visual_attention.att.key.weight.mul_(1.5)
+    lg = visual(m, txt, img)
+    loss_of(lg).backward()                                    # must not raise "backward through the graph a second time"
+    assert (lg.detach() - fresh_logits(m, txt, img))[torch.isfinite(lg)].abs().max().item() < 1e-5
+    # (2) the fused optimizer step: raw-pointer writes, no version counter moves
+    tr = FlatTrainer(m, lr=5e-2, weight_decay=0.0)
+    try:
+        for _ in range(2):
+            tr.zero_grad()
+            lg = visual(m, txt, img)
+            assert (lg.detach() - fresh_logits(m, txt, img))[torch.isfinite(lg)].abs().max().item() < 1e-5
+            loss_of(lg).backward()
+            tr.step()
+        with torch.no_grad():                                 # under no_grad the cached projection carries no graph: only the keys protect it
+            a = visual(m, txt, img)
+        tr.zero_grad()
+        loss_of(visual(m, txt, img)).backward()
+        tr.step()
+        with torch.no_grad():
+            b = visual(m, txt, img)
+        assert (b - fresh_logits(m, txt, img))[torch.isfinite(b)].abs().max().item() < 1e-5
+        assert (a - b)[torch.isfinite(b)].abs().max().item() > 1e-6          # the step really moved the logits
+    finally:
+        tr.close()
+        ops._WQ.clear()

@@ -42,7 +42,10 @@ def test_oracle_matches_reference_golden(name, golden_dir):
     for i, te in enumerate(txt_list):              # no_lang_ca: the per-layer text states of the `language` call
         key = "txt_embeds.samples" if i == 0 else f"txt_embeds{i}.samples"
         _close(synth.probe(te.detach().numpy())["samples"], g[key], what=key)
-    _close(out["imagine_embeds"].detach(), g["imagine_embeds"], what="imagine_embeds")
+    if "imagine_embeds" in g.files:                # absent for imagine_enc_pano=False
+        _close(out["imagine_embeds"].detach(), g["imagine_embeds"], what="imagine_embeds")
+    else:
+        assert out["imagine_embeds"] is None
     _close(out["hist_cls"].detach(), g["hist_cls"], what="hist_cls")
     for t in range(ep.T):
         _close(out["logits"][t].detach(), g[f"logits{t}"], what=f"logits{t}")

@@ -69,13 +69,18 @@ def ce_sum(logits, target):
 
 
 def run_episode(model, et, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5,
-                criterion=ce_sum, keep=True):
-    """Runs one episode; returns dict with loss terms and (if keep) per-step outputs."""
+                criterion=ce_sum, keep=True, use_imagine=True):
+    """Runs one episode; returns dict with loss terms and (if keep) per-step outputs.
+    use_imagine=False: a model built with imagine_enc_pano=False (the paper's no-imagination baseline, vilmodel_cmt.py:975-996,1099-1116):
+    no `imagine` / alignment call, the `visual` calls get no imagination tokens (agent_cmt.py:419-462 guards them with args.imagine_enc_pano)."""
     ep = et.ep
     out = {"logits": [], "states": [], "hist": [], "txt_o": [], "ob_o": [], "hist_o": []}
     txt_embeds = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
-    imagine_embeds = model("imagine", imagine_pano_img_feats=et.imagine_feats,
-                           imagine_masks=None if bypass else et.imagine_masks)
+    imagine_embeds = None
+    if use_imagine:
+        imagine_embeds = model("imagine", imagine_pano_img_feats=et.imagine_feats,
+                               imagine_masks=None if bypass else et.imagine_masks)
+    use_aux = use_aux and use_imagine
     aux = None
     if use_aux:
         aux, imagine_embeds = model(
@@ -91,7 +96,7 @@ def run_episode(model, et, bypass=True, use_aux=True, train_ml=0.2, cosine_weigh
             "visual", txt_embeds=txt_embeds, txt_masks=et.txt_masks, hist_embeds=hist_embeds,
             hist_masks=et.hist_masks[t], ob_img_feats=s["ob_img_feats"],
             ob_ang_feats=s["ob_ang_feats"], ob_nav_types=s["ob_nav_types"],
-            ob_masks=s["ob_masks"], imagine_embeds=imagine_embeds, imagine_masks=et.imagine_masks)
+            ob_masks=s["ob_masks"], imagine_embeds=imagine_embeds, imagine_masks=et.imagine_masks if use_imagine else None)
         ml_loss = ml_loss + criterion(logits, s["target"])
         h = model("history", hist_img_feats=s["hist_img_feats"], hist_ang_feats=s["hist_ang_feats"],
                   ob_step_ids=et.step_ids[t],
@@ -111,7 +116,7 @@ def run_episode(model, et, bypass=True, use_aux=True, train_ml=0.2, cosine_weigh
     return out
 
 
-def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum):
+def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, use_imagine=True):
     """The same teacher-forced episode with all T steps executed as ONE batch of T*B samples.
 
     Under teacher forcing every step's observation and history INPUTS are known up front (agent_cmt.py:561-562), so the
@@ -138,7 +143,9 @@ def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2,
                       ob_step_ids=torch.arange(T, device=dev).repeat_interleave(B),
                       hist_pano_img_feats=cat("hist_pano_img_feats"), hist_pano_ang_feats=cat("hist_pano_ang_feats"))
     txt = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
-    img = model("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None if bypass else et.imagine_masks)
+    img = model("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None if bypass else et.imagine_masks) if use_imagine else None
+    use_aux = use_aux and use_imagine
+    im_masks = et.imagine_masks if use_imagine else None
     aux = None
     if use_aux:
         aux, img = model("align_with_contrastive_loss", align_txt_embeds=txt, txt_masks=et.txt_masks, align_imagine_embeds=img,
@@ -157,11 +164,11 @@ def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2,
     rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
     kw = {}
     if hasattr(model, "language_side") and not isinstance(txt, list):      # product model: the episode's language side built once (see TapedEpisode)
-        kw["lang_side"] = model.language_side(txt, et.txt_masks, img, et.imagine_masks).repeat(T)
+        kw["lang_side"] = model.language_side(txt, et.txt_masks, img, im_masks).repeat(T)
     logits, txt_o, hist_o, ob_o = model(
         "visual", txt_embeds=rep(txt), txt_masks=rep(et.txt_masks), hist_embeds=hist, hist_masks=hist_masks,
         ob_img_feats=cat("ob_img_feats"), ob_ang_feats=cat("ob_ang_feats"), ob_nav_types=cat("ob_nav_types"),
-        ob_masks=cat("ob_masks"), imagine_embeds=rep(img), imagine_masks=rep(et.imagine_masks), **kw)
+        ob_masks=cat("ob_masks"), imagine_embeds=rep(img) if use_imagine else None, imagine_masks=rep(im_masks) if use_imagine else None, **kw)
     ml_loss = criterion(logits, cat("target"))
     loss = ml_loss * train_ml / B
     if use_aux and torch.is_tensor(aux):
@@ -198,8 +205,10 @@ class TapedEpisode:
     ghost_compute=True (tests): the batched pass COMPUTES with the recorded dropout seeds instead of reusing the steps' buffers."""
 
     def __init__(self, model, et, tape=None, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum,
-                 ghost_compute=False, overlap_history=True, lag_history=False, want_states=False, feat_dropout=0.0):
+                 ghost_compute=False, overlap_history=True, lag_history=False, want_states=False, feat_dropout=0.0, use_imagine=True):
         from vln_imagine_amd import ops
+        self.use_imagine = use_imagine
+        use_aux = use_aux and use_imagine
         self.model, self.et, self.B, self.T = model, et, et.B, et.T
         self.feat_dropout, self._ops = float(feat_dropout), ops
         self.tape = tape if tape is not None else ops.EpisodeTape(et.T)
@@ -231,7 +240,8 @@ class TapedEpisode:
         imf = et.imagine_feats                                 # outside the tape (one call per episode): torch's own dropout
         if self.feat_dropout > 0.0:
             imf = F.dropout(imf, self.feat_dropout, model.training)
-        img = model("imagine", imagine_pano_img_feats=imf, imagine_masks=None if self.bypass else et.imagine_masks)
+        img = model("imagine", imagine_pano_img_feats=imf, imagine_masks=None if self.bypass else et.imagine_masks) if self.use_imagine else None
+        self.im_masks = et.imagine_masks if self.use_imagine else None
         self.aux = None
         if self.use_aux:
             self.aux, img = model("align_with_contrastive_loss", align_txt_embeds=self.txt, txt_masks=et.txt_masks, align_imagine_embeds=img,
@@ -239,7 +249,7 @@ class TapedEpisode:
                                   sub_instr_imag_flag=ep.sub_instr_imag_flag, noun_phrase_segs=ep.noun_phrase_segs)
         self.img = img
         # the language stream of every `visual` call of the episode, incl. the first cross-modal layer's language Q / K / V: once, with autograd
-        self.ls = None if isinstance(self.txt, list) else model.language_side(self.txt, et.txt_masks, img, et.imagine_masks)
+        self.ls = None if isinstance(self.txt, list) else model.language_side(self.txt, et.txt_masks, img, self.im_masks)
         self.cls = cls = model("history").expand(B, -1)                                        # [B, H]
         H, dt = cls.shape[-1], cls.dtype
         self.ar = torch.arange(T, device=dev)
@@ -295,7 +305,7 @@ class TapedEpisode:
             lg, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=self.txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm,
                 ob_img_feats=self._drop(f("ob_img_feats")[sl]), ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
-                ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=et.imagine_masks, lang_side=self.ls,
+                ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=self.im_masks, lang_side=self.ls,
                 vis_mask_add=self.vm_full[sl] if self.vm_full is not None else None,
                 ob_is_nav0=self.nav0_full[sl] if self.nav0_full is not None else None)
         self.step_logits.append(lg)
@@ -343,7 +353,8 @@ class TapedEpisode:
             logits, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=rep(self.txt), txt_masks=rep(et.txt_masks), hist_embeds=hist.reshape(T * B, T, H), hist_masks=hm_full,
                 ob_img_feats=self._drop(f("ob_img_feats")), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
-                ob_masks=f("ob_masks"), imagine_embeds=rep(self.img), imagine_masks=rep(et.imagine_masks),
+                ob_masks=f("ob_masks"), imagine_embeds=rep(self.img) if self.use_imagine else None,
+                imagine_masks=rep(self.im_masks) if self.use_imagine else None,
                 lang_side=self.ls.repeat(T) if self.ls is not None else None,
                 vis_mask_add=self.vm_full if not self.lag else None, ob_is_nav0=self.nav0_full if not self.lag else None)
         ml_loss = self.criterion(logits, f("target"))
@@ -355,10 +366,10 @@ class TapedEpisode:
 
 
 def run_episode_taped(model, et, tape=None, bypass=True, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
-                      ghost_compute=False, overlap_history=True, lag_history=False, feat_dropout=0.0):
+                      ghost_compute=False, overlap_history=True, lag_history=False, feat_dropout=0.0, use_imagine=True):
     """One episode through TapedEpisode: begin, T steps (`on_step(t, logits, state)` may choose the action), finish."""
     te = TapedEpisode(model, et, tape, bypass, use_aux, train_ml, cosine_weight, criterion, ghost_compute, overlap_history, lag_history,
-                      want_states=on_step is not None, feat_dropout=feat_dropout)
+                      want_states=on_step is not None, feat_dropout=feat_dropout, use_imagine=use_imagine)
     te.begin()
     for t in range(et.T):
         lg, state = te.step(t)

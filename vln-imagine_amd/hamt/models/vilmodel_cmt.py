@@ -547,6 +547,12 @@ class NavCMT(nn.Module):
         while those tensors are the same objects at the same versions; their gradients then arrive through one concatenation node."""
         keys = tuple((id(t), t._version) if torch.is_tensor(t) else None for t in (txt_embeds, txt_masks, imagine_embeds, imagine_masks)) \
             + (dt, torch.is_grad_enabled())
+        if LANG_QKV_ONCE and not self.config.no_lang_ca and len(self.encoder.x_layers) > 0:
+            # the cached LangSide also holds the first cross-modal layer's language Q / K / V: they depend on six PARAMETERS, so a hit is only
+            # valid while those are unchanged - their version counters (load_state_dict, torch.optim) and the shadow cache's epochs (the
+            # fused AdamW step rewrites the arena through raw pointers: no version counter moves)
+            att = _att(self.encoder.x_layers[0].visual_attention)[:6]
+            keys = keys + tuple(p._version for p in att) + (ops.SHADOWS.epoch, ops.SHADOWS.opt_epoch)
         hit = self._lang_side
         if hit is not None and hit[0] == keys and all(a is b for a, b in zip(hit[1], (txt_embeds, txt_masks, imagine_embeds, imagine_masks))):
             return hit[2]
@@ -554,6 +560,8 @@ class NavCMT(nn.Module):
         self._lang_side = (keys, (txt_embeds, txt_masks, imagine_embeds, imagine_masks), ls)      # strong refs keep the ids unique
         if ls.lang.requires_grad:              # once a backward pass has consumed this node its buffers are gone: build it anew next time
             ls.lang.register_hook(self._drop_language_side)
+        if ls.qkv is not None and ls.qkv.requires_grad:      # frozen / detached language: the projection node alone carries a graph (its weights)
+            ls.qkv.register_hook(self._drop_language_side)
         return ls
 
     def language_side(self, txt_embeds, txt_masks, imagine_embeds=None, imagine_masks=None, dt=None):

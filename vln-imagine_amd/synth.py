@@ -77,7 +77,7 @@ def angle_feat(name: str, shape_prefix):
     return np.stack([np.sin(h), np.cos(h), np.sin(e), np.cos(e)], -1).astype(np.float32)
 
 
-def _build_text_imagine(self, tag, B, L, I, ragged, feat=768, vocab=30522):
+def _build_text_imagine(self, tag, B, L, I, ragged, feat=768, vocab=30522, imag_feat=None):
     """Instruction tokens, imagination features and the sub-instruction / noun-phrase annotation shared by the
     HAMT and DUET synthetic episodes (reference builders: r2r/agent_cmt.py:247-313, r2r/data_utils.py:119-450)."""
     k = lambda s: f"{tag}/{s}"
@@ -93,7 +93,8 @@ def _build_text_imagine(self, tag, B, L, I, ragged, feat=768, vocab=30522):
     self.txt_masks = pos < lens[:, None]
     self.txt_ids = np.where(self.txt_masks, ids, 0).astype(np.int64)
     # ---- imaginations + sub-instruction / noun-phrase annotation
-    self.imagine_feats = det_uniform(k("imag"), (B, I, feat), -0.5, 0.5)
+    # imagination features keep their own width (768-d in the released stores, data_utils.py:15-47) when the view features are wider
+    self.imagine_feats = det_uniform(k("imag"), (B, I, imag_feat or feat), -0.5, 0.5)
     valid = np.ones((B, I), bool)
     if ragged:
         valid = det_randint(k("imag_valid"), (B, I), 0, 5) > 0   # 80 % valid
@@ -142,10 +143,10 @@ class HamtEpisode:
     """
 
     def __init__(self, tag="ep0", B=4, L=80, V=37, I=4, T=2, ragged=True,
-                 feat=768, ang=4, pano=36, vocab=30522):
+                 feat=768, ang=4, pano=36, vocab=30522, imag_feat=None):
         self.B, self.L, self.V, self.I, self.T = B, L, V, I, T
         k = lambda s: f"{tag}/{s}"
-        _build_text_imagine(self, tag, B, L, I, ragged, feat, vocab)
+        _build_text_imagine(self, tag, B, L, I, ragged, feat, vocab, imag_feat)
         lens, valid = self.txt_lens, self.imagine_masks
         # ---- per-step observations / history / targets
         self.steps = []
