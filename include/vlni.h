@@ -72,6 +72,15 @@ int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* lda, const vo
                       const void* const* dact_src, const long* ldd, int dact, int variant, float drop_p,
                       const unsigned* drop_seed, void* stream);
 
+/* nprob (1..4) problems of the same N, K and epilogue kind in ONE launch (arrays of nprob); vlni_gemm_nt_dual is nprob = 2. Round 5: the
+ * history panorama encoder's BertLayer (R:216-239 under HistoryEmbeddings R:603-614) rides as a third problem beside the language / vision
+ * streams of the cross-modal layer with the same (N, K, epilogue) (R:399-421). */
+int vlni_gemm_nt_multi(int dtype, int nprob, const void* const* A, const long* lda, const void* const* B, const long* ldb, void* const* C,
+                       const long* ldc, const int* M, int N, int K, const float* const* bias, int act,
+                       const void* const* residual, const long* ldr, void* const* preact, const long* ldp,
+                       const void* const* dact_src, const long* ldd, int dact, int variant, float drop_p,
+                       const unsigned* drop_seed, void* stream);
+
 /* Weight gradient without transposes: C[N,K] += A[M,N]^T B[M,K] (bf16 in, float32 atomics out, split over M rows);
  * colsum[N] (optional) += column sums of A = bias gradient. Autograd of nn.Linear (R:101-103,...). */
 int vlni_gemm_tn_bf16(const void* A, long lda, const void* B, long ldb, float* C, long ldc, int M, int N, int K,

@@ -20,6 +20,7 @@ SIGNATURES = {
     "vlni_gemm_nt": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, P],
     "vlni_gemm_nt_v": [I, P, L, P, L, P, L, I, I, I, P, I, P, L, P, L, P, L, I, F, I, I, I, F, U, P],
     "vlni_gemm_nt_dual": [I, P, P, P, P, P, P, P, I, I, P, I, P, P, P, P, P, P, I, I, F, P, P],
+    "vlni_gemm_nt_multi": [I, I, P, P, P, P, P, P, P, I, I, P, I, P, P, P, P, P, P, I, I, F, P, P],
     "vlni_gemm_tn_bf16": [P, L, P, L, P, L, I, I, I, P, I, P],
     "vlni_gemm_tn_bf16_grouped": [I, P, P, P, L, L, P, L, I, I, P, I, P],
     "vlni_gemm_tn_bf16_grouped_v": [I, P, P, P, L, L, P, L, I, I, P, I, I, P],

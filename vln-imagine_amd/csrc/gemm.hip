@@ -74,6 +74,15 @@ extern "C" int vlni_gemm_nt_dual(int dtype, const void* const* A, const long* ld
                            : k_bf16::vlni_gemm_nt_dual(dtype, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, preact, ldp, dact_src, ldd, dact,
                                                        variant, drop_p, drop_seed, stream);
 }
+extern "C" int vlni_gemm_nt_multi(int dtype, int nprob, const void* const* A, const long* lda, const void* const* B, const long* ldb, void* const* C,
+                                  const long* ldc, const int* M, int N, int K, const float* const* bias, int act, const void* const* residual,
+                                  const long* ldr, void* const* preact, const long* ldp, const void* const* dact_src, const long* ldd, int dact,
+                                  int variant, float drop_p, const unsigned* drop_seed, void* stream) {
+  return dtype == VLNI_F16 ? k_f16::vlni_gemm_nt_multi(dtype, nprob, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, preact, ldp, dact_src, ldd,
+                                                       dact, variant, drop_p, drop_seed, stream)
+                           : k_bf16::vlni_gemm_nt_multi(dtype, nprob, A, lda, B, ldb, C, ldc, M, N, K, bias, act, residual, ldr, preact, ldp, dact_src, ldd,
+                                                        dact, variant, drop_p, drop_seed, stream);
+}
 extern "C" int vlni_gemm_nt(int dtype, const void* A, long lda, const void* B, long ldb, void* C, long ldc, int M, int N, int K,
                             const float* bias, int act, const void* residual, long ldr, void* preact, long ldp, const void* dact_src,
                             long ldd, int dact, float alpha, int split_k, int atomic_f32, void* stream) {
