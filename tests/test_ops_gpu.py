@@ -549,6 +549,41 @@ def test_gemm_dual_launch_variants(ops, variant):
         ops._GEMM_BEST.clear()
 
 
+@pytest.mark.parametrize("nprob", [1, 3, 4])
+@pytest.mark.parametrize("variant", [1, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 32])
+def test_gemm_multi_problem_launch_variants(ops, variant, nprob):
+    """vlni_gemm_nt_multi: 1, 3 or 4 problems of one (N, K, epilogue kind) in ONE launch (the language / vision streams of a cross-modal layer
+    + the history panorama encoder's layer; ragged row counts so that every problem ends in a partial tile) == single launches of the
+    register-staged kernel, for every tile geometry, with the epilogues a step uses (bias + residual + dropout; GELU with stored
+    pre-activation); and against float64 directly."""
+    saved = (ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS)
+    rows = (5 * 86, 5 * 44 + 3, 5 * 36, 77)[:nprob]
+    try:
+        ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS = True, (variant,), 1 << 30, 1 << 30
+        for dtype in (torch.bfloat16, torch.float32):
+            for (N, K) in ((768, 768), (640, 384)):
+                ops._GEMM_BEST.clear()
+                a = [_rand((m, K), dtype, 141 + i, 0.5) for i, m in enumerate(rows)]
+                b = [_rand((N, K), dtype, 151 + i, 0.05) for i in range(nprob)]
+                bias = [_rand((N,), torch.float32, 161 + i, 0.1) for i in range(nprob)]
+                res = [_rand((m, N), dtype, 171 + i, 0.5) for i, m in enumerate(rows)]
+                seeds = tuple(1000 + 17 * i for i in range(nprob))
+                outs = ops.gemm_ntn(a, b, bias=bias, residual=res, drop=(0.25, seeds))
+                z = [torch.empty_like(r) for r in res]
+                acts = ops.gemm_ntn(a, b, bias=bias, act=1, preact=z)
+                for i in range(nprob):
+                    r = torch.empty_like(outs[i]); rz = torch.empty_like(outs[i]); ra = torch.empty_like(outs[i])
+                    ops._gemm_call(1, a[i], b[i], r, bias[i], 0, res[i], None, None, 0, 1.0, 1, False, rows[i], N, K, drop=(0.25, seeds[i]))
+                    ops._gemm_call(1, a[i], b[i], ra, bias[i], 1, None, rz, None, 0, 1.0, 1, False, rows[i], N, K)
+                    assert _same(outs[i], r, variant), (variant, dtype, N, K, i, "residual + dropout")
+                    assert _same(acts[i], ra, variant) and _same(z[i], rz, variant), (variant, dtype, N, K, i, "gelu + pre-activation")
+                    pre = a[i].double() @ b[i].double().t() + bias[i].double()
+                    _chk(z[i], pre, TOL[dtype] if dtype in TOL else 1e-5, (variant, dtype, N, K, i, "float64"))
+    finally:
+        ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS = saved
+        ops._GEMM_BEST.clear()
+
+
 @pytest.mark.parametrize("variant", [2, 3, 4, 5, 6])
 def test_gemm_nn_weight_layout_matches_transposed_copy(ops, variant):
     """dgrad straight from W[out, in] (transposing LDS reads, variant + 16) == the NT kernel on an explicit W^T copy, bit for bit,

@@ -112,25 +112,36 @@ def test_taped_episode_with_dropout_equals_the_batched_pass_computed_with_its_se
 
 
 def test_taped_bf16_full_width_tracks_the_stepwise_bf16_run():
-    """bfloat16 at the bench's layer width: the taped episode and the step-by-step autograd rollout differ by kernel choice and by
-    the padded history keys only."""
+    """bfloat16 at the bench's layer width: the taped episode and the step-by-step autograd rollout are two bfloat16 programs of the same
+    math (other kernels per launch shape, padded history keys, and - round 5 - the history tokens of all steps from ONE batched call).
+    Both are held to the float32 step-by-step run: the taped program may not be further from it than the stepwise one by more than 15 %,
+    and the two stay within the distance two bfloat16 programs have from each other."""
     from vln_imagine_amd import ops
     from vln_imagine_amd.hamt.config import HamtConfig
     cfg = HamtConfig(num_l_layers=2, num_x_layers=2, num_h_pano_layers=1)
     ep = synth.HamtEpisode(tag="tape16", B=16, L=80, V=37, I=6, T=4)
     et = EpisodeTensors(ep, "cuda")
-    m1, m2 = build_product(cfg, torch.bfloat16), build_product(cfg, torch.bfloat16)
+    m0, m1, m2 = build_product(cfg), build_product(cfg, torch.bfloat16), build_product(cfg, torch.bfloat16)
+    o0 = run_episode(m0, et, criterion=ops.cross_entropy_sum)
+    o0["loss"].backward()
     o1 = run_episode(m1, et, criterion=ops.cross_entropy_sum)
     o1["loss"].backward()
     o2 = run_episode_taped(m2, et, criterion=ops.cross_entropy_sum)
     o2["loss"].backward()
     assert abs(o1["loss"].item() - o2["loss"].item()) < 5e-3
-    num = den = 0.0
-    for (n, p), (_, q) in zip(m1.named_parameters(), m2.named_parameters()):
-        if p.grad is not None:
-            num += float((p.grad.double() - q.grad.double()).pow(2).sum())
-            den += float(p.grad.double().pow(2).sum())
-    assert (num / den) ** 0.5 < 0.044, (num / den) ** 0.5          # measured 0.0334 (two bf16 programs; bf16 vs fp32 is 0.07): 1.3 x
+
+    def rel(ma, mb):
+        num = den = 0.0
+        for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+            if q.grad is not None:
+                num += float((p.grad.double() - q.grad.double()).pow(2).sum())
+                den += float(q.grad.double().pow(2).sum())
+        return (num / den) ** 0.5
+
+    e_step, e_tape, e_pair = rel(m1, m0), rel(m2, m0), rel(m2, m1)
+    print(f"\n[bf16 vs fp32 stepwise] stepwise {e_step:.4f}, taped {e_tape:.4f}; taped vs stepwise bf16 {e_pair:.4f}")
+    assert e_tape <= 1.15 * e_step + 0.005, (e_tape, e_step)      # measured round 5: see the printed line (round 4, per-step history calls: pair 0.033)
+    assert e_pair <= 1.5 * max(e_step, e_tape), (e_pair, e_step, e_tape)
 
 
 @pytest.mark.parametrize("variant", ["c1_T3_dense", "c1_shipped", "c1_nofuse_nosprel"])

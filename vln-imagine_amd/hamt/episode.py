@@ -18,6 +18,26 @@ import torch.nn.functional as F
 _MASK_IN_GRAPH = int(os.environ.get("VLNI_MASK_IN_GRAPH", "0"))       # tools/stale_mask_repro.py (round-3 anomaly hunt)
 _EPISODE_MASKS = os.environ.get("VLNI_EPISODE_MASKS", "1") != "0"     # A/B switch: mask forms of all steps once per episode
 _OVERLAP_HISTORY = os.environ.get("VLNI_OVERLAP_HISTORY", "1") != "0"  # A/B switch: the history encoder of step t on a side stream
+# Round 5: in which ORDER the two concurrent calls of a step are issued (and so captured). The kernel trace of the replayed step
+# (gpurun_out/r5f/last_step.tsv) shows the `visual` chain idle for ~180 us at the start of every step while the queue that got the history
+# branch runs its first ~20 small kernels: with the history call captured first the graph executor continues on that branch and starts the
+# other one late. 1 = `visual` first (the critical path), then `history` on the second stream.
+_HISTORY_AFTER = os.environ.get("VLNI_HISTORY_AFTER", "1") == "1"
+# Round 5: teacher forcing knows every step's history inputs when the episode starts (the drivers already rely on that for the history
+# masks of all steps), so the T `history` calls are ONE call on T x B samples in begin() (EpisodeTape.record_steps), on the second stream
+# beside the text encoder (5.1 k-row launches: half of the chip idle), and the steps' `visual` calls run alone on the chip with no fork /
+# join per step. Why: a replayed hipGraph with parallel branches is fed by the host in CAPTURE order at ~8 us per node (a single-stream
+# graph: ~2.3 us; tools/graph_fork_probe.py), so the ~32 small launches of a per-step history call captured in front of the step's `visual`
+# call held the critical path back by ~180 us per step (gpurun_out/r5f/last_step.tsv). 0 = one history call beside each step's `visual`
+# call (rounds 2-4). Sampled rollouts (lag_history=True) are not affected.
+_HISTORY_UPFRONT = os.environ.get("VLNI_HISTORY_UPFRONT", "1") == "1"
+# Round 5: step t's `history` call INSIDE its `visual` call's launches (3-problem GEMMs). OFF by default - measured on one box
+# (gpurun_out/r5c-r5e, 30 steps x 2): side-stream overlap 27.02 ms, lockstep with the panorama's attention / LayerNorm forked to a second stream
+# 27.0-27.2, everything on one stream 26.4 -> 26.6 on another box (+0.5); a timing-only build WITHOUT the panorama's attention / LayerNorm
+# launches (the bound for 3-problem attention / LayerNorm kernels) 26.65. The step-long launches are one round of tiles either way, so the
+# merged launch costs what the unmerged one did and the side stream was already running the history encoder in the idle quarter of the chip;
+# what lockstep adds are dependencies (the merged GEMM waits for both chains). The GEMM family's own time falls by 1.2 ms (0.26 -> 0.28 of peak).
+_LOCKSTEP_HISTORY = os.environ.get("VLNI_LOCKSTEP_HISTORY", "0") == "1"
 
 
 class EpisodeTensors:
@@ -216,6 +236,10 @@ class TapedEpisode:
         self.bypass, self.use_aux, self.train_ml, self.cosine_weight, self.criterion = bypass, use_aux, train_ml, cosine_weight, criterion
         self.ghost_compute, self.lag, self.want_states = ghost_compute, lag_history, want_states
         self.overlap = overlap_history and not lag_history and _OVERLAP_HISTORY
+        # teacher forcing, product model: step t's `history` call runs in lockstep with its `visual` call (3-problem GEMM launches, NavCMT
+        # `visual` with hist_step=) instead of beside it on a second stream; the ghost pass and the backward keep the two separate calls
+        self.lockstep = (_LOCKSTEP_HISTORY and overlap_history and not lag_history and hasattr(model, "language_side")
+                         and getattr(getattr(model, "config", None), "hist_enc_pano", False) and not getattr(model.config, "no_lang_ca", True))
         self.step_logits = []
 
     def _drop(self, x):
@@ -236,6 +260,26 @@ class TapedEpisode:
         dev = et.txt_ids.device
         tape.reset()
         self.step_logits = []
+        self.main = torch.cuda.current_stream() if dev.type == "cuda" else None
+        self.side = None
+        if self.overlap and self.main is not None:
+            self.side = getattr(tape, "_side", None)
+            if self.side is None:
+                self.side = tape._side = torch.cuda.Stream()
+        for k in ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats", "ob_img_feats", "ob_ang_feats",
+                  "ob_nav_types", "ob_masks", "target"):
+            et.full(k)                                         # built (once) on the main stream before any side-stream reader
+        self.ar = torch.arange(T, device=dev)
+        if not self.lag:
+            self.valid = et.hist_mask_T                                                        # [step t, sample b, entry j]: entry j < history length before step t
+            self.hm_full = self.valid.reshape(T * B, T).contiguous()
+        # teacher forcing, product model: ALL T `history` calls of the episode (and the [CLS] one) on the second stream from here on, beside
+        # the text encoder, whose 5.1 k-row launches fill half of the chip. They read features only (vilmodel_cmt.py:576-618); step t waits
+        # for the event behind history t - 1. See _HISTORY_UPFRONT.
+        self.upfront = (_HISTORY_UPFRONT and dev.type == "cuda" and not self.lag and not self.lockstep and hasattr(model, "language_side"))
+        self.h_event = None
+        if self.upfront and self.side is not None:
+            self.side.wait_stream(self.main)                   # the fork point; the call itself is issued below, AFTER the text side
         self.txt = model("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
         imf = et.imagine_feats                                 # outside the tape (one call per episode): torch's own dropout
         if self.feat_dropout > 0.0:
@@ -250,36 +294,54 @@ class TapedEpisode:
         self.img = img
         # the language stream of every `visual` call of the episode, incl. the first cross-modal layer's language Q / K / V: once, with autograd
         self.ls = None if isinstance(self.txt, list) else model.language_side(self.txt, et.txt_masks, img, self.im_masks)
+        self.lock = self.lockstep and self.ls is not None
+        if not self.upfront:
+            self._cls_and_history_buffer(dev)
+        else:
+            with (torch.cuda.stream(self.side) if self.side is not None else contextlib.nullcontext()):
+                self._cls_and_history_buffer(dev)
+                f = et.full
+                with tape.record_steps("history", T):          # the call the ghost pass repeats (finish())
+                    h_all = model("history", hist_img_feats=self._drop(f("hist_img_feats")), hist_ang_feats=f("hist_ang_feats"),
+                                  ob_step_ids=self.ar.repeat_interleave(B), hist_pano_img_feats=self._drop(f("hist_pano_img_feats")),
+                                  hist_pano_ang_feats=f("hist_pano_ang_feats"))
+                with torch.no_grad():                          # entry j + 1 of every later step's input = h_j (zero where the history is shorter)
+                    prefix = torch.cat([self.cls.detach().to(h_all.dtype).unsqueeze(0), h_all.view(T, B, -1)[:T - 1]], 0)
+                    torch.mul(prefix.permute(1, 0, 2).unsqueeze(0), self.valid.to(h_all.dtype).unsqueeze(-1), out=self.hb)
+                if self.side is not None:
+                    self.h_event = torch.cuda.Event()
+                    self.h_event.record(self.side)
+        # teacher forcing knows the masks of all T steps here: their additive / boolean forms once per episode, not once per step
+        self.vm_full = self.nav0_full = None
+        if not self.lag and dev.type == "cuda" and _EPISODE_MASKS:
+            self.vm_full = self._ops.additive_mask(torch.cat([self.hm_full, et.full("ob_masks")], 1))      # [T B, T + V]
+            self.nav0_full = et.full("ob_nav_types") == 0
+
+    def _cls_and_history_buffer(self, dev):
+        """The [CLS] history token and the history inputs of all steps: sample (t, b) holds [CLS, h_0 .. h_{t-1}, ...]. Entries beyond a
+        sample's history length are masked keys: teacher forcing zeroes them (all lengths are known), a lagging history leaves later entries
+        as they are (finite: the buffer is zeroed once per tape). The recorded steps read slices of it, the ghost pass an autograd expression
+        with the same values."""
+        model, tape, B, T = self.model, self.tape, self.B, self.T
         self.cls = cls = model("history").expand(B, -1)                                        # [B, H]
         H, dt = cls.shape[-1], cls.dtype
-        self.ar = torch.arange(T, device=dev)
-        # history inputs of all steps: sample (t, b) holds [CLS, h_0 .. h_{t-1}, ...]. Entries beyond a sample's history length are masked
-        # keys: teacher forcing zeroes them (all lengths are known), a lagging history leaves later entries as they are (finite: the buffer
-        # is zeroed once per tape). The recorded steps read slices of it, the ghost pass an autograd expression with the same values
         hb = getattr(tape, "_hist_buf", None)
         if hb is None or hb.shape != (T, B, T, H) or hb.dtype != dt:
             hb = tape._hist_buf = torch.zeros((T, B, T, H), dtype=dt, device=dev)
         self.hb = hb
         with torch.no_grad():
             hb[:, :, 0] = cls
-        if not self.lag:
-            self.valid = et.hist_mask_T                                                        # [step t, sample b, entry j]: entry j < history length before step t
-            self.hm_full = self.valid.reshape(T * B, T).contiguous()
-        for k in ("hist_img_feats", "hist_ang_feats", "hist_pano_img_feats", "hist_pano_ang_feats", "ob_img_feats", "ob_ang_feats",
-                  "ob_nav_types", "ob_masks", "target"):
-            et.full(k)                                         # built (once) on the main stream before any side-stream reader
-        # teacher forcing knows the masks of all T steps here: their additive / boolean forms once per episode, not once per step
-        self.vm_full = self.nav0_full = self.validf = None
-        if not self.lag and dev.type == "cuda" and _EPISODE_MASKS:
-            self.vm_full = self._ops.additive_mask(torch.cat([self.hm_full, et.full("ob_masks")], 1))      # [T B, T + V]
-            self.nav0_full = et.full("ob_nav_types") == 0
-            self.validf = self.valid.to(dt)
-        self.main = torch.cuda.current_stream() if dev.type == "cuda" else None
-        self.side = None
-        if self.overlap and self.main is not None:
-            self.side = getattr(tape, "_side", None)
-            if self.side is None:
-                self.side = tape._side = torch.cuda.Stream()
+        self.validf = self.valid.to(dt) if (not self.lag and dev.type == "cuda" and _EPISODE_MASKS) else None
+
+    def _put_history(self, t, h):
+        """History token of step t into entry t + 1 of the later steps' inputs (teacher forcing: zero where the sample's history is shorter)."""
+        if t + 1 < self.T:
+            hb = self.hb
+            with torch.no_grad():
+                if self.validf is not None and h.dtype == hb.dtype:
+                    torch.mul(h.unsqueeze(0), self.validf[t + 1:, :, t + 1, None], out=hb[t + 1:, :, t + 1])      # one launch
+                else:
+                    hb[t + 1:, :, t + 1] = h * self.valid[t + 1:, :, t + 1, None].to(h.dtype)
 
     def step(self, t):
         model, et, tape, B, T, hb = self.model, self.et, self.tape, self.B, self.T, self.hb
@@ -297,30 +359,42 @@ class TapedEpisode:
                 hm = et.hist_mask_T[t]
         else:
             hm = self.hm_full[sl]
-            if side is not None:
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    h = self._history(t)
-        with tape.record("visual", t):
-            lg, txt_o, hist_o, ob_o = model(
+            if self.upfront:
+                if t == 0 and self.h_event is not None:
+                    main.wait_event(self.h_event)          # the history buffer of the whole episode is filled
+            elif side is not None and not self.lock:
+                side.wait_stream(main)                     # the fork point: step t's history needs nothing of step t's `visual` call
+                if not _HISTORY_AFTER:
+                    with torch.cuda.stream(side):
+                        h = self._history(t)
+        lock = self.lock
+        with tape.record(("visual", "history") if lock else "visual", t):
+            hist_step = None
+            if lock:
+                with tape.use("history"):                  # the arguments of _history(t), drawn under its key in its order
+                    hist_step = ("visual", "history", dict(
+                        hist_img_feats=self._drop(f("hist_img_feats")[sl]), hist_ang_feats=f("hist_ang_feats")[sl], ob_step_ids=et.step_ids[t],
+                        hist_pano_img_feats=self._drop(f("hist_pano_img_feats")[sl]), hist_pano_ang_feats=f("hist_pano_ang_feats")[sl]), side)
+            res = model(
                 "visual", txt_embeds=self.txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm,
                 ob_img_feats=self._drop(f("ob_img_feats")[sl]), ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
                 ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=self.im_masks, lang_side=self.ls,
                 vis_mask_add=self.vm_full[sl] if self.vm_full is not None else None,
-                ob_is_nav0=self.nav0_full[sl] if self.nav0_full is not None else None)
+                ob_is_nav0=self.nav0_full[sl] if self.nav0_full is not None else None, **({"hist_step": hist_step} if lock else {}))
+        lg, txt_o, hist_o, ob_o = res[:4]
+        if _HISTORY_AFTER and not self.lag and not lock and side is not None and not self.upfront:
+            with torch.cuda.stream(side):                  # issued AFTER the `visual` call, forked where it was before (see _HISTORY_AFTER)
+                h = self._history(t)
         self.step_logits.append(lg)
         state = txt_o[:, 0] * hist_o[:, 0] if self.want_states else None                      # model_HAMT.py:86
-        if not self.lag:
-            if side is not None:
+        if not self.lag and not self.upfront:
+            if lock:
+                h = res[4]
+            elif side is not None:
                 main.wait_stream(side)
             else:
                 h = self._history(t)
-            if t + 1 < T:
-                with torch.no_grad():
-                    if self.validf is not None and h.dtype == hb.dtype:
-                        torch.mul(h.unsqueeze(0), self.validf[t + 1:, :, t + 1, None], out=hb[t + 1:, :, t + 1])      # one launch
-                    else:
-                        hb[t + 1:, :, t + 1] = h * self.valid[t + 1:, :, t + 1, None].to(h.dtype)
+            self._put_history(t, h)
         return lg, state
 
     def finish(self):

@@ -188,6 +188,31 @@ class LXRTXLayer(nn.Module):
                              drop=_drop(self.visn_output))
         return lang, visn
 
+    def forward_with_pano(self, lang, lang_mask, visn, visn_mask, lang_qkv, pano, pano_layer, keys, side=None, pending=None):
+        """forward() of this layer and `pano_layer` (a BertLayer of the history panorama encoder on its own [B, 36, H] input, no key mask) in
+        LOCKSTEP inside a recording episode tape: the self-attention and FFN projections of the language stream, the vision stream and the
+        panorama run as 3-problem GEMM launches (ops.rec_self_att3 / rec_ffn3). The panorama encoder's BertLayers have exactly the (N, K,
+        epilogue) of these launches and independent data; 5504 + 2752 + 2304 rows are 0.98 / 2.95 / 3.94 rounds of 256 x 128 tiles where
+        the two streams alone are 0.77 / 2.32 / 3.09. keys = (tape key of this layer's call, tape key of the history call): every draw of a
+        dropout seed happens under the key of the call it belongs to, in that call's own order. side: a second stream for the panorama's
+        small launches between the shared GEMMs (ops.fork); pending: an ops.fork whose body produced `pano` (joined before its first use)."""
+        kv, kh = keys
+        tape = ops._TAPE
+        lang, visn = self._cross(lang, lang_mask, visn, visn_mask, lang_qkv)
+        if pending is not None:
+            pending.join()
+        d0, d1 = _drop(self.lang_self_att), _drop(self.visn_self_att)
+        with tape.use(kh):
+            d2 = _drop(pano_layer.attention)
+        lang, visn, pano = ops.rec_self_att3((lang, visn, pano), (lang_mask, visn_mask, None), (d0, d1, d2),
+                                             (_att(self.lang_self_att), _att(self.visn_self_att), _att(pano_layer.attention)), HID_EPS, keys, side)
+        d0, d1 = _drop(self.lang_output), _drop(self.visn_output)
+        with tape.use(kh):
+            d2 = _drop(pano_layer.output)
+        return ops.rec_ffn3((lang, visn, pano), (d0, d1, d2),
+                            (_ffn(self.lang_inter, self.lang_output), _ffn(self.visn_inter, self.visn_output),
+                             _ffn(pano_layer.intermediate, pano_layer.output)), HID_EPS, keys, side)
+
     def forward_cls(self, lang, lang_mask, visn, visn_mask, lang_qkv=None):
         """The LAST cross-modal layer when only the language stream's [CLS] row is read afterwards (NavCMT.visual_lang_rows): the
         cross-attention still updates every language row - they are the keys and values of the language self-attention - but the
@@ -276,7 +301,13 @@ class HistoryEmbeddings(_FeatEmbed):
         if img is None:                                   # CLS path, reference :592-595
             srcs = [(self.cls_token, "bcast", None), (self.type_embedding.weight, "bcast", None)]
             return F.dropout(ops.sum_layer_norm(srcs, g, b, 1, dt, HID_EPS), self.p_drop, self.training)
-        B = img.shape[0]
+        srcs, pe = self.embed(img, ang, pos_ids, pano_img, pano_ang, dt)
+        return self.combine(srcs, self.pano_encoder(pe, None) if pe is not None else None, img.shape[0], dt)
+
+    def embed(self, img, ang, pos_ids, pano_img, pano_ang, dt):
+        """First half of the step path (:596-610): the sources of the final sum-LayerNorm and the panorama encoder's input (None without
+        hist_enc_pano). Split from combine() so that a lockstep step (NavCMT `visual` with hist_step=) can run the encoder's layers beside
+        the cross-modal layers."""
         ti, ta = self._feat(img, ang, "", dt)
         if pos_ids.numel() == 1:                          # one step for the whole batch (the agent's per-step call)
             row = self.position_embeddings.weight.index_select(0, pos_ids.reshape(-1)) + self.type_embedding.weight
@@ -284,15 +315,22 @@ class HistoryEmbeddings(_FeatEmbed):
         else:                                             # per-row step ids (time-batched teacher forcing)
             srcs = [(ti, "dense", None), (ta, "dense", None), (self.type_embedding.weight, "bcast", None),
                     (self.position_embeddings.weight, "gather", pos_ids.reshape(-1).contiguous())]
+        pe = None
         if self.pano_encoder is not None:                 # :603-614, pano mask is all ones -> no key mask
             Bp, P, _ = pano_img.shape
             pi, pa = self._feat(pano_img, pano_ang, "pano_", dt)
             pe = ops.dropout((pi + pa).view(Bp, P, -1), self.p_drop, self.training)
-            pm = ops.seq_mean(self.pano_encoder(pe, None))
+        return srcs, pe
+
+    def combine(self, srcs, pano_out, B, dt):
+        """Second half (:611-618): mean over the encoded panorama, sum of the sources, LayerNorm, dropout."""
+        g, b = self.layer_norm.weight, self.layer_norm.bias
+        if pano_out is not None:
+            pm = ops.seq_mean(pano_out)
             if len(srcs) == 4:                            # the sum kernel takes 4 sources: fold the type row into the pano mean
                 pm = pm + self.type_embedding.weight.to(pm.dtype)
                 srcs = [srcs[0], srcs[1], srcs[3]]
-            srcs.append((pm, "dense", None))
+            srcs = srcs + [(pm, "dense", None)]
         return ops.dropout(ops.sum_layer_norm(srcs, g, b, B, dt, HID_EPS), self.p_drop, self.training)
 
 
@@ -583,6 +621,13 @@ class NavCMT(nn.Module):
             qkv = ops.qkv_proj(lang, _att(self.encoder.x_layers[0].visual_attention))
         return LangSide(lang, lm, nt, qkv)
 
+    def _history_tail(self, h_srcs, pano, pano_layers, hk, dt):
+        """The end of a lockstep step's `history` call: panorama-encoder layers nobody took along, mean + sum + LayerNorm (:611-618)."""
+        for l in pano_layers:
+            pano = l(pano, None)
+        h = self.hist_embeddings.combine(h_srcs, pano, hk["hist_img_feats"].shape[0], dt)
+        return h.detach() if self.fix_hist_embedding else h
+
     def _drop_language_side(self, grad):
         self._lang_side = None
         return grad
@@ -606,10 +651,14 @@ class NavCMT(nn.Module):
                 ob_img_feats=None, ob_ang_feats=None, ob_nav_types=None, ob_masks=None, imagine_pano_img_feats=None,
                 imagine_masks=None, imagine_embeds=None, align_txt_embeds=None, align_imagine_embeds=None,
                 sub_instr_segs=None, sub_instr_imag_flag=None, noun_phrase_segs=None, obs_instr_ids=None,
-                return_cross_attention_probs=False, lang_side=None, vis_mask_add=None, ob_is_nav0=None):
+                return_cross_attention_probs=False, lang_side=None, vis_mask_add=None, ob_is_nav0=None, hist_step=None):
         """`visual` extras of the episode drivers (all optional, values a plain call computes itself): lang_side = language_side(...);
         vis_mask_add = additive_mask(cat([hist_masks, ob_masks], 1)) and ob_is_nav0 = (ob_nav_types == 0), which a driver that knows
-        the masks of all T steps builds once per episode instead of once per step."""
+        the masks of all T steps builds once per episode instead of once per step.
+        hist_step = (tape key of this call, tape key of the history call, kwargs of the step's `history` call): inside a RECORDING episode
+        tape opened with both keys, the step's `history` call runs in lockstep with this one - its panorama encoder layer i beside cross-modal
+        layer i in 3-problem GEMM launches (LXRTXLayer.forward_with_pano) - and its result comes back as a fifth output. Both calls read
+        inputs only (history tokens are re-encoded from features, :576-618), so the step computes exactly what the two calls compute."""
         c, dt = self.config, self.compute_dtype
         if mode == "language":
             B, L = txt_ids.shape
@@ -653,6 +702,18 @@ class NavCMT(nn.Module):
         if return_cross_attention_probs and c.no_lang_ca:
             raise NotImplementedError("return_cross_attention_probs with no_lang_ca (the reference's own comment: 'this might break')")
         cross_probs, self_probs = [], []
+        pano = pano_layers = h_srcs = None
+        if hist_step is not None:
+            kv, kh, hk = hist_step[:3]
+            h_side = hist_step[3] if len(hist_step) > 3 else None        # a second stream for the history call's small launches
+            assert ops._TAPE is not None and ops._TAPE.mode == "record" and not isinstance(txt_embeds, list) and not return_cross_attention_probs
+            he = self.hist_embeddings
+            h_pending = ops.fork(h_side)                                 # the history embeddings beside this call's own embeddings
+            with h_pending, ops._TAPE.use(kh):
+                h_srcs, pano = he.embed(hk["hist_img_feats"], hk["hist_ang_feats"], hk["ob_step_ids"], hk["hist_pano_img_feats"],
+                                        hk["hist_pano_ang_feats"], dt)
+            pano_layers = list(he.pano_encoder.layer) if pano is not None else []
+            h_step = None
         hist = hist_embeds.to(dt)
         if self.encoder.h_layers is not None:
             hm = ops.additive_mask(hist_masks)
@@ -700,8 +761,24 @@ class NavCMT(nn.Module):
             q0 = lang_qkv if i == 0 else None               # layer 0's language input IS the episode's language side
             if cls_only and i == len(self.encoder.x_layers) - 1:
                 lang, visn = xl.forward_cls(lang, lm, visn, vm, q0)
+            elif pano_layers and not c.no_lang_ca:          # lockstep: the next panorama-encoder layer rides in this layer's launches
+                lang, visn, pano = xl.forward_with_pano(lang, lm, visn, vm, q0, pano, pano_layers.pop(0), (kv, kh), h_side, h_pending)
+                h_pending = None
+                if not pano_layers:                         # the panorama is encoded: the rest of the history call beside the later layers
+                    h_pending = ops.fork(h_side)
+                    with h_pending, ops._TAPE.use(kh):
+                        h_step = self._history_tail(h_srcs, pano, (), hk, dt)
             else:
                 lang, visn = xl(lang, lm, visn, vm, q0)
+        if hist_step is None:
+            h_step = None
+        elif h_step is None:                                # no cross-modal layer took the panorama layers along (or not all of them)
+            if h_pending is not None:
+                h_pending.join()
+            with ops._TAPE.use(kh):
+                h_step = self._history_tail(h_srcs, pano, pano_layers, hk, dt)
+        elif h_pending is not None:
+            h_pending.join()
         hist_o, ob_o = visn[:, :nh], visn[:, nh:nh + no]
         txt_o = lang[:, :nt]
         img_o = None
@@ -725,4 +802,6 @@ class NavCMT(nn.Module):
         act_logits = self.next_action(f.contiguous(), ob_is_nav0 if ob_is_nav0 is not None else ob_nav_types == 0)
         if return_cross_attention_probs:
             return act_logits, txt_o, hist_o, ob_o, cross_probs, self_probs
+        if hist_step is not None:
+            return act_logits, txt_o, hist_o, ob_o, h_step
         return act_logits, txt_o, hist_o, ob_o

@@ -80,45 +80,92 @@ class EpisodeTape:
     def __init__(self, T):
         self.T = T
         self.bufs, self.seeds, self.steps = {}, {}, {}
-        self.key = self.mode = None
+        self.key = self.mode = self.batch_n = None
         self.t = self.i = self.si = 0
+        self._open = {}                 # key -> (allocation index, seed index) of the keys of the context in flight that are not the active one
 
     def reset(self):
         """New episode: fresh dropout seeds; the buffers are kept (a captured step graph replays into the same addresses)."""
         self.seeds, self.steps = {}, {}
 
-    def _enter(self, key, mode, t):
+    def _enter(self, keys, mode, t, batch_n=None):
         global _TAPE
         assert _TAPE is None, "episode tapes do not nest"
-        self.key, self.mode, self.t, self.i, self.si = key, mode, t, 0, 0
-        self.bufs.setdefault(key, [])
-        self.seeds.setdefault(key, [])
+        self.key, self.mode, self.t, self.i, self.si = keys[0], mode, t, 0, 0
+        self.batch_n = batch_n          # record mode only: ONE call on the samples of steps 0 .. batch_n - 1 fills the whole buffers
+        self._open = {k: (0, 0) for k in keys}
+        for k in keys:
+            self.bufs.setdefault(k, [])
+            self.seeds.setdefault(k, [])
         _TAPE = self
+
+    def _swap(self, key):
+        """Makes `key` (one of the keys of the context in flight) the key that allocations and seed draws go to; returns the previous one."""
+        prev = self.key
+        if key is None or key == prev:
+            return prev
+        assert key in self._open, f"tape: {key!r} is not open (open: {sorted(self._open)})"
+        self._open[prev] = (self.i, self.si)
+        self.key = key
+        self.i, self.si = self._open[key]
+        return prev
+
+    def use(self, key):
+        """Context manager: inside, activations and dropout seeds belong to `key`. A recorded step that runs two calls of the model in
+        lockstep (the `visual` call and the `history` call of a HAMT step share multi-problem GEMM launches) opens both keys with
+        record((k0, k1), t) and switches per allocation, so each key's sequence is the one its own ghost pass will ask for."""
+        return _TapeUse(self, key)
 
     def _exit(self):
         global _TAPE
-        if self.mode == "record":
-            self.steps[self.key] = self.t + 1 if self.t == 0 else max(self.steps.get(self.key, 0), self.t + 1)
-            if self.t == 0 and self.i < len(self.bufs[self.key]):        # another program than the last episode's (e.g. NavCMT.visual_lang_rows
-                _KEEPALIVE.extend(self.bufs[self.key][self.i:])          # switched): step 0 defines it; an older capture may still use the rest
-                del self.bufs[self.key][self.i:]
-        n_alloc, n_seed = self.i, self.si
+        self._open[self.key] = (self.i, self.si)
+        counts = {}
+        for key, (n_alloc, n_seed) in self._open.items():
+            if self.mode == "record" and self.batch_n:
+                self.steps[key] = self.batch_n
+            elif self.mode == "record":
+                self.steps[key] = self.t + 1 if self.t == 0 else max(self.steps.get(key, 0), self.t + 1)
+                if self.t == 0 and n_alloc < len(self.bufs[key]):        # another program than the last episode's (e.g. NavCMT.visual_lang_rows
+                    _KEEPALIVE.extend(self.bufs[key][n_alloc:])          # switched): step 0 defines it; an older capture may still use the rest
+                    del self.bufs[key][n_alloc:]
+            counts[key] = (n_alloc, n_seed)
         _TAPE = None
         self.key = self.mode = None
-        return n_alloc, n_seed
+        self._open = {}
+        return counts
 
     def record(self, key, t):
-        return _TapeCtx(self, key, "record", t)
+        """key: one tape key, or a tuple of keys recorded by ONE lockstep pass (see use())."""
+        return _TapeCtx(self, key if isinstance(key, tuple) else (key,), "record", t)
+
+    def record_steps(self, key, n):
+        """RECORD the calls of steps 0 .. n - 1 of `key` as ONE call on n x B samples (teacher forcing: the inputs of all steps are known -
+        the history tokens of a HAMT episode are encoded from features alone, vilmodel_cmt.py:576-618): the operators compute, with fresh
+        dropout seeds, straight into the episode-wide buffers - exactly the tensors the n per-step calls would have filled (the masks too:
+        a step's launch draws the window of the batched tensor's mask, see _shift). The ghost pass of `key` is then this very call again."""
+        return _TapeCtx(self, (key,), "record", 0, batch_n=n)
 
     def ghost(self, key, compute=False):
         """compute=True: the batched call computes for real with the recorded dropout seeds (the reference the tests hold the tape to)."""
-        return _TapeCtx(self, key, "compute" if compute else "ghost", 0)
+        return _TapeCtx(self, (key,), "compute" if compute else "ghost", 0)
 
     def take(self, shape, dtype, device):
         if self.mode == "compute":
             return torch.empty(shape, dtype=dtype, device=device)
         bufs, i = self.bufs[self.key], self.i
         self.i += 1
+        if self.mode == "record" and self.batch_n:
+            n = self.batch_n
+            assert shape[0] % n == 0, f"tape {self.key!r}: batched allocation {i} of {tuple(shape)} does not split into {n} steps"
+            per = shape[0] // n
+            full = (self.T * per,) + tuple(shape[1:])
+            if i == len(bufs):
+                bufs.append(torch.empty(full, dtype=dtype, device=device))
+            b = bufs[i]
+            if tuple(b.shape) != full or b.dtype != dtype:
+                _KEEPALIVE.append(b)                    # an older capture may still write here
+                b = bufs[i] = torch.empty(full, dtype=dtype, device=device)
+            return b[:n * per]
         if self.mode == "record":
             full = (self.T * shape[0],) + tuple(shape[1:])
             if i == len(bufs):
@@ -150,14 +197,28 @@ class EpisodeTape:
         return seeds[si]
 
 
+class _TapeUse:
+    def __init__(self, tape, key):
+        self.tape, self.key, self.prev = tape, key, None
+
+    def __enter__(self):
+        self.prev = self.tape._swap(self.key)
+        return self.tape
+
+    def __exit__(self, *exc):
+        self.tape._swap(self.prev)
+        return False
+
+
 class _TapeCtx:
-    def __init__(self, tape, key, mode, t):
-        self.a = (tape, key, mode, t)
+    def __init__(self, tape, keys, mode, t, batch_n=None):
+        self.a = (tape, keys, mode, t)
+        self.batch_n = batch_n
         self.ng = torch.no_grad() if mode == "record" else None
 
     def __enter__(self):
-        tape, key, mode, t = self.a
-        tape._enter(key, mode, t)
+        tape, keys, mode, t = self.a
+        tape._enter(keys, mode, t, self.batch_n)
         if self.ng is not None:
             self.ng.__enter__()
         return tape
@@ -166,11 +227,12 @@ class _TapeCtx:
         tape = self.a[0]
         if self.ng is not None:
             self.ng.__exit__(*exc)
-        n_alloc, n_seed = tape._exit()
+        counts = tape._exit()
         if exc[0] is None and self.a[2] != "compute":
-            assert n_alloc == len(tape.bufs[self.a[1]]) and n_seed == len(tape.seeds[self.a[1]]), \
-                f"tape {self.a[1]!r}: {self.a[2]} pass made {n_alloc} allocations / {n_seed} seed draws, step 0 made " \
-                f"{len(tape.bufs[self.a[1]])} / {len(tape.seeds[self.a[1]])}"
+            for key, (n_alloc, n_seed) in counts.items():
+                assert n_alloc == len(tape.bufs[key]) and n_seed == len(tape.seeds[key]), \
+                    f"tape {key!r}: {self.a[2]} pass made {n_alloc} allocations / {n_seed} seed draws, step 0 made " \
+                    f"{len(tape.bufs[key])} / {len(tape.seeds[key])}"
         return False
 
 
@@ -386,6 +448,144 @@ def gemm_nt2(a, b, bias=(None, None), act=0, residual=(None, None), preact=(None
             variant = _GEMM_BEST[key] = _pick([16 + u for u in NN_VARIANTS] if kn else _nt_variants(M0 + M1, K, a0.dtype), launch)
     launch(variant)
     return outs
+
+
+def _use(key):
+    """Allocations / seed draws of one problem of a lockstep recorded step go to tape key `key` (None: the active key)."""
+    import contextlib
+    return _TAPE.use(key) if (_TAPE is not None and key is not None) else contextlib.nullcontext()
+
+
+class fork:
+    """`with fork(side): ...` queues the body on stream `side` behind everything queued on the current stream so far; join() makes the current
+    stream wait for it. Inside a captured step these are graph edges: two small kernels of independent problems (the panorama's attention
+    beside the two streams' dual attention, its LayerNorm beside theirs) run side by side instead of back to back. side=None: no-op."""
+
+    def __init__(self, side):
+        self.side = side
+        self.main = torch.cuda.current_stream() if side is not None else None
+        self.ctx = None
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.main)
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            self.ctx = None
+        return False
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+
+
+def gemm_ntn(a, b, bias=None, act=0, residual=None, preact=None, dact_src=None, dact=0, drop=None, keys=None):
+    """n <= 4 GEMMs with the same (N, K) and epilogue kind in ONE launch (vlni_gemm_nt_multi): out_i = epi(a_i @ b_i^T). Every per-problem
+    argument is a sequence of n; drop = (p, seeds); keys: per problem the episode-tape key its output belongs to (lockstep recorded
+    steps, EpisodeTape.use). Returns the n outputs. n = 2 is gemm_nt2's launch."""
+    n = len(a)
+    none = (None,) * n
+    bias, residual, preact, dact_src, keys = bias or none, residual or none, preact or none, dact_src or none, keys or none
+    K = a[0].shape[1]
+    N = b[0].shape[0]
+    dt = a[0].dtype
+    assert 1 <= n <= 4 and all(x.shape[1] == K and x.dtype == dt and x.stride(1) == 1 for x in a)
+    assert all(w.shape == b[0].shape and w.dtype == dt and w.stride(1) == 1 for w in b) and b[0].shape[1] == K
+    outs = []
+    for i in range(n):
+        with _use(keys[i]):
+            outs.append(_new((a[i].shape[0], N), dt, a[i].device))
+    if _ghost():
+        return tuple(outs)
+    vp, lg = ctypes.c_void_p, ctypes.c_long
+    ptrs = lambda ts: (vp * n)(*[_p(t) for t in ts])
+    lds = lambda ts: (lg * n)(*[t.stride(0) if t is not None else 0 for t in ts])
+    Ms = [x.shape[0] for x in a]
+    if drop is not None and drop[0] <= 0.0:
+        drop = None
+    seeds = (ctypes.c_uint * n)(*([_shift(drop[1][i], Ms[i] * N) for i in range(n)] if drop else [0] * n))
+    cargs = (_dt(a[0]), n, ptrs(a), lds(a), ptrs(b), lds(b), ptrs(outs), lds(outs), (ctypes.c_int * n)(*Ms), N, K,
+             ptrs(bias), act, ptrs(residual), lds(residual), ptrs(preact), lds(preact), ptrs(dact_src), lds(dact_src), dact)
+    launch = lambda v: _lib.call("vlni_gemm_nt_multi", *cargs, v, drop[0] if drop else 0.0, seeds, _st())
+    variant = 0
+    if AUTOTUNE:
+        key = (dt, tuple(Ms), N, K, act, dact, residual[0] is not None, preact[0] is not None, "n")
+        variant = _GEMM_BEST.get(key)
+        if variant is None and torch.cuda.is_current_stream_capturing():
+            variant = 0
+        elif variant is None:
+            variant = _GEMM_BEST[key] = _pick(_nt_variants(sum(Ms), K, dt), launch)
+    launch(variant)
+    return tuple(outs)
+
+
+def rec_self_att3(xs, kms, drops, Ps, eps, keys, side=None):
+    """RECORD-mode forward (episode tape, no autograd) of _DualSelfAttBlock(x0, x1) + _SelfAttBlock(x2) in lockstep: the two projections of all
+    three problems run as 3-problem GEMM launches (the history panorama encoder's layer beside the language / vision streams of the
+    cross-modal layer with the same (N, K, epilogue): vilmodel_cmt.py:399-407 and :216-239 under :603-614). keys = (key of problems 0 / 1,
+    key of problem 2): every activation is allocated under its own call's tape key, in the order that call's ghost pass asks for it
+    (_DualSelfAttBlock.forward / _SelfAttBlock.forward), so the episode-batched backward runs the UNMERGED autograd nodes on these buffers."""
+    assert _TAPE is not None and _TAPE.mode == "record"
+    kv, kh = keys
+    k3 = (kv, kv, kh)
+    x0, x1, x2 = xs
+    (B, S0, H), S1, (B2, S2, _) = x0.shape, x1.shape[1], x2.shape
+    a = [_rows(_chk(x, "x")) for x in xs]
+    dt = x0.dtype
+    wqkv = [_w((P[0], P[2], P[4]), dt) for P in Ps]
+    bqkv = [_w((P[1], P[3], P[5]), torch.float32) for P in Ps]
+    q = gemm_ntn(a, wqkv, bias=bqkv, keys=k3)
+    d0, d1, d2 = drops
+    f = fork(side)                         # problem 2's attention (and LayerNorm below) beside the dual launch of problems 0 / 1
+    with f, _use(kh):
+        c2, _ = attn_fwd(q[2][:, :H], q[2][:, H:2 * H], q[2][:, 2 * H:], B2, S2, S2, kms[2], None, drop=(d2[0], d2[2]))
+    with _use(kv):
+        (c0, _), (c1, _) = attn_fwd2((q[0][:, :H], q[1][:, :H]), (q[0][:, H:2 * H], q[1][:, H:2 * H]), (q[0][:, 2 * H:], q[1][:, 2 * H:]), B,
+                                     (S0, S1), (S0, S1), (kms[0], kms[1]), None, drop=(max(d0[0], d1[0]), (d0[2], d1[2])))
+    f.join()
+    ph = max(d0[1], d1[1])
+    assert ph == d2[1], "lockstep blocks: one hidden-dropout probability"
+    pre = gemm_ntn((c0, c1, c2), [_w((P[6],), dt) for P in Ps], bias=[P[7] for P in Ps], residual=a,
+                   drop=(ph, (d0[2] + 1, d1[2] + 1, d2[2] + 1)), keys=k3)
+    f = fork(side)
+    with f, _use(kh):
+        y2, _, _ = ln_fwd(pre[2], Ps[2][8], Ps[2][9], eps)
+    with _use(kv):
+        (y0, _, _), (y1, _, _) = ln_fwd2((pre[0], pre[1]), (Ps[0][8], Ps[1][8]), (Ps[0][9], Ps[1][9]), eps)
+    f.join()
+    return y0.view(B, S0, H), y1.view(B, S1, H), y2.view(B2, S2, H)
+
+
+def rec_ffn3(xs, drops, Ps, eps, keys, side=None):
+    """RECORD-mode forward of _DualFfnBlock(x0, x1) + _FfnBlock(x2) in lockstep (see rec_self_att3): FFN-in and FFN-out as 3-problem launches."""
+    assert _TAPE is not None and _TAPE.mode == "record"
+    kv, kh = keys
+    k3 = (kv, kv, kh)
+    shp = [x.shape for x in xs]
+    a = [_rows(_chk(x, "x")) for x in xs]
+    dt = xs[0].dtype
+    FF = Ps[0][0].shape[0]
+    z = []
+    for i in range(3):
+        with _use(k3[i]):
+            z.append(_new((a[i].shape[0], FF), dt, a[i].device))
+    h = gemm_ntn(a, [_w((P[0],), dt) for P in Ps], bias=[P[1] for P in Ps], act=_gelu_codes(dt)[0], preact=z, keys=k3)
+    d0, d1, d2 = drops
+    ph = max(d0[1], d1[1])
+    assert ph == d2[1], "lockstep blocks: one hidden-dropout probability"
+    pre = gemm_ntn(h, [_w((P[2],), dt) for P in Ps], bias=[P[3] for P in Ps], residual=a, drop=(ph, (d0[2], d1[2], d2[2])), keys=k3)
+    f = fork(side)
+    with f, _use(kh):
+        y2, _, _ = ln_fwd(pre[2], Ps[2][4], Ps[2][5], eps)
+    with _use(kv):
+        (y0, _, _), (y1, _, _) = ln_fwd2((pre[0], pre[1]), (Ps[0][4], Ps[1][4]), (Ps[0][5], Ps[1][5]), eps)
+    f.join()
+    return y0.view(shp[0]), y1.view(shp[1]), y2.view(shp[2])
 
 
 def transpose_pad(x, rpad, dtype=None):
