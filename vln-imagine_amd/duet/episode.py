@@ -2,6 +2,8 @@
 and the loss assembly (VLN-DUET/map_nav_src/r2r/agent.py:409-500 modes, :468-479 node embeddings, :541 CE sum,
 :616-623 loss = ml * train_ml / B + 0.5 * aux). `model(mode, batch)` is anything with the
 GlocalTextPathNavCMT.forward contract (models/vilmodel.py:1237-1288)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -27,6 +29,9 @@ class DuetEpisodeTensors:
                     idx[b, j + 1] = base[src[1]] + (0 if src[0] == "avg" else 1 + src[2])
             S_t = int(base[t_ + 1])                                    # bank rows per sample once step t_'s panorama is in
             self.node_idx.append(t((idx + np.arange(ep.B)[:, None] * S_t).reshape(-1)))
+
+
+_PANORAMA_UPFRONT = os.environ.get("VLNI_PANORAMA_UPFRONT", "1") == "1"     # A/B switch (round 5): TapedEpisode(upfront_panorama=True)
 
 
 def ce_sum(logits, target):
@@ -165,9 +170,13 @@ class TapedEpisode:
     a rollout fills as it goes), finish() all of them."""
 
     def __init__(self, model, et, tape=None, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, ghost_compute=False,
-                 feat_dropout=0.0):
+                 feat_dropout=0.0, upfront_panorama=False):
         from vln_imagine_amd import ops
         self.model, self.et, self.B, self.T = model, et, et.B, et.T
+        # teacher forcing (the ground-truth path's panoramas are known when the episode starts, agent.py:449-467): the T `panorama` calls as
+        # ONE call on T x B samples in begin() (EpisodeTape.record_steps) - 6.9 k-row launches instead of T x 1.2 k-row ones, and the steps
+        # are `navigation` calls only. Off for rollouts with the host in the loop (the next viewpoint is the agent's choice).
+        self.upfront = bool(upfront_panorama) and _PANORAMA_UPFRONT
         # the wrapper's feature dropout on the panorama image features (VLNBert.drop_env, model.py:20): the drivers call the model itself,
         # so it is applied here with the tape's counter-based masks (step, ghost pass and batched backward see the same mask)
         self.feat_dropout = float(feat_dropout)
@@ -208,20 +217,34 @@ class TapedEpisode:
             bank = tape._bank = torch.zeros((ZERO + 1, H), dtype=dt, device=dev)
             tape._vpbuf = torch.zeros((T, B, 1 + P, H), dtype=dt, device=dev)
         self.bank, self.bank4, self.vpbuf = bank, bank[:ZERO].view(T, B, P + 1, H), tape._vpbuf
+        if self.upfront:
+            from vln_imagine_amd import ops
+            model, full = self.model, self.full
+            with tape.record_steps("panorama", T):               # the call the ghost pass repeats (_batched)
+                pano_all, _ = model("panorama", {"view_img_fts": self._drop(full["view_img_fts"]), "obj_img_fts": None, "loc_fts": full["loc_fts"],
+                                                 "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None,
+                                                 "pano_masks": full["pano_masks"]})
+            with torch.no_grad():
+                pano4 = pano_all.view(T, B, P, H)
+                self.bank4[:, :, 0] = ops.seq_mean(pano_all, full["view_lens"]).view(T, B, H)     # masked mean, agent.py:468-469
+                self.bank4[:, :, 1:] = pano4
+                self.vpbuf[:, :, 1:] = pano4
 
     def step(self, t):
         from vln_imagine_amd import ops
         model, tape, B, st = self.model, self.tape, self.B, self.steps[t]
-        with tape.record("panorama", t):
-            pano, pmask = model("panorama", {"view_img_fts": self._drop(st["view_img_fts"]), "obj_img_fts": None, "loc_fts": st["loc_fts"],
-                                             "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": None,
-                                             "pano_masks": st["pano_masks"]})
+        if not self.upfront:
+            with tape.record("panorama", t):
+                pano, pmask = model("panorama", {"view_img_fts": self._drop(st["view_img_fts"]), "obj_img_fts": None, "loc_fts": st["loc_fts"],
+                                                 "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": None,
+                                                 "pano_masks": st["pano_masks"]})
         with torch.no_grad():
-            self.bank4[t, :, 0] = ops.seq_mean(pano, st["view_lens"])                 # masked mean, agent.py:468-469
-            self.bank4[t, :, 1:] = pano
+            if not self.upfront:
+                self.bank4[t, :, 0] = ops.seq_mean(pano, st["view_lens"])             # masked mean, agent.py:468-469
+                self.bank4[t, :, 1:] = pano
+                self.vpbuf[t][:, 1:] = pano
             gmap_img = self.bank.index_select(0, self.idx[t].reshape(-1)).view(B, self.Gmax, -1)
             vp_img = self.vpbuf[t]
-            vp_img[:, 1:] = pano
         with tape.record("navigation", t):
             nav = model("navigation", _nav_batch(st, gmap_img, vp_img, self.kv_g, self.kv_l, self.lm))
         self.step_logits.append(nav["fused_logits"])
@@ -262,7 +285,8 @@ class TapedEpisode:
 def run_episode_taped(model, et, tape=None, use_aux=True, train_ml=0.2, cosine_weight=0.5, criterion=ce_sum, on_step=None,
                       ghost_compute=False, feat_dropout=0.0):
     """One episode through TapedEpisode: begin, T steps (`on_step(t, fused_logits)` may pick the next viewpoint), finish."""
-    te = TapedEpisode(model, et, tape, use_aux, train_ml, cosine_weight, criterion, ghost_compute, feat_dropout)
+    te = TapedEpisode(model, et, tape, use_aux, train_ml, cosine_weight, criterion, ghost_compute, feat_dropout,
+                      upfront_panorama=on_step is None)          # nobody picks viewpoints between the steps: teacher forcing
     te.begin()
     for t in range(et.T):
         lg = te.step(t)
