@@ -856,6 +856,39 @@ def main():
         trd.close()
         del wd, trd
 
+    # The number an UNCHANGED reference agent gets: the VLNBertCMT / VLNBert wrappers called eagerly mode by mode,
+    # plain autograd, clip_grad_norm_, torch.optim.AdamW - no episode tape, no FlatTrainer, no captured graph (vln_imagine_amd/dropin.py =
+    # agent_cmt.py:400-700,827-832 / agent.py:409-500 + agent_base.py:223-228). Host-bound: wall clock over whole iterations.
+    if world == 1 and not forced and not args.no_extras and not shipped:
+        import gc
+        from vln_imagine_amd import dropin
+        drop = {}
+        for fam, bsz in ((("hamt", args.batch), ("duet", 32)) if (args.model == "hamt" and args.dtype == "bf16") else ((args.model, args.batch),)):
+            gc.collect()
+            torch.cuda.empty_cache()
+            wx = Workload(fam, args, False, dev, dtype, batch=bsz, tag=f"bench{rank}")
+            if args.train_mode:
+                wx.model.train()
+            tr = dropin.DropInTrainer((dropin.wrap_hamt if fam == "hamt" else dropin.wrap_duet)(wx.model, feat_dropout=0.4 if args.train_mode else 0.0),
+                                      wx.et, fam)
+            for _ in range(3):
+                tr.step()
+            torch.cuda.synchronize()
+            kx = 6
+            t0 = time.perf_counter()
+            for _ in range(kx):
+                loss_x = tr.step()
+            torch.cuda.synchronize()
+            sx = (time.perf_counter() - t0) / kx
+            log(f"drop-in eager ({fam}, batch {bsz}): {1e3 * sx:.2f} ms per iteration, loss {float(loss_x):.4f}")
+            drop[fam] = {"value": round(bsz / sx, 2), "unit": "episodes/s", "ms_per_step": round(1e3 * sx, 3), "batch": bsz, "iterations": kx,
+                         "step_algorithmic_tflops": round(wx.flops / sx / 1e12, 2)}
+            del tr, wx
+        drop["note"] = ("an unchanged reference agent on the drop-in modules: wrappers called eagerly per mode / step, plain autograd, clip_grad_norm_, "
+                        "torch.optim.AdamW (host-bound: every kernel is a Python -> C-ABI crossing; the optimizer's writes invalidate the 16-bit weight "
+                        "shadows each step); the headline needs the trainer of INTEGRATION.md section 4")
+        extras["drop_in_eager"] = drop
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, shipped)

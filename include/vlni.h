@@ -317,6 +317,21 @@ int vlni_adamw_step_groups(float* p, const float* g, float* m, float* v, void* s
    averaging with bf16 compression, r2r/agent_cmt.py:61-63); src 16-byte, dst 8-byte aligned */
 int vlni_scale_cast(int dt_in, int dt_out, const void* src, void* dst, long n, float scale, void* stream);
 
+/* SURVEY.md section 8(b) lists a minimum operator set by name; four of those names are these entry points (same signatures):
+ *   vlni_gemm_bias_act_fwd / _bwd        -> vlni_gemm_nt (forward: bias + act epilogue; backward: the dgrad launch with dact / dact_src)
+ *   vlni_embed_sum_layernorm_fwd / _bwd  -> vlni_sum_layernorm_fwd / vlni_layernorm_bwd (+ vlni_scatter_add_rows for gathered tables)
+ *   vlni_cosine_loss_fwd / _bwd          -> vlni_cosine_fwd / vlni_cosine_bwd (the alignment head's 1 - cos terms, R:737-790)
+ *   vlni_masked_fill_head_fwd / _bwd     -> vlni_rowdot_fwd / vlni_rowdot_bwd (Linear(768 -> 1) + masked_fill(-inf), R:953-963,1200)
+ * vlni_attn_fwd/bwd, vlni_bias_residual_layernorm_fwd/bwd and vlni_segment_mean_fwd/bwd carry the survey's names already. */
+#define vlni_gemm_bias_act_fwd vlni_gemm_nt
+#define vlni_gemm_bias_act_bwd vlni_gemm_nt
+#define vlni_embed_sum_layernorm_fwd vlni_sum_layernorm_fwd
+#define vlni_embed_sum_layernorm_bwd vlni_layernorm_bwd
+#define vlni_cosine_loss_fwd vlni_cosine_fwd
+#define vlni_cosine_loss_bwd vlni_cosine_bwd
+#define vlni_masked_fill_head_fwd vlni_rowdot_fwd
+#define vlni_masked_fill_head_bwd vlni_rowdot_bwd
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,3 +45,13 @@ def test_bench_exchange_pipeline_through_a_one_rank_rccl_communicator():
     assert d["config"]["launch"].startswith("hipGraph replay") and "ranges" in d["config"]["launch"], d["config"]["launch"]
     assert d["config"]["rccl"]["exchange"]["ranges"] >= 3
     assert d["roofline"] is not None and d["value"] > 0
+
+
+def test_bench_two_ranks_duet_float16_configs4_argument_path():
+    """BASELINE.json configs[4]: DUET, data parallel, float16 + dynamic loss scale, alignment head on - the first 8-GPU driver run of that
+    configuration must not die on an argument path. Two gloo ranks on the one GPU; what cannot be shown here is bytes on xGMI."""
+    d = _job("bench2_duet_f16")
+    assert d["n_gpus"] == 2 and d["dtype"] == "fp16" and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 16
+    assert d["metric"].startswith("episodes/sec (fwd+bwd) DUET") and d["value"] > 0
+    assert d["config"]["launch"].startswith("hipGraph replay"), d["config"]["launch"]
+    assert d["config"]["rccl"]["world_size"] == 2 and d["config"]["rccl"]["exchange"]["ranges"] >= 3

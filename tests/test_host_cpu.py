@@ -292,6 +292,27 @@ def test_bench_starts_its_own_ranks():
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
 
 
+def test_bench_eight_rank_launch_paths_dry_run():
+    """The driver's scaling run is `bench.py --gpus 8` (BASELINE.json configs[2]) and, for configs[4], `--model duet --dtype fp16`: both
+    through the launcher's own rank start-up AND through torchrun's environment (the driver's form), no GPU work (VLNI_BENCH_DRY_RUN)."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for extra in ([], ["--model", "duet", "--dtype", "fp16", "--steps", "20", "--warmup", "5"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"] + extra, env=dict(env, VLNI_BENCH_DRY_RUN="1"),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 8 and sorted(map(tuple, line["ranks"])) == [(i, i) for i in range(8)], line
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=dict(env, VLNI_BENCH_DRY_RUN="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert line == {"n_gpus": 2, "ranks": [[0, 0], [1, 1]]}
+
+
 def test_duet_static_episode_buffers_hold_the_padded_episode():
     """duet.buckets.DuetEpisodeBuffers (what the captured DUET graphs read) == the padded step inputs duet.episode._taped_inputs builds from a
     resident episode: same tensors inside the bucket, masked / neutral values in the padding, the same node -> bank-row table, and the fusion

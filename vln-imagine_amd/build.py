@@ -18,6 +18,9 @@ if os.environ.get("VLNI_DIAG") == "1":       # stamped / timing-only kernel buil
     FLAGS.append("-DVLNI_DIAG")
 
 
+LAST = {}        # what the last build() call did: {"compiled": [sources], "linked": bool, "reused": bool}
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -26,6 +29,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
+    force = force or os.environ.get("VLNI_FORCE_BUILD") == "1"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
@@ -50,11 +54,18 @@ def build(force=False, verbose=True):
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(cc, jobs))
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    linked = False
     if force or jobs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+        linked = True
+    # one line that tells a build from a no-op (`build_exercised` was not observable)
+    LAST.update(compiled=[os.path.basename(s) for s, _ in jobs], linked=linked, reused=not jobs and not linked)
+    if verbose:
+        sys.stderr.write(f"[vlni build] compiled {len(jobs)}/{len(SOURCES)} sources for gfx950 ({', '.join(LAST['compiled']) or 'none'}), "
+                         f"{'linked' if linked else 'kept'} {os.path.relpath(LIB)}" + (" (up to date: reused)" if LAST['reused'] else "") + "\n")
     return LIB
 
 

@@ -270,6 +270,22 @@ P8H_MIN_ROWS = int(os.environ.get("VLNI_P8H_MIN_ROWS", "1024"))
 _GEMM_BEST = {}
 
 
+def export_tune():
+    """The kernel choices of this process (GEMM pipeline per launch shape, weight-gradient variant x split) as plain JSON-able lists."""
+    enc = lambda k: [str(x) if isinstance(x, torch.dtype) else (list(x) if isinstance(x, tuple) else x) for x in k]
+    return {"gemm": [[enc(k), v] for k, v in _GEMM_BEST.items()], "tn": [[list(k), list(v)] for k, v in _TN_BEST.items()],
+            "tnb": [[list(k), list(v)] for k, v in _TNB_BEST.items()]}
+
+
+def import_tune(obj):
+    """Adopts choices written by export_tune() (bench.py --load-tune: the counter passes then launch the timed run's kernels)."""
+    dts = {str(d): d for d in (torch.float32, torch.bfloat16, torch.float16)}
+    dec = lambda k: tuple(dts.get(x, x) if isinstance(x, str) else (tuple(x) if isinstance(x, list) else x) for x in k)
+    _GEMM_BEST.update({dec(k): v for k, v in obj["gemm"]})
+    _TN_BEST.update({tuple(k): tuple(v) for k, v in obj["tn"]})
+    _TNB_BEST.update({tuple(k): tuple(v) for k, v in obj["tnb"]})
+
+
 def _nt_variants(rows, K, dtype):
     v = GEMM_VARIANTS
     if dtype in H16 and len(v) > 1:
