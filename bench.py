@@ -437,10 +437,9 @@ def main():
         return dt / steps, launch, float(loss.detach()), eager
 
     if args.load_tune:
-        import pickle
-        with open(args.load_tune, "rb") as fh:
-            tn = pickle.load(fh)
-        ops._GEMM_BEST.update(tn["gemm"]); ops._TN_BEST.update(tn["tn"]); ops._TNB_BEST.update(tn["tnb"])
+        with open(args.load_tune) as fh:                  # JSON written by --dump-tune (ops.export_tune): plain data, no object deserialisation
+            tn = json.load(fh)
+        ops.import_tune(tn)
         log(f"kernel choices loaded from {args.load_tune}: {len(tn['gemm'])} GEMM shapes, {len(tn['tn']) + len(tn['tnb'])} weight-gradient classes")
 
     # ---- the metric's workload -------------------------------------------------------------------------------------------
@@ -455,9 +454,8 @@ def main():
     ms = sec * 1e3
     eps = args.batch * world / sec
     if args.dump_tune and rank == 0:
-        import pickle
-        with open(args.dump_tune, "wb") as fh:
-            pickle.dump({"gemm": dict(ops._GEMM_BEST), "tn": dict(ops._TN_BEST), "tnb": dict(ops._TNB_BEST)}, fh)
+        with open(args.dump_tune, "w") as fh:
+            json.dump(ops.export_tune(), fh)
 
     # ---- roofline of the dominant kernel family (instrumented pass, not part of the timed region) -----------------------------
     def roofline_of(w, sec, eager_step, family, with_ceiling=True):
