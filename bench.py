@@ -463,7 +463,7 @@ def main():
         weight-gradient and attention families of the same step. Not part of any timed region."""
         ms = sec * 1e3
         from vln_imagine_amd import _lib
-        rec, epi, fam = [], [0.0], []
+        rec, epi, fam, wg_bytes = [], [0.0], [], [0.0]
         orig_call = _lib.call
         FAM = ("vlni_gemm_tn_h16_grouped_part", "vlni_gemm_tn_h16_grouped_v", "vlni_reduce_parts", "vlni_attn_bwd_dual", "vlni_attn_bwd", "vlni_attn_fwd_dual",
                "vlni_attn_fwd")
@@ -478,7 +478,9 @@ def main():
             es_ = 2
             if name.startswith("vlni_gemm_tn"):                     # (dtype, nseg, A, B, M[], lda/N, ldb/K, ...): 2 sum(M) N K flop
                 n_, pm_ = a_[1], a_[4]
-                work = 2.0 * sum(pm_[i] for i in range(n_)) * a_[9] * a_[10]
+                rows_ = sum(pm_[i] for i in range(n_))
+                work = 2.0 * rows_ * a_[9] * a_[10]
+                wg_bytes[0] += 2.0 * rows_ * (a_[9] + a_[10]) + 4.0 * a_[9] * a_[10]        # dY and X read once (16-bit), dW written once (float32)
             elif name == "vlni_reduce_parts":
                 work = 0.0
             elif name.endswith("_dual"):                            # (..., B, nh, Sq[2], Sk[2], ...): bytes of q, k, v, out (+ dout, dq, dk, dv)
@@ -566,12 +568,16 @@ def main():
                 log(f"gemm M={shp[0]:6d} N={shp[1]:5d} K={shp[2]:5d} {kind:34s}: {n:4d} calls {ms_:7.3f} ms {ms_ / n * 1e3:7.1f} us each {f / ms_ / 1e9:7.1f} TF/s"
                     f"  over 0.32 of peak: {ms_ - f / (0.32 * peak * 1e9):6.3f} ms")
         ach = tot_f / (tot_ms * 1e-3) / 1e12
-        traffic, traffic_src = None, None
+        traffic, traffic_src, wg_traffic = None, None, None
         try:      # HBM bytes per launch: separate rocprofv3 --pmc passes of this command (never collected inside a timed run)
             pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
                          if f.endswith("_pmc_traffic.json") and ("duet" in f) == (family == "duet"))
             if pmc and args.dtype == "bf16" and args.mode == "taped" and args.train_mode:      # collected on the default workloads only
-                traffic = round(json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))["bytes_per_launch"])
+                pj = json.load(open(os.path.join(ROOT, "profiles", pmc[-1])))
+                traffic = round(pj["bytes_per_launch"])
+                tn_ = [v for k_, v in pj.get("per_family_kb_per_launch", {}).items() if k_.startswith("gemm_tn")]
+                if tn_:                            # weight-gradient kernels: FETCH_SIZE doubled (gfx950 correction) + WRITE_SIZE, per launch
+                    wg_traffic = round(sum((2.0 * v["fetch_raw"] + v["write"]) * 1024.0 * v["launches"] for v in tn_) / sum(v["launches"] for v in tn_))
                 traffic_src = f"profiles/{pmc[-1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; not measured in this run)"
         except Exception:
             traffic = None
@@ -610,7 +616,10 @@ def main():
         nr_, _, tr_ = fam_sum(("vlni_reduce_parts",))
         if n_:
             families["weight_gradients"] = {"bound": "mfma", "launches": n_, "ms": round(t_, 3), "achieved": round(f_ / (t_ * 1e-3) / 1e12, 1), "unit": "TFLOP/s",
-                                            "frac": round(f_ / (t_ * 1e-3) / 1e12 / peak, 4), "partial_reduction_ms": round(tr_, 3)}
+                                            "frac": round(f_ / (t_ * 1e-3) / 1e12 / peak, 4), "partial_reduction_ms": round(tr_, 3),
+                                            # dY and X read once, dW written once per launch; traffic from the same --pmc passes as `roofline.traffic`
+                                            "algorithmic_bytes": round(wg_bytes[0] / n_), "traffic": wg_traffic,
+                                            "traffic_ratio": round(wg_traffic / (wg_bytes[0] / n_), 3) if wg_traffic else None}
         for key_, pre_ in (("attention_bwd", ("vlni_attn_bwd",)), ("attention_fwd", ("vlni_attn_fwd",))):
             n_, by_, t_ = fam_sum(pre_)
             if n_:

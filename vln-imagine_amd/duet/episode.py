@@ -153,7 +153,7 @@ def _nav_batch(st, gmap_img, vp_img, kvg, kvl, mask):
             "gmap_pair_dists": st["gmap_pair_dists"], "gmap_visited_masks": st["gmap_visited_masks"], "gmap_vpids": st["gmap_vpids"],
             "vp_img_embeds": vp_img, "vp_pos_fts": st["vp_pos_fts"], "vp_masks": st["vp_masks"], "vp_nav_masks": st["vp_nav_masks"],
             "vp_obj_masks": None, "vp_cand_vpids": st["vp_cand_vpids"], "imagine_embeds": None, "imagine_masks": None,
-            "fuse_plan": st.get("fuse_plan")}
+            "fuse_plan": st.get("fuse_plan"), "masks_add": st.get("masks_add")}
 
 
 class TapedEpisode:
@@ -220,6 +220,10 @@ class TapedEpisode:
         if self.upfront:
             from vln_imagine_amd import ops
             model, full = self.model, self.full
+            # teacher forcing knows the maps of all steps: the additive forms of their masks in two launches instead of two per step
+            gm_all, vm_all = ops.additive_mask(full["gmap_masks"]), ops.additive_mask(full["vp_masks"])
+            self.full = full = dict(full, masks_add=(gm_all, vm_all))
+            self.steps = [dict(st, masks_add=(gm_all[t * B:(t + 1) * B], vm_all[t * B:(t + 1) * B])) for t, st in enumerate(self.steps)]
             with tape.record_steps("panorama", T):               # the call the ghost pass repeats (_batched)
                 pano_all, _ = model("panorama", {"view_img_fts": self._drop(full["view_img_fts"]), "obj_img_fts": None, "loc_fts": full["loc_fts"],
                                                  "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None,

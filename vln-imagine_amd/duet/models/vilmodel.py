@@ -292,9 +292,10 @@ class GlocalTextPathNavCMT(nn.Module):
     def forward_navigation_per_step(self, txt_embeds, txt_masks, gmap_img_embeds, gmap_step_ids, gmap_pos_fts, gmap_masks,
                                     gmap_pair_dists, gmap_visited_masks, gmap_vpids, vp_img_embeds, vp_pos_fts, vp_masks,
                                     vp_nav_masks, vp_obj_masks, vp_cand_vpids, imagine_embeds=None, imagine_masks=None, text_kv=None,
-                                    fuse_plan=None):
+                                    fuse_plan=None, masks_add=None):
         """fuse_plan = (src [B,G] int32, bw [B,V] uint8): the caller's own index plan of the global / local fusion (fuse_plan() lists as device
-        tensors, e.g. static buffers a captured graph reads); default: built from gmap_vpids / vp_cand_vpids here and cached."""
+        tensors, e.g. static buffers a captured graph reads); default: built from gmap_vpids / vp_cand_vpids here and cached.
+        masks_add = (additive_mask(gmap_masks), additive_mask(vp_masks)) where an episode driver converted the masks of all steps at once."""
         c, dt = self.config, self.compute_dtype
         ge, le = self.global_encoder, self.local_encoder
         B, G = gmap_masks.shape
@@ -339,7 +340,7 @@ class GlocalTextPathNavCMT(nn.Module):
         else:
             txt, lm = language_side()
         gmap, vp = gmap.contiguous(), vp.contiguous()
-        gm, vm = ops.additive_mask(gmap_masks), ops.additive_mask(vp_masks)
+        gm, vm = masks_add if masks_add is not None else (ops.additive_mask(gmap_masks), ops.additive_mask(vp_masks))
         if DUAL_BRANCHES and kv_g is not None:
             # the global-map and local-viewpoint branches are independent and have the same layer shapes: layer i of both runs as
             # dual-problem GEMM launches (each branch alone is 2-10 row tiles, far below one wave of CUs)
@@ -429,5 +430,6 @@ class GlocalTextPathNavCMT(nn.Module):
                 batch["gmap_pos_fts"], batch["gmap_masks"], batch["gmap_pair_dists"], batch["gmap_visited_masks"],
                 batch["gmap_vpids"], batch["vp_img_embeds"], batch["vp_pos_fts"], batch["vp_masks"], batch["vp_nav_masks"],
                 batch.get("vp_obj_masks"), batch["vp_cand_vpids"], imagine_embeds=batch.get("imagine_embeds"),
-                imagine_masks=batch.get("imagine_masks"), text_kv=batch.get("text_kv"), fuse_plan=batch.get("fuse_plan"))
+                imagine_masks=batch.get("imagine_masks"), text_kv=batch.get("text_kv"), fuse_plan=batch.get("fuse_plan"),
+                masks_add=batch.get("masks_add"))
         raise NotImplementedError("wrong mode: %s" % mode)

@@ -423,6 +423,8 @@ class TapedEpisode:
         else:
             hist = prefix.permute(1, 0, 2).unsqueeze(0) * valid.to(h_all.dtype)[:, :, :, None]        # zeros beyond the valid entries
         rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+        if self.ls is not None and getattr(getattr(model, "config", None), "concat_imagine_with", None) == "language":
+            rep = lambda x: x          # the language side is handed over ready-made (lang_side=): `visual` only checks these for presence
         with tape.ghost("visual", compute=self.ghost_compute):
             logits, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=rep(self.txt), txt_masks=rep(et.txt_masks), hist_embeds=hist.reshape(T * B, T, H), hist_masks=hm_full,

@@ -526,7 +526,10 @@ class LangSide:
 
     def repeat(self, T):
         rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
-        return LangSide(rep(self.lang), rep(self.lm), self.nt, rep(self.qkv) if self.qkv is not None else None)
+        # with the projections handed over, `lang` enters the first cross-modal layer as a residual only (ops._XAttPairGivenQBlock: its backward
+        # never reads it): no copies inside a tape's ghost pass. Without them the layer projects `lang` itself and its weight gradient reads it.
+        lang = ops.repeat_unread(self.lang, T) if self.qkv is not None else rep(self.lang)
+        return LangSide(lang, rep(self.lm), self.nt, rep(self.qkv) if self.qkv is not None else None)
 
 
 class NavCMT(nn.Module):

@@ -2368,6 +2368,28 @@ def gate_rows(visn, lang, r0, n):
 NO_DROP = (0.0, 0.0, 0)
 
 
+class _RepeatUnread(torch.autograd.Function):
+    """x [n, ...] -> [T * n, ...] (T copies) for a tensor that the GHOST pass of an episode tape hands to operators which launch nothing and whose
+    backward never reads it (a residual input): inside a ghost pass the copies are not made (uninitialised memory of the right shape - 63 MB
+    of clone per episode for HAMT's language stream), anywhere else this is expand + reshape. Backward: the sum over the T copies."""
+
+    @staticmethod
+    def forward(ctx, x, T):
+        ctx.T = T
+        shape = (T * x.shape[0],) + tuple(x.shape[1:])
+        if _ghost():
+            return torch.empty(shape, dtype=x.dtype, device=x.device)
+        return x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy.reshape((ctx.T, dy.shape[0] // ctx.T) + tuple(dy.shape[1:])).sum(0), None
+
+
+def repeat_unread(x, T):
+    return _RepeatUnread.apply(x, T)
+
+
 def drop_cfg(p_attn, p_hidden, training):
     """(p_attn, p_hidden, seed) for one fused block call; zeros outside training."""
     if not training or (p_attn <= 0.0 and p_hidden <= 0.0):
