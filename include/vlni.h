@@ -317,6 +317,49 @@ int vlni_adamw_step_groups(float* p, const float* g, float* m, float* v, void* s
    averaging with bf16 compression, r2r/agent_cmt.py:61-63); src 16-byte, dst 8-byte aligned */
 int vlni_scale_cast(int dt_in, int dt_out, const void* src, void* dst, long n, float scale, void* stream);
 
+/* ---- block-level entry points (round 5; csrc/blocks.hip) -------------------------------------------------------------------------
+ * One call = one transformer SUBLAYER of one or two streams, forward or backward: the function issues the sublayer's own 4-7 launches
+ * (vlni_gemm_nt_multi, vlni_attn_*, vlni_layernorm_*) on `stream`, so an eager caller crosses the boundary once per sublayer and direction.
+ *   self-attention block  y = LN(dense(attn(x Wq, x Wk, x Wv)) + x)    BertAttention R:151-161 (R:100-134, R:144-148)
+ *   FFN block             y = LN(W2 gelu(W1 x + b1) + b2 + x)         BertIntermediate R:173-176 + BertOutput R:186-190
+ * n = 1: one stream (text encoder, history panorama encoder); n = 2: the two streams of a cross-modal layer (R:399-421) / DUET's global
+ * and local branches as dual-problem launches. Caller-owned buffers throughout; weight / bias gradients stay separate calls
+ * (vlni_gemm_tn_h16_grouped_*: dW_out = dmid_drop^T aux|mid, dW_in = dmid|daux^T x). */
+typedef struct VlniBlockSide {
+  int B, S;                                   /* samples, tokens per sample */
+  const void* x; long ldx;                    /* input [B*S, H] */
+  const float* kmask;                         /* attention: additive key mask [B, S] or NULL */
+  const void* w_in; const float* b_in;        /* attention: packed Wqkv [3H, H] / bqkv; FFN: W1 [FF, H] / b1 (weights in the compute dtype) */
+  const void* w_out; const float* b_out;      /* attention: Wo [H, H] / bo; FFN: W2 [H, FF] / b2 */
+  const void* wt_in; const void* wt_out;      /* backward: transposed weights (dgrad operands): Wqkv^T [H, 3H] / W1^T [H, FF]; Wo^T / W2^T [FF, H] */
+  const float* gamma; const float* beta;
+  unsigned seed_attn, seed_dense;             /* dropout seeds: attention probabilities / dense output */
+  void* mid;                                  /* attention: packed qkv [B*S, 3H]; FFN: gelu(z) [B*S, FF] */
+  void* aux;                                  /* attention: context [B*S, H]; FFN: z (act 1) or GELU'(z) (act 3) [B*S, FF] */
+  float* lse;                                 /* attention: [B, nh, S] */
+  void* pre;                                  /* pre-LayerNorm sum [B*S, H] */
+  void* y; float* mean; float* rstd;
+  const void* dy; long lddy;
+  void* dpre;                                 /* d(pre) */
+  void* dmid_drop;                            /* d(dense output) = d(pre) * mask / (1 - p); == dpre when p_hidden == 0 */
+  void* daux;                                 /* attention: d(context); FFN: d(z) */
+  void* dmid;                                 /* attention: d(qkv) */
+  void* dx;                                   /* or NULL: the input needs no gradient */
+  float* dgamma; float* dbeta;                /* accumulated into, or NULL */
+} VlniBlockSide;
+typedef struct VlniBlockArgs {
+  int dtype, n, H, FF, nh;
+  float eps, p_attn, p_hidden;
+  int act, dact;                              /* FFN epilogue codes of vlni_gemm_nt (1 / 1 or 3 / 3) */
+  int v_in, v_out;                            /* GEMM pipeline ids (`variant` of vlni_gemm_nt_v) of the in / out projections of this direction */
+  const float* bias0; float* dbias0;          /* attention, stream 0: additive [B, S, S] score bias (D:1145-1147) and its gradient */
+  VlniBlockSide s[2];
+} VlniBlockArgs;
+int vlni_self_att_block_fwd(const VlniBlockArgs* a, void* stream);
+int vlni_self_att_block_bwd(const VlniBlockArgs* a, void* stream);
+int vlni_ffn_block_fwd(const VlniBlockArgs* a, void* stream);
+int vlni_ffn_block_bwd(const VlniBlockArgs* a, void* stream);
+
 /* SURVEY.md section 8(b) lists a minimum operator set by name; four of those names are these entry points (same signatures):
  *   vlni_gemm_bias_act_fwd / _bwd        -> vlni_gemm_nt (forward: bias + act epilogue; backward: the dgrad launch with dact / dact_src)
  *   vlni_embed_sum_layernorm_fwd / _bwd  -> vlni_sum_layernorm_fwd / vlni_layernorm_bwd (+ vlni_scatter_add_rows for gathered tables)

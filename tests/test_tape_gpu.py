@@ -74,6 +74,32 @@ def test_tape_is_reused_across_episodes_and_rejects_other_shapes():
     assert torch.isfinite(o["loss"]).item() and tape.bufs["visual"][0].shape[0] == rows0 // ep.B * (ep.B + 1)
 
 
+@pytest.mark.parametrize("family", ["hamt", "duet"])
+def test_one_tape_serves_train_and_eval_programs(family):
+    """train() and eval() are two programs (dropout allocates): the same tape must take either, in both orders - also through the batched
+    up-front record of the history / panorama calls (round 5: bench.py's eval-mode extra died on 49 vs 51 allocations)."""
+    from vln_imagine_amd import ops
+    if family == "hamt":
+        cfg, ep = hamt_variant_setup("c1_T3_dense")
+        et, run = EpisodeTensors(ep, "cuda"), run_episode_taped
+        m = build_product(cfg)
+    else:
+        from tests.golden.variants import duet_variant_setup
+        from tests.test_duet_gpu import build_product as build_duet
+        from vln_imagine_amd.duet.episode import DuetEpisodeTensors, run_episode_taped as run
+        cfg, ep = duet_variant_setup("c1_T3_dense")
+        et, m = DuetEpisodeTensors(ep, "cuda"), build_duet(cfg)
+    tape = ops.EpisodeTape(ep.T)
+    losses = []
+    for training in (True, False, True, False):
+        m.train(training)
+        m.zero_grad()
+        o = run(m, et, tape=tape, criterion=ops.cross_entropy_sum)
+        o["loss"].backward()
+        losses.append(o["loss"].item())
+    assert abs(losses[1] - losses[3]) < 1e-6 and all(map(lambda v: v == v, losses)), losses
+
+
 @pytest.mark.parametrize("dtype,feat_dropout", [(torch.float32, 0.0), (torch.bfloat16, 0.0), (torch.float32, 0.4)])
 def test_taped_episode_with_dropout_equals_the_batched_pass_computed_with_its_seeds(dtype, feat_dropout):
     """train(): every step's launch draws the window of the episode-wide mask that belongs to its rows (seed shifted by t x elements x

@@ -82,6 +82,7 @@ SIGNATURES = {
     "vlni_optim_prepare_groups": [P, F, F, F, P, P, P, I, I, P],
     "vlni_adamw_step_groups": [P, P, P, P, P, I, L, P, P, P, I, F, F, F, F, P, P],
     "vlni_scale_cast": [I, I, P, P, L, F, P],
+    "vlni_self_att_block_fwd": [P, P], "vlni_self_att_block_bwd": [P, P], "vlni_ffn_block_fwd": [P, P], "vlni_ffn_block_bwd": [P, P],
 }
 
 

@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvlni.so")
-SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "attention.hip", "graphmap.hip"]
+SOURCES = ["api.hip", "gemm.hip", "layernorm.hip", "elementwise.hip", "attention.hip", "graphmap.hip", "blocks.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # per-source flags. attention.hip: MFMA results in VGPRs - with the accumulators in AGPRs every softmax operation on a score tile is an
 # accvgpr read + write around it (448 of the forward kernel's 1872 VALU instructions, 144 registers instead of 113: -16 % per launch)

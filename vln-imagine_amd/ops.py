@@ -121,12 +121,13 @@ class EpisodeTape:
         self._open[self.key] = (self.i, self.si)
         counts = {}
         for key, (n_alloc, n_seed) in self._open.items():
-            if self.mode == "record" and self.batch_n:
-                self.steps[key] = self.batch_n
-            elif self.mode == "record":
-                self.steps[key] = self.t + 1 if self.t == 0 else max(self.steps.get(key, 0), self.t + 1)
+            if self.mode == "record":
+                if self.batch_n:
+                    self.steps[key] = self.batch_n
+                else:
+                    self.steps[key] = self.t + 1 if self.t == 0 else max(self.steps.get(key, 0), self.t + 1)
                 if self.t == 0 and n_alloc < len(self.bufs[key]):        # another program than the last episode's (e.g. NavCMT.visual_lang_rows
-                    _KEEPALIVE.extend(self.bufs[key][n_alloc:])          # switched): step 0 defines it; an older capture may still use the rest
+                    _KEEPALIVE.extend(self.bufs[key][n_alloc:])          # switched, train() -> eval()): step 0 defines it; an older capture may still use the rest
                     del self.bufs[key][n_alloc:]
             counts[key] = (n_alloc, n_seed)
         _TAPE = None
