@@ -297,6 +297,82 @@ def test_blocks_against_torch(ops, dtype):
     run(lambda v, l: ops.xatt_block(v, l, aml, P), lambda v, l: ref_att(v, l, aml, att), [visn, lang])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_block_calls_equal_the_launch_by_launch_path(ops, dtype, p_drop):
+    """The block-level entry points (csrc/blocks.hip: one Python -> C crossing per sublayer and direction) issue the same launches with the
+    same kernel choices as the launch-by-launch code: outputs, input gradients and parameter gradients are bit-identical, for one and two
+    streams, self-attention (with an additive score bias on stream 0) and FFN, with and without dropout - and the second call of a shape
+    really takes the block path."""
+    from vln_imagine_amd import _lib
+    torch.manual_seed(3)
+    B, S0, S1, H, FF = 4, 86, 43, 768, 3072
+    mk = lambda *s, sc=0.04: (torch.randn(*s) * sc).cuda().requires_grad_(True)
+
+    def att():
+        return (mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1), mk(H, H), mk(H, sc=0.1),
+                (1 + 0.1 * torch.randn(H)).cuda().requires_grad_(True), (0.1 * torch.randn(H)).cuda().requires_grad_(True))
+
+    def ffn():
+        return (mk(FF, H), mk(FF, sc=0.1), mk(H, FF, sc=0.02), mk(H, sc=0.1),
+                (1 + 0.1 * torch.randn(H)).cuda().requires_grad_(True), (0.1 * torch.randn(H)).cuda().requires_grad_(True))
+
+    PA0, PA1, PF0, PF1 = att(), att(), ffn(), ffn()
+    x0, x1 = torch.randn(B, S0, H).cuda().to(dtype), torch.randn(B, S1, H).cuda().to(dtype)
+    km0 = ((torch.rand(B, S0) < 0.2).float() * -10000.0).cuda()
+    km1 = ((torch.rand(B, S1) < 0.2).float() * -10000.0).cuda()
+    bias0 = (0.1 * torch.randn(B, S0, S0)).cuda().requires_grad_(True)
+    d = lambda seed: (p_drop, p_drop, seed) if p_drop else ops.NO_DROP
+    cases = {
+        "self-att, one stream": lambda a, b: (ops.self_att_block(a, km0, PA0, drop=d(11)),),
+        "ffn, one stream": lambda a, b: (ops.ffn_block(a, PF0, drop=d(21)),),
+        "self-att, two streams + bias": lambda a, b: ops.dual_self_att_block(a, b, km0, km1, PA0, PA1, drop0=d(31), drop1=d(41), bias0=bias0),
+        "ffn, two streams": lambda a, b: ops.dual_ffn_block(a, b, PF0, PF1, drop0=d(51), drop1=d(61)),
+    }
+    params = [t for P in (PA0, PA1, PF0, PF1) for t in P] + [bias0]
+    saved = ops.BLOCK_CALLS
+    counts = {}
+    orig = _lib.call
+
+    def counting(name, *a):
+        counts[name] = counts.get(name, 0) + 1
+        return orig(name, *a)
+
+    def run(fn):
+        a, b = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True)
+        for p in params:
+            p.grad = None
+        outs = fn(a, b)
+        torch.manual_seed(5)
+        sum((o.float() * torch.randn_like(o.float())).sum() for o in outs).backward()
+        return [o.detach().clone() for o in outs], [t.grad.clone() if t.grad is not None else None for t in [a, b] + params]
+
+    try:
+        for name, fn in cases.items():
+            ops.BLOCK_CALLS = False
+            ref = run(fn)
+            ops.BLOCK_CALLS = True
+            run(fn)                                          # (a shape's first call may time the GEMM pipelines)
+            counts.clear()
+            _lib.call = counting
+            try:
+                got = run(fn)
+            finally:
+                _lib.call = orig
+            assert any(k.endswith("_block_fwd") for k in counts) and any(k.endswith("_block_bwd") for k in counts), (name, counts)
+            assert not any(k.startswith(("vlni_gemm_nt_dual", "vlni_attn", "vlni_layernorm")) for k in counts), (name, counts)
+            for o, r in zip(got[0], ref[0]):
+                assert torch.equal(o, r), name
+            for gg, gr in zip(got[1], ref[1]):
+                assert (gg is None) == (gr is None), name
+                if gg is not None:
+                    # float atomics (column sums, LayerNorm dgamma / dbeta) add in another order from run to run
+                    assert torch.equal(gg, gr) or (gg - gr).abs().max().item() <= 1e-5 * max(1.0, gr.abs().max().item()), name
+    finally:
+        ops.BLOCK_CALLS = saved
+        _lib.call = orig
+
+
 def test_small_ops(ops):
     import torch.nn.functional as F
     torch.manual_seed(0)

@@ -1361,6 +1361,239 @@ def _ln_bwd_to(dy, x, g, b, mean, rstd, want, dres=None, drop=None):
 
 
 # =====================================================================================
+#  block-level calls: one Python -> C crossing per sublayer and direction (csrc/blocks.hip)
+# =====================================================================================
+# An eager caller - an unchanged reference agent on the drop-in modules - pays ~35-50 us of Python per kernel launch (argument marshalling,
+# ctypes arrays, kernel-choice lookups): a dual self-attention block is 4 launches forward and 4 backward. The block entry points issue the
+# same launches from C; Python allocates the activations (in the order the launch-by-launch code allocates them: an episode tape matches a
+# recorded step's buffers to its ghost pass by sequence), fills one struct and crosses once. The launch-by-launch code below stays: it is the
+# path of the first call of every shape (it times the GEMM pipelines and fills the kernel-choice cache the block calls read), of ghost passes,
+# of float32 / unusual operands, and the reference the tests hold the block calls to (VLNI_BLOCK_CALLS=0).
+BLOCK_CALLS = os.environ.get("VLNI_BLOCK_CALLS", "1") == "1"
+
+
+class _BlkSide(ctypes.Structure):            # VlniBlockSide (include/vlni.h)
+    _fields_ = [("B", ctypes.c_int), ("S", ctypes.c_int), ("x", ctypes.c_void_p), ("ldx", ctypes.c_long), ("kmask", ctypes.c_void_p),
+                ("w_in", ctypes.c_void_p), ("b_in", ctypes.c_void_p), ("w_out", ctypes.c_void_p), ("b_out", ctypes.c_void_p),
+                ("wt_in", ctypes.c_void_p), ("wt_out", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+                ("seed_attn", ctypes.c_uint), ("seed_dense", ctypes.c_uint),
+                ("mid", ctypes.c_void_p), ("aux", ctypes.c_void_p), ("lse", ctypes.c_void_p), ("pre", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+                ("dy", ctypes.c_void_p), ("lddy", ctypes.c_long), ("dpre", ctypes.c_void_p), ("dmid_drop", ctypes.c_void_p),
+                ("daux", ctypes.c_void_p), ("dmid", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p)]
+
+
+class _BlkArgs(ctypes.Structure):            # VlniBlockArgs
+    _fields_ = [("dtype", ctypes.c_int), ("n", ctypes.c_int), ("H", ctypes.c_int), ("FF", ctypes.c_int), ("nh", ctypes.c_int),
+                ("eps", ctypes.c_float), ("p_attn", ctypes.c_float), ("p_hidden", ctypes.c_float), ("act", ctypes.c_int), ("dact", ctypes.c_int),
+                ("v_in", ctypes.c_int), ("v_out", ctypes.c_int), ("bias0", ctypes.c_void_p), ("dbias0", ctypes.c_void_p), ("s", _BlkSide * 2)]
+
+
+_BLK = _BlkArgs()
+_BLK_REF = ctypes.addressof(_BLK)
+
+
+def _known_variant(dt, Ms, N, K, act, dact, res, pre):
+    """The cached kernel choice of a (dual) GEMM launch exactly as gemm_nt / gemm_nt2 key it; None = not timed yet (take the launch-by-launch path,
+    which times the pipelines)."""
+    if len(Ms) == 2:
+        if not AUTOTUNE:
+            return 0
+        key = (dt, Ms[0], Ms[1], N, K, act, dact, res, pre, False)
+    else:
+        if not AUTOTUNE or Ms[0] < 512:
+            return 0
+        key = (dt, Ms[0], N, K, act, dact, res, pre, False)
+    v = _GEMM_BEST.get(key)
+    if v is None and torch.cuda.is_current_stream_capturing():
+        return 0
+    return v
+
+
+def _blk_ok(xs):
+    return BLOCK_CALLS and not _ghost() and not NN_DGRAD and all(x.is_cuda for x in xs)
+
+
+def _blk_seed(seed, elems, on):
+    return _shift(seed, elems) if on else 0
+
+
+def _blk_self_att_fwd(sides, bias0, eps, nh=12):
+    """sides: [(x [B, S, H], kmask, drop, P)] (1 or 2). Returns per side (x2, qkv, c, lse, pre, y, mean, rstd), or None: take the launch-by-launch path."""
+    n = len(sides)
+    x0 = sides[0][0]
+    dt, dev, H = x0.dtype, x0.device, x0.shape[2]
+    Ms = [s[0].shape[0] * s[0].shape[1] for s in sides]
+    v_in = _known_variant(dt, Ms, 3 * H, H, 0, 0, False, False)
+    v_out = _known_variant(dt, Ms, H, H, 0, 0, True, False)
+    if v_in is None or v_out is None or any(s[0].dtype != dt or s[0].shape[2] != H for s in sides):
+        return None
+    pa = max(s[2][0] for s in sides)
+    ph = max(s[2][1] for s in sides)
+    x2 = [_rows(s[0]) for s in sides]
+    mid = [_new((Ms[i], 3 * H), dt, dev) for i in range(n)]
+    if n == 2 and dt in H16 and max(s[0].shape[1] for s in sides) <= 256:       # attn_fwd2's dual launch: contexts, then statistics
+        aux = [_new((Ms[i], H), dt, dev) for i in range(n)]
+        lse = [_new((sides[i][0].shape[0], nh, sides[i][0].shape[1]), torch.float32, dev) for i in range(n)]
+    else:                                                                       # one attention launch per stream: (context, statistics) each
+        aux, lse = [], []
+        for i in range(n):
+            aux.append(_new((Ms[i], H), dt, dev))
+            lse.append(_new((sides[i][0].shape[0], nh, sides[i][0].shape[1]), torch.float32, dev))
+    pre = [_new((Ms[i], H), dt, dev) for i in range(n)]
+    y = [_new((Ms[i], H), dt, dev) for i in range(n)]
+    mean = [_new((Ms[i],), torch.float32, dev) for i in range(n)]
+    rstd = [_new((Ms[i],), torch.float32, dev) for i in range(n)]
+    a = _BLK
+    a.dtype, a.n, a.H, a.FF, a.nh, a.eps, a.p_attn, a.p_hidden = _DT[dt], n, H, 0, nh, eps, pa, ph
+    a.v_in, a.v_out, a.bias0, a.dbias0 = v_in, v_out, _p(bias0) or None, None
+    for i, (x, kmask, drop, P) in enumerate(sides):
+        B, S = x.shape[0], x.shape[1]
+        sd = a.s[i]
+        sd.B, sd.S, sd.x, sd.ldx, sd.kmask = B, S, x2[i].data_ptr(), x2[i].stride(0), _p(kmask) or None
+        sd.w_in, sd.b_in = _w((P[0], P[2], P[4]), dt).data_ptr(), _w((P[1], P[3], P[5]), torch.float32).data_ptr()
+        sd.w_out, sd.b_out, sd.gamma, sd.beta = _w((P[6],), dt).data_ptr(), P[7].data_ptr(), P[8].data_ptr(), P[9].data_ptr()
+        sd.seed_attn, sd.seed_dense = _blk_seed(drop[2], B * nh * S * S, pa > 0.0), _blk_seed(drop[2] + 1, Ms[i] * H, ph > 0.0)
+        sd.mid, sd.aux, sd.lse, sd.pre = mid[i].data_ptr(), aux[i].data_ptr(), lse[i].data_ptr(), pre[i].data_ptr()
+        sd.y, sd.mean, sd.rstd = y[i].data_ptr(), mean[i].data_ptr(), rstd[i].data_ptr()
+    _lib.call("vlni_self_att_block_fwd", _BLK_REF, _st())
+    return [(x2[i], mid[i], aux[i], lse[i], pre[i], y[i], mean[i], rstd[i]) for i in range(n)]
+
+
+def _blk_param_grads(want, g, b, dev, H):
+    """(dgamma, dbeta, returned?) of one stream's LayerNorm: accumulated straight into the arena where the trainer marked the parameters."""
+    if not want:
+        return None, None, False
+    if _direct(g, b):
+        return g.grad, b.grad, False
+    return torch.zeros((H,), dtype=torch.float32, device=dev), torch.zeros((H,), dtype=torch.float32, device=dev), True
+
+
+def _blk_self_att_bwd(sides, bias0, want_dbias, nh=12):
+    """sides: [(dy, x2, qkv, c, lse, pre, mean, rstd, kmask, drop, P, wants_params, wants_dx, B, S)]. Returns (per side (dx, grads dict), dbias0) or None.
+    The weight / bias gradients go through _wb_grad_to exactly as in the launch-by-launch backward."""
+    n = len(sides)
+    dt, dev, H = sides[0][1].dtype, sides[0][1].device, sides[0][1].shape[1]
+    Ms = [s[1].shape[0] for s in sides]
+    nd = [i for i in range(n) if sides[i][12]]
+    v_out = _known_variant(dt, Ms, H, H, 0, 0, False, False)
+    v_in = _known_variant(dt, [Ms[i] for i in nd], H, 3 * H, 0, 0, True, False) if nd else 0
+    if v_in is None or v_out is None:
+        return None
+    pa = max(s[9][0] for s in sides)
+    ph = max(s[9][1] for s in sides)
+    a = _BLK
+    a.dtype, a.n, a.H, a.FF, a.nh, a.eps, a.p_attn, a.p_hidden = _DT[dt], n, H, 0, nh, 0.0, pa, ph
+    dbias0 = torch.zeros_like(bias0) if (bias0 is not None and want_dbias) else None
+    a.v_in, a.v_out, a.bias0, a.dbias0 = v_in, v_out, _p(bias0) or None, _p(dbias0) or None
+    keep, out = [], []
+    for i, (dy, x2, qkv, c, lse, pre, mean, rstd, kmask, drop, P, wp, wdx, B, S) in enumerate(sides):
+        dy2 = _rows(dy)
+        dpre = torch.empty((Ms[i], H), dtype=dt, device=dev)
+        dmd = torch.empty((Ms[i], H), dtype=dt, device=dev) if ph > 0.0 else dpre
+        dc = torch.empty((Ms[i], H), dtype=dt, device=dev)
+        dqkv = torch.empty_like(qkv)
+        dx = torch.empty((Ms[i], H), dtype=dt, device=dev) if wdx else None
+        dg, db, ret = _blk_param_grads(wp, P[8], P[9], dev, H)
+        sd = a.s[i]
+        sd.B, sd.S, sd.kmask = B, S, _p(kmask) or None
+        sd.wt_in, sd.wt_out = _w((P[0], P[2], P[4]), dt, True).data_ptr(), _w((P[6],), dt, True).data_ptr()
+        sd.gamma = P[8].data_ptr()
+        sd.seed_attn, sd.seed_dense = drop[2] if pa > 0.0 else 0, (drop[2] + 1) if ph > 0.0 else 0
+        sd.mid, sd.aux, sd.lse, sd.pre, sd.mean, sd.rstd = qkv.data_ptr(), c.data_ptr(), lse.data_ptr(), pre.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        sd.dy, sd.lddy, sd.dpre, sd.dmid_drop, sd.daux, sd.dmid = dy2.data_ptr(), dy2.stride(0), dpre.data_ptr(), dmd.data_ptr(), dc.data_ptr(), dqkv.data_ptr()
+        sd.dx, sd.dgamma, sd.dbeta = _p(dx) or None, _p(dg) or None, _p(db) or None
+        keep.append((dy2, dpre, dmd, dc, dqkv, dx, dg, db, ret))
+    _lib.call("vlni_self_att_block_bwd", _BLK_REF, _st())
+    for i, (dy, x2, qkv, c, lse, pre, mean, rstd, kmask, drop, P, wp, wdx, B, S) in enumerate(sides):
+        dy2, dpre, dmd, dc, dqkv, dx, dg, db, ret = keep[i]
+        g8 = [None] * 8
+        if wp:
+            (g8[6],), (g8[7],) = _wb_grad_to((P[6],), (P[7],), dmd, c)
+            (g8[0], g8[2], g8[4]), (g8[1], g8[3], g8[5]) = _wb_grad_to((P[0], P[2], P[4]), (P[1], P[3], P[5]), dqkv, x2)
+        out.append((dx, g8, dg if ret else None, db if ret else None))
+    return out, dbias0
+
+
+def _blk_ffn_fwd(sides, eps):
+    """sides: [(x, drop, P = (w1, b1, w2, b2, g, b))]. Returns per side (x2, z, h, pre, y, mean, rstd) or None."""
+    n = len(sides)
+    x0 = sides[0][0]
+    dt, dev, H = x0.dtype, x0.device, x0.shape[-1]
+    FF = sides[0][2][0].shape[0]
+    x2 = [_rows(s[0]) for s in sides]
+    Ms = [t.shape[0] for t in x2]
+    act, dact = _gelu_codes(dt)
+    v_in = _known_variant(dt, Ms, FF, H, act, 0, False, True)
+    v_out = _known_variant(dt, Ms, H, FF, 0, 0, True, False)
+    if v_in is None or v_out is None or any(s[0].dtype != dt or s[2][0].shape[0] != FF for s in sides):
+        return None
+    ph = max(s[1][1] for s in sides)
+    z = [_new((Ms[i], FF), dt, dev) for i in range(n)]
+    h = [_new((Ms[i], FF), dt, dev) for i in range(n)]
+    pre = [_new((Ms[i], H), dt, dev) for i in range(n)]
+    y = [_new((Ms[i], H), dt, dev) for i in range(n)]
+    mean = [_new((Ms[i],), torch.float32, dev) for i in range(n)]
+    rstd = [_new((Ms[i],), torch.float32, dev) for i in range(n)]
+    a = _BLK
+    a.dtype, a.n, a.H, a.FF, a.nh, a.eps, a.p_attn, a.p_hidden = _DT[dt], n, H, FF, 0, eps, 0.0, ph
+    a.act, a.dact, a.v_in, a.v_out, a.bias0, a.dbias0 = act, dact, v_in, v_out, None, None
+    for i, (x, drop, P) in enumerate(sides):
+        sd = a.s[i]
+        sd.B, sd.S, sd.x, sd.ldx, sd.kmask = Ms[i], 1, x2[i].data_ptr(), x2[i].stride(0), None
+        sd.w_in, sd.b_in, sd.w_out, sd.b_out = _w((P[0],), dt).data_ptr(), P[1].data_ptr(), _w((P[2],), dt).data_ptr(), P[3].data_ptr()
+        sd.gamma, sd.beta = P[4].data_ptr(), P[5].data_ptr()
+        sd.seed_attn, sd.seed_dense = 0, _blk_seed(drop[2], Ms[i] * H, ph > 0.0)
+        sd.mid, sd.aux, sd.lse, sd.pre = h[i].data_ptr(), z[i].data_ptr(), None, pre[i].data_ptr()
+        sd.y, sd.mean, sd.rstd = y[i].data_ptr(), mean[i].data_ptr(), rstd[i].data_ptr()
+    _lib.call("vlni_ffn_block_fwd", _BLK_REF, _st())
+    return [(x2[i], z[i], h[i], pre[i], y[i], mean[i], rstd[i]) for i in range(n)]
+
+
+def _blk_ffn_bwd(sides):
+    """sides: [(dy, x2, z, h, pre, mean, rstd, drop, P, wants_params, wants_dx)]. Returns per side (dx, g4, dgamma, dbeta) or None."""
+    n = len(sides)
+    dt, dev, H = sides[0][1].dtype, sides[0][1].device, sides[0][1].shape[1]
+    FF = sides[0][2].shape[1]
+    Ms = [s[1].shape[0] for s in sides]
+    act, dact = _gelu_codes(dt)
+    nd = [i for i in range(n) if sides[i][10]]
+    v_out = _known_variant(dt, Ms, FF, H, 0, dact, False, False)
+    v_in = _known_variant(dt, [Ms[i] for i in nd], H, FF, 0, 0, True, False) if nd else 0
+    if v_in is None or v_out is None:
+        return None
+    ph = max(s[7][1] for s in sides)
+    a = _BLK
+    a.dtype, a.n, a.H, a.FF, a.nh, a.eps, a.p_attn, a.p_hidden = _DT[dt], n, H, FF, 0, 0.0, 0.0, ph
+    a.act, a.dact, a.v_in, a.v_out, a.bias0, a.dbias0 = act, dact, v_in, v_out, None, None
+    keep, out = [], []
+    for i, (dy, x2, z, h, pre, mean, rstd, drop, P, wp, wdx) in enumerate(sides):
+        dy2 = _rows(dy)
+        dpre = torch.empty((Ms[i], H), dtype=dt, device=dev)
+        dmd = torch.empty((Ms[i], H), dtype=dt, device=dev) if ph > 0.0 else dpre
+        dz = torch.empty((Ms[i], FF), dtype=dt, device=dev)
+        dx = torch.empty((Ms[i], H), dtype=dt, device=dev) if wdx else None
+        dg, db, ret = _blk_param_grads(wp, P[4], P[5], dev, H)
+        sd = a.s[i]
+        sd.B, sd.S, sd.kmask = Ms[i], 1, None
+        sd.wt_in, sd.wt_out, sd.gamma = _w((P[0],), dt, True).data_ptr(), _w((P[2],), dt, True).data_ptr(), P[4].data_ptr()
+        sd.seed_attn, sd.seed_dense = 0, drop[2] if ph > 0.0 else 0
+        sd.mid, sd.aux, sd.lse, sd.pre, sd.mean, sd.rstd = h.data_ptr(), z.data_ptr(), None, pre.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        sd.dy, sd.lddy, sd.dpre, sd.dmid_drop, sd.daux, sd.dmid = dy2.data_ptr(), dy2.stride(0), dpre.data_ptr(), dmd.data_ptr(), dz.data_ptr(), None
+        sd.dx, sd.dgamma, sd.dbeta = _p(dx) or None, _p(dg) or None, _p(db) or None
+        keep.append((dy2, dpre, dmd, dz, dx, dg, db, ret))
+    _lib.call("vlni_ffn_block_bwd", _BLK_REF, _st())
+    for i, (dy, x2, z, h, pre, mean, rstd, drop, P, wp, wdx) in enumerate(sides):
+        dy2, dpre, dmd, dz, dx, dg, db, ret = keep[i]
+        g4 = [None] * 4
+        if wp:
+            (g4[2],), (g4[3],) = _wb_grad_to((P[2],), (P[3],), dmd, h)
+            (g4[0],), (g4[1],) = _wb_grad_to((P[0],), (P[1],), dz, x2)
+        out.append((dx, g4, dg if ret else None, db if ret else None))
+    return out
+
+
+# =====================================================================================
 #  sublayer autograd functions
 # =====================================================================================
 class _SelfAttBlock(torch.autograd.Function):
@@ -1370,6 +1603,14 @@ class _SelfAttBlock(torch.autograd.Function):
     def forward(ctx, x, kmask, bias, eps, drop, wq, bq, wk, bk, wv, bv, wo, bo, g, b):
         B, S, H = x.shape
         pa, ph, sd = drop
+        if _blk_ok((x,)):
+            r = _blk_self_att_fwd([(x, kmask, drop, (wq, bq, wk, bk, wv, bv, wo, bo, g, b))], bias, eps)
+            if r is not None:
+                x2, qkv, c, lse, pre, y, mean, rstd = r[0]
+                ctx.save_for_backward(x2, qkv, c, lse, pre, mean, rstd, kmask, bias)
+                ctx.P = (wq, bq, wk, bk, wv, bv, wo, bo, g, b)
+                ctx.dims, ctx.drop = (B, S, H), drop
+                return y.view(B, S, H)
         x2 = _rows(_chk(x, "x"))
         dt = x.dtype
         wqkv, bqkv = _w((wq, wk, wv), dt), _w((bq, bk, bv), torch.float32)
@@ -1391,6 +1632,11 @@ class _SelfAttBlock(torch.autograd.Function):
         dt = x2.dtype
         ng = ctx.needs_input_grad
         wparams = any(ng[5:])
+        if _blk_ok((dy,)):
+            r = _blk_self_att_bwd([(dy, x2, qkv, c, lse, pre, mean, rstd, kmask, ctx.drop, ctx.P, wparams, ng[0], B, S)], bias, bias is not None and ng[2])
+            if r is not None:
+                (dx, g8, dg, db), dbias = r[0][0], r[1]
+                return (dx.view(B, S, H) if dx is not None else None, None, dbias, None, None) + tuple(g8) + (dg, db)
         dpre, dg, db, dpm = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams, drop=(ph, sd + 1))
         dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = None
         if wparams:
@@ -1412,6 +1658,14 @@ class _FfnBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eps, drop, w1, b1, w2, b2, g, b):
         shp = x.shape
+        if _blk_ok((x,)):
+            r = _blk_ffn_fwd([(x, drop, (w1, b1, w2, b2, g, b))], eps)
+            if r is not None:
+                x2, z, a, pre, y, mean, rstd = r[0]
+                ctx.save_for_backward(x2, z, a, pre, mean, rstd)
+                ctx.P = (w1, b1, w2, b2, g, b)
+                ctx.shp, ctx.drop = shp, drop
+                return y.view(shp)
         x2 = _rows(_chk(x, "x"))
         dt = x.dtype
         z = _new((x2.shape[0], w1.shape[0]), dt, x.device)           # z, or GELU'(z) on the 16-bit paths (_gelu_codes)
@@ -1430,6 +1684,11 @@ class _FfnBlock(torch.autograd.Function):
         dt = x2.dtype
         ng = ctx.needs_input_grad
         wparams = any(ng[3:])
+        if _blk_ok((dy,)):
+            r = _blk_ffn_bwd([(dy, x2, z, a, pre, mean, rstd, ctx.drop, ctx.P, wparams, ng[0])])
+            if r is not None:
+                dx, g4, dg, db = r[0]
+                return (dx.view(ctx.shp) if dx is not None else None, None, None) + tuple(g4) + (dg, db)
         dpre, dg, db, dpm = _ln_bwd_to(_rows(dy), pre, g, b, mean, rstd, wparams, drop=(ctx.drop[1], ctx.drop[2]))
         dw1 = db1 = dw2 = db2 = None
         if wparams:
@@ -1604,6 +1863,13 @@ class _DualSelfAttBlock(torch.autograd.Function):
     def forward(ctx, x0, x1, km0, km1, bias0, eps, drop0, drop1, *P):
         P0, P1 = P[:10], P[10:]
         (B, S0, H), S1 = x0.shape, x1.shape[1]
+        if _blk_ok((x0, x1)) and x0.dtype == x1.dtype and x1.shape[0] == B:
+            r = _blk_self_att_fwd([(x0, km0, drop0, P0), (x1, km1, drop1, P1)], bias0, eps)
+            if r is not None:
+                (a0, q0, c0, lse0, pre0, y0, m0, r0), (a1, q1, c1, lse1, pre1, y1, m1, r1) = r
+                ctx.save_for_backward(a0, a1, q0, q1, c0, c1, lse0, lse1, pre0, pre1, m0, r0, m1, r1, km0, km1, bias0)
+                ctx.P, ctx.dims, ctx.drop = (P0, P1), (B, S0, S1, H), (drop0, drop1, max(drop0[1], drop1[1]))
+                return y0.view(B, S0, H), y1.view(B, S1, H)
         a0, a1 = _rows(_chk(x0, "x0")), _rows(_chk(x1, "x1"))
         dt = x0.dtype
         wqkv = [_w((Pi[0], Pi[2], Pi[4]), dt) for Pi in (P0, P1)]
@@ -1628,6 +1894,13 @@ class _DualSelfAttBlock(torch.autograd.Function):
         dt = a0.dtype
         ng = ctx.needs_input_grad
         w0, w1 = any(ng[8:18]), any(ng[18:28])
+        if _blk_ok((dy0, dy1)):
+            r = _blk_self_att_bwd([(dy0, a0, q0, c0, lse0, pre0, m0, r0, km0, drop0, P0, w0, True, B, S0),
+                                   (dy1, a1, q1, c1, lse1, pre1, m1, r1, km1, drop1, P1, w1, True, B, S1)], bias0, bias0 is not None and ng[4])
+            if r is not None:
+                ((dx0, g0, dg0, db0), (dx1, g1, dg1, db1)), dbias0 = r
+                return (dx0.view(B, S0, H), dx1.view(B, S1, H), None, None, dbias0, None, None, None) + tuple(g0) + (dg0, db0) + tuple(g1) \
+                    + (dg1, db1)
         dbias0 = torch.zeros_like(bias0) if (bias0 is not None and ng[4]) else None
         (dp0, dg0, db0, dm0), (dp1, dg1, db1, dm1) = _ln_bwd_to2((_rows(dy0), _rows(dy1)), (pre0, pre1), (P0[8], P1[8]), (P0[9], P1[9]),
                                                                  (m0, m1), (r0, r1), (w0, w1), drop=(ph, (drop0[2] + 1, drop1[2] + 1)))
@@ -1712,6 +1985,13 @@ class _DualFfnBlock(torch.autograd.Function):
     def forward(ctx, x0, x1, eps, drop0, drop1, *P):
         P0, P1 = P[:6], P[6:]
         s0, s1 = x0.shape, x1.shape
+        if _blk_ok((x0, x1)) and x0.dtype == x1.dtype:
+            r = _blk_ffn_fwd([(x0, drop0, P0), (x1, drop1, P1)], eps)
+            if r is not None:
+                (a0, z0, h0, pre0, y0, m0, r0), (a1, z1, h1, pre1, y1, m1, r1) = r
+                ctx.save_for_backward(a0, a1, z0, z1, h0, h1, pre0, pre1, m0, r0, m1, r1)
+                ctx.P, ctx.shp, ctx.drop = (P0, P1), (s0, s1), (drop0, drop1, max(drop0[1], drop1[1]))
+                return y0.view(s0), y1.view(s1)
         a0, a1 = _rows(_chk(x0, "x0")), _rows(_chk(x1, "x1"))
         dt = x0.dtype
         FF = P0[0].shape[0]
@@ -1734,6 +2014,11 @@ class _DualFfnBlock(torch.autograd.Function):
         dt = a0.dtype
         ng = ctx.needs_input_grad
         w0, w1 = any(ng[5:11]), any(ng[11:17])
+        if _blk_ok((dy0, dy1)):
+            r = _blk_ffn_bwd([(dy0, a0, z0, h0, pre0, m0, r0, drop0, P0, w0, True), (dy1, a1, z1, h1, pre1, m1, r1, drop1, P1, w1, True)])
+            if r is not None:
+                (dx0, g0, dg0, db0), (dx1, g1, dg1, db1) = r
+                return (dx0.view(ctx.shp[0]), dx1.view(ctx.shp[1]), None, None, None) + tuple(g0) + (dg0, db0) + tuple(g1) + (dg1, db1)
         (dp0, dg0, db0, dm0), (dp1, dg1, db1, dm1) = _ln_bwd_to2((_rows(dy0), _rows(dy1)), (pre0, pre1), (P0[4], P1[4]), (P0[5], P1[5]),
                                                                  (m0, m1), (r0, r1), (w0, w1), drop=(ph, (drop0[2], drop1[2])))
         g0, g1 = [None] * 4, [None] * 4
