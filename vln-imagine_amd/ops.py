@@ -1505,13 +1505,20 @@ def _blk_self_att_bwd(sides, bias0, want_dbias, nh=12):
         sd.dx, sd.dgamma, sd.dbeta = _p(dx) or None, _p(dg) or None, _p(db) or None
         keep.append((dy2, dpre, dmd, dc, dqkv, dx, dg, db, ret))
     _lib.call("vlni_self_att_block_bwd", _BLK_REF, _st())
-    for i, (dy, x2, qkv, c, lse, pre, mean, rstd, kmask, drop, P, wp, wdx, B, S) in enumerate(sides):
+    # weight gradients in the launch-by-launch backward's ORDER (out projections of all streams, then in projections): the deferred queue
+    # keeps first-insertion order, and a captured flush must find the reduction table its warm-up step built
+    g8s = [[None] * 8 for _ in range(n)]
+    for i, sd_ in enumerate(sides):
+        if sd_[11]:
+            P = sd_[10]
+            (g8s[i][6],), (g8s[i][7],) = _wb_grad_to((P[6],), (P[7],), keep[i][2], sd_[3])
+    for i, sd_ in enumerate(sides):
+        if sd_[11]:
+            P = sd_[10]
+            (g8s[i][0], g8s[i][2], g8s[i][4]), (g8s[i][1], g8s[i][3], g8s[i][5]) = _wb_grad_to((P[0], P[2], P[4]), (P[1], P[3], P[5]), keep[i][4], sd_[1])
+    for i in range(n):
         dy2, dpre, dmd, dc, dqkv, dx, dg, db, ret = keep[i]
-        g8 = [None] * 8
-        if wp:
-            (g8[6],), (g8[7],) = _wb_grad_to((P[6],), (P[7],), dmd, c)
-            (g8[0], g8[2], g8[4]), (g8[1], g8[3], g8[5]) = _wb_grad_to((P[0], P[2], P[4]), (P[1], P[3], P[5]), dqkv, x2)
-        out.append((dx, g8, dg if ret else None, db if ret else None))
+        out.append((dx, g8s[i], dg if ret else None, db if ret else None))
     return out, dbias0
 
 
@@ -1583,13 +1590,18 @@ def _blk_ffn_bwd(sides):
         sd.dx, sd.dgamma, sd.dbeta = _p(dx) or None, _p(dg) or None, _p(db) or None
         keep.append((dy2, dpre, dmd, dz, dx, dg, db, ret))
     _lib.call("vlni_ffn_block_bwd", _BLK_REF, _st())
-    for i, (dy, x2, z, h, pre, mean, rstd, drop, P, wp, wdx) in enumerate(sides):
+    g4s = [[None] * 4 for _ in range(n)]                     # (same order as the launch-by-launch backward: see _blk_self_att_bwd)
+    for i, sd_ in enumerate(sides):
+        if sd_[9]:
+            P = sd_[8]
+            (g4s[i][2],), (g4s[i][3],) = _wb_grad_to((P[2],), (P[3],), keep[i][2], sd_[3])
+    for i, sd_ in enumerate(sides):
+        if sd_[9]:
+            P = sd_[8]
+            (g4s[i][0],), (g4s[i][1],) = _wb_grad_to((P[0],), (P[1],), keep[i][3], sd_[1])
+    for i in range(n):
         dy2, dpre, dmd, dz, dx, dg, db, ret = keep[i]
-        g4 = [None] * 4
-        if wp:
-            (g4[2],), (g4[3],) = _wb_grad_to((P[2],), (P[3],), dmd, h)
-            (g4[0],), (g4[1],) = _wb_grad_to((P[0],), (P[1],), dz, x2)
-        out.append((dx, g4, dg if ret else None, db if ret else None))
+        out.append((dx, g4s[i], dg if ret else None, db if ret else None))
     return out
 
 
