@@ -317,6 +317,25 @@ int vlni_adamw_step_groups(float* p, const float* g, float* m, float* v, void* s
    averaging with bf16 compression, r2r/agent_cmt.py:61-63); src 16-byte, dst 8-byte aligned */
 int vlni_scale_cast(int dt_in, int dt_out, const void* src, void* dst, long n, float scale, void* stream);
 
+/* Fused embed-and-combine (round 5): y = dropout([LN_o]([LN_a](a) + LN_b(f W_b^T + b_b) + row + table[idx] + table2[idx2] + extra)) in ONE launch -
+ * the observation / history / panorama / map-node embeddings (ImageEmbeddings R:535-544, HistoryEmbeddings R:596-618, D:1087-1131, D:1140-1156) that were
+ * LayerNorm + small-K linear + LayerNorm + sum-LayerNorm + dropout. a [rows, H] is the image linear's output; f [rows, K <= 16] float32 angle / position
+ * features; optional parts NULL. Writes what the backward needs: linb (the small linear's output), xsum (pre-LN_o sum), the LayerNorms' statistics.
+ * Backward = the existing operators (vlni_dropout, vlni_layernorm_bwd x3, vlni_smallk_linear_bwd, vlni_colsum, vlni_scatter_add_rows). */
+int vlni_embed_combine_fwd(int dtype, const void* a, long lda, const float* ga, const float* ba, const float* f, long ldf, int K,
+                           const float* Wb, const float* bb, const float* gb, const float* beb, const void* extra, long lde,
+                           const float* row, const float* table, const long* idx, const float* table2, const long* idx2,
+                           const float* go, const float* bo, float eps, void* linb, void* xsum, void* y, long ldy, float* mean_a,
+                           float* rstd_a, float* mean_b, float* rstd_b, float* mean_o, float* rstd_o, float drop_p, unsigned drop_seed,
+                           int rows, int H, void* stream);
+
+/* Prediction-head tail in one launch (round 5): out[r] = mask[r] ? -inf : <dropout(LayerNorm(x[r])), w> + bias - NextActionPrediction R:953-963 + R:1200 and
+ * ClsPrediction D:1009-1020 after their first Linear + ReLU. hd [rows, H] (the dropped LayerNorm output) and mean / rstd are kept for the backward
+ * (vlni_rowdot_bwd, the dropout mask, vlni_layernorm_bwd). */
+int vlni_ln_rowdot_fwd(int dtype, const void* x, long ldx, const float* gamma, const float* beta, float eps, void* hd, float* mean, float* rstd,
+                       const float* w, const float* bias, const unsigned char* mask, float* out, float drop_p, unsigned drop_seed, int rows, int H,
+                       void* stream);
+
 /* ---- block-level entry points (round 5; csrc/blocks.hip) -------------------------------------------------------------------------
  * One call = one transformer SUBLAYER of one or two streams, forward or backward: the function issues the sublayer's own 4-7 launches
  * (vlni_gemm_nt_multi, vlni_attn_*, vlni_layernorm_*) on `stream`, so an eager caller crosses the boundary once per sublayer and direction.

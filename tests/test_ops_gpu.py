@@ -373,6 +373,113 @@ def test_block_calls_equal_the_launch_by_launch_path(ops, dtype, p_drop):
         _lib.call = orig
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_combine_equals_the_unfused_operators(ops, dtype):
+    """vlni_embed_combine_fwd - LayerNorm + small-K linear + LayerNorm + gathers + sum-LayerNorm + dropout in ONE launch - against the operators it
+    replaces (ops.layer_norm, smallk_linear, sum_layer_norm, the library's counter-based dropout), forward and every gradient, in the four shapes the
+    models use: observation embedding (ImageEmbeddings, vilmodel_cmt.py:535-544), history combine with the panorama mean (:611-618), panorama input
+    without outer LayerNorm (:603-610), DUET map nodes (no LayerNorm on the image, step-embedding gather, vilmodel.py:1140-1147)."""
+    torch.manual_seed(2)
+    rows, H, K = 3 * 37, 768, 4
+    mk = lambda *s_, sc=1.0: (torch.randn(*s_) * sc).cuda().requires_grad_(True)
+    a0 = torch.randn(rows, H).cuda().to(dtype)
+    f = torch.randn(rows, K).cuda()
+    extra0 = torch.randn(rows, H).cuda().to(dtype)
+    idx = torch.randint(0, 3, (rows,)).cuda()
+    idx2 = torch.randint(0, 50, (rows,)).cuda()
+    ga, ba, gb, beb, go, bo = [(1 + 0.1 * torch.randn(H)).cuda().requires_grad_(True) if i % 2 == 0 else mk(H, sc=0.1) for i in range(6)]
+    Wb, bb, row, table, table2 = mk(H, K, sc=0.3), mk(H, sc=0.1), mk(H, sc=0.2), mk(3, H, sc=0.2), mk(50, H, sc=0.2)
+    params = [ga, ba, gb, beb, go, bo, Wb, bb, row, table, table2]
+    tol = TOL[dtype]
+
+    def unfused(a, extra, kind):
+        ta = ops.layer_norm(ops.smallk_linear(f, Wb, bb, dtype), gb, beb, 1e-12)
+        if kind == "observation":
+            srcs = [(ops.layer_norm(a, ga, ba, 1e-12), "dense", None), (ta, "dense", None), (row, "bcast", None), (table, "gather", idx)]
+            return ops.sum_layer_norm(srcs, go, bo, rows, dtype, 1e-12)
+        if kind == "history":
+            srcs = [(ops.layer_norm(a, ga, ba, 1e-12), "dense", None), (ta, "dense", None), (row, "bcast", None), (extra, "dense", None)]
+            return ops.sum_layer_norm(srcs, go, bo, rows, dtype, 1e-12)
+        if kind == "panorama input":
+            return ops.layer_norm(a, ga, ba, 1e-12) + ta
+        return a + table2.index_select(0, idx2).to(dtype) + ta          # map nodes
+
+    def fused(a, extra, kind, p=0.0):
+        small = (f, Wb, bb, gb, beb)
+        if kind == "observation":
+            return ops.embed_combine(a, dtype, ln_a=(ga, ba), small=small, row=row, table=(table, idx), ln_o=(go, bo), p_drop=p, training=True)
+        if kind == "history":
+            return ops.embed_combine(a, dtype, ln_a=(ga, ba), small=small, row=row, extra=extra, ln_o=(go, bo), p_drop=p, training=True)
+        if kind == "panorama input":
+            return ops.embed_combine(a, dtype, ln_a=(ga, ba), small=small, p_drop=p, training=True)
+        return ops.embed_combine(a, dtype, small=small, table=(table2, idx2), p_drop=p, training=True)
+
+    w = torch.randn(rows, H).cuda()
+    for kind in ("observation", "history", "panorama input", "map nodes"):
+        res = []
+        for fn in (unfused, fused):
+            a, extra = a0.clone().requires_grad_(True), extra0.clone().requires_grad_(True)
+            for p_ in params:
+                p_.grad = None
+            y = fn(a, extra, kind)
+            (y.float() * w).sum().backward()
+            res.append((y.detach().float(), [t.grad.clone().float() if t.grad is not None else None for t in [a, extra] + params]))
+        (y0, g0), (y1, g1) = res
+        assert (y0 - y1).abs().max().item() <= (1e-5 if dtype == torch.float32 else 2 * tol) * max(1.0, y0.abs().max().item()), kind
+        for i, (u, v) in enumerate(zip(g0, g1)):
+            assert (u is None) == (v is None), (kind, i)
+            if u is not None:
+                assert (u - v).abs().max().item() <= (2e-5 if dtype == torch.float32 else 4 * tol) * max(1.0, u.abs().max().item()), (kind, i)
+    # dropout: the fused epilogue draws the mask the library's dropout kernel draws for the same seed
+    ops.reseed(77)
+    y_d = fused(a0, extra0, "observation", p=0.25).float()
+    ops.reseed(77)
+    seed = ops.next_seeds(1)
+    y_ref = ops.dropout_apply(fused(a0, extra0, "observation").contiguous(), 0.25, seed).float()
+    assert torch.equal(y_d, y_ref) and float((y_d == 0).float().mean()) > 0.15
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+def test_ln_rowdot_equals_layernorm_dropout_rowdot(ops, dtype, p_drop):
+    """vlni_ln_rowdot_fwd (the prediction heads' LayerNorm + dropout + Linear(768 -> 1) + masked_fill in one launch, vilmodel_cmt.py:953-963,1200)
+    against ops.layer_norm -> the library's dropout -> ops.row_dot: the same logits (same roundings, same summation order) and gradients."""
+    torch.manual_seed(4)
+    rows, H = 5 * 37, 768
+    x0 = torch.randn(rows, H).cuda().to(dtype)
+    g = (1 + 0.1 * torch.randn(H)).cuda().requires_grad_(True)
+    b = (0.1 * torch.randn(H)).cuda().requires_grad_(True)
+    w = (0.05 * torch.randn(1, H)).cuda().requires_grad_(True)
+    bias = torch.randn(1).cuda().requires_grad_(True)
+    mask = (torch.rand(rows) < 0.3).cuda()
+    wt = torch.randn(rows).cuda()
+    res = []
+    for fused in (False, True):
+        x = x0.clone().requires_grad_(True)
+        for t in (g, b, w, bias):
+            t.grad = None
+        ops.reseed(99)
+        if fused:
+            lg = ops.ln_rowdot(x, g, b, w, bias, mask, p_drop=p_drop, training=True)
+        else:
+            h = ops.layer_norm(x, g, b, 1e-12)
+            if p_drop:
+                h = ops._TapeDropout.apply(h, p_drop, ops.next_seeds(1))
+            lg = ops.row_dot(h, w, bias, mask)
+        fin = torch.isfinite(lg)
+        assert torch.equal(~fin, mask)
+        (lg[fin] * wt[fin]).sum().backward()
+        res.append((lg.detach().clone(), [t.grad.clone() for t in (x, g, b, w, bias)]))
+    (l0, g0), (l1, g1) = res
+    fin = torch.isfinite(l0)
+    # same arithmetic, but the compiler contracts the two kernels' multiply-adds differently: last-bit differences in float32, and a rare
+    # flipped rounding of one of the 768 activation-dtype elements of a row in bf16
+    tol = 2e-6 if dtype == torch.float32 else 1e-3
+    assert (l0[fin] - l1[fin]).abs().max().item() <= tol * l0[fin].abs().max().item()
+    for u, v in zip(g0, g1):
+        assert (u.float() - v.float()).abs().max().item() <= max(tol, 1e-5) * max(1.0, u.float().abs().max().item())
+
+
 def test_small_ops(ops):
     import torch.nn.functional as F
     torch.manual_seed(0)

@@ -82,6 +82,8 @@ SIGNATURES = {
     "vlni_optim_prepare_groups": [P, F, F, F, P, P, P, I, I, P],
     "vlni_adamw_step_groups": [P, P, P, P, P, I, L, P, P, P, I, F, F, F, F, P, P],
     "vlni_scale_cast": [I, I, P, P, L, F, P],
+    "vlni_embed_combine_fwd": [I, P, L, P, P, P, L, I, P, P, P, P, P, L, P, P, P, P, P, P, P, F, P, P, P, L, P, P, P, P, P, P, F, U, I, I, P],
+    "vlni_ln_rowdot_fwd": [I, P, L, P, P, F, P, P, P, P, P, P, P, F, U, I, I, P],
     "vlni_self_att_block_fwd": [P, P], "vlni_self_att_block_bwd": [P, P], "vlni_ffn_block_fwd": [P, P], "vlni_ffn_block_bwd": [P, P],
 }
 

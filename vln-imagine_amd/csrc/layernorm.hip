@@ -242,6 +242,170 @@ __global__ __launch_bounds__(256) void sum_ln_fwd_kernel(SumP sp, const float* _
   }
 }
 
+// ---- fused "embed and combine" (round 5): the observation / history / panorama / map-node embeddings as ONE launch ----
+//   y = dropout( [LN_o]( [LN_a](a) + LN_b(f W_b^T + b_b) + extra + row + table[idx] + table2[idx2] ) )
+// a: the image linear's output [rows, H] (a GEMM of its own); f: K <= 16 float32 angle / position features per row; row: one broadcast
+// float32 row; table / table2: float32 embedding tables gathered by int64 row indices; extra: one more dense [rows, H] activation
+// (HistoryEmbeddings: the mean of the encoded panorama). Replaces, per call, LayerNorm + small-K linear + LayerNorm + sum-LayerNorm +
+// dropout (ImageEmbeddings R:535-544, HistoryEmbeddings R:596-618, D:1087-1131, D:1140-1156) - five launches of 5-8 us on the critical path in
+// front of the first cross-modal layer. Every intermediate the unfused operators round to the activation type is rounded here the same
+// way (LN_a / LN_b outputs, the small linear's output, the pre-LN sum), so the results are the unfused ones bit for bit; what the
+// backward needs is written out: the small linear's output, the pre-LN sum and the three LayerNorms' statistics.
+struct EmbedP {
+  const void* a; long lda; const float* ga; const float* ba;
+  const float* f; long ldf; int K; const float* Wb; const float* bb; const float* gb; const float* beb;
+  const void* extra; long lde;
+  const float* row; const float* table; const long* idx; const float* table2; const long* idx2;
+  const float* go; const float* bo; float eps;
+  void* linb; void* xsum; void* y; long ldy;
+  float* mean_a; float* rstd_a; float* mean_b; float* rstd_b; float* mean_o; float* rstd_o;
+  unsigned drop_thr, drop_seed; float drop_inv; const unsigned* sbase;
+  int rows;
+};
+template <typename T> __device__ __forceinline__ float rt(float x) { return (float)(T)x; }       // round to the activation type and back
+template <> __device__ __forceinline__ float rt<float>(float x) { return x; }
+
+template <typename T, int NC>
+__device__ __forceinline__ void ln_inplace(f32x4 (&v)[NC], const float* __restrict__ g, const float* __restrict__ b, float eps, int lane,
+                                           float& mu, float& rs) {
+  constexpr int H = 256 * NC;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+  mu = wave_sum(s) * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float d = v[c][j] - mu;
+      q += d * d;
+    }
+  rs = 1.0f / sqrtf(wave_sum(q) * (1.0f / H) + eps);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const f32x4 gv = *(const f32x4*)(g + c * 256 + lane * 4), bv = *(const f32x4*)(b + c * 256 + lane * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[c][j] = rt<T>((v[c][j] - mu) * rs * gv[j] + bv[j]);     // what the unfused LayerNorm stores
+  }
+}
+
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void embed_combine_kernel(EmbedP p) {
+  constexpr int H = 256 * NC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned seed = p.drop_thr ? eff_seed(p.drop_seed, p.sbase) : 0u;
+  for (int row = blockIdx.x * WAVES + wave; row < p.rows; row += gridDim.x * WAVES) {
+    f32x4 v[NC], t[NC];
+    float mu, rs;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = DT<T>::ld4((const T*)p.a + (long)row * p.lda + c * 256 + lane * 4);
+    if (p.ga) {
+      ln_inplace<T, NC>(v, p.ga, p.ba, p.eps, lane, mu, rs);
+      if (lane == 0) { p.mean_a[row] = mu; p.rstd_a[row] = rs; }
+    }
+    if (p.f) {
+      float fr[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) fr[k] = k < p.K ? p.f[(long)row * p.ldf + k] : 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int col = c * 256 + lane * 4 + j;
+          float acc = p.bb ? p.bb[col] : 0.f;
+#pragma unroll
+          for (int k = 0; k < 16; ++k)
+            if (k < p.K) acc += fr[k] * p.Wb[(long)col * p.K + k];
+          t[c][j] = acc;
+        }
+        if (p.linb) DT<T>::st4((T*)p.linb + (long)row * H + c * 256 + lane * 4, t[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[c][j] = rt<T>(t[c][j]);                               // normalise what the backward will re-read
+      }
+      ln_inplace<T, NC>(t, p.gb, p.beb, p.eps, lane, mu, rs);
+      if (lane == 0) { p.mean_b[row] = mu; p.rstd_b[row] = rs; }
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[c] += t[c];
+    }
+    if (p.row) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[c] += *(const f32x4*)(p.row + c * 256 + lane * 4);
+    }
+    if (p.table) {
+      const long r = p.idx[row];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[c] += *(const f32x4*)(p.table + r * H + c * 256 + lane * 4);
+    }
+    if (p.table2) {
+      const long r = p.idx2[row];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[c] += *(const f32x4*)(p.table2 + r * H + c * 256 + lane * 4);
+    }
+    if (p.extra) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) v[c] += DT<T>::ld4((const T*)p.extra + (long)row * p.lde + c * 256 + lane * 4);
+    }
+    if (p.go) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        DT<T>::st4((T*)p.xsum + (long)row * H + c * 256 + lane * 4, v[c]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[c][j] = rt<T>(v[c][j]);
+      }
+      ln_inplace<T, NC>(v, p.go, p.bo, p.eps, lane, mu, rs);
+      if (lane == 0) { p.mean_o[row] = mu; p.rstd_o[row] = rs; }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (p.drop_thr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[c][j] *= drop_scale((unsigned)((long)row * H + c * 256 + lane * 4 + j), seed, p.drop_thr, p.drop_inv);
+      }
+      DT<T>::st4((T*)p.y + (long)row * p.ldy + c * 256 + lane * 4, v[c]);
+    }
+  }
+}
+
+// ---- fused prediction-head tail (round 5): logits[r] = mask[r] ? -inf : <dropout(LN(x[r])), w> + bias ----
+// NextActionPrediction R:953-963 (LayerNorm, Dropout, Linear(768 -> 1), then masked_fill R:1200) and DUET's ClsPrediction D:1009-1020 after their
+// first Linear + ReLU: LayerNorm + dropout + row dot were three launches of ~5 us at the end of every step. hd (the dropped LayerNorm output, what
+// the row dot's weight gradient needs) and the statistics are written for the backward, which stays vlni_rowdot_bwd + the mask + vlni_layernorm_bwd.
+// Same roundings and the same summation order as the three kernels: identical results.
+template <typename T, int NC>
+__global__ __launch_bounds__(256) void ln_rowdot_kernel(const T* __restrict__ x, long ldx, const float* __restrict__ g, const float* __restrict__ b,
+                                                        float eps, T* __restrict__ hd, float* __restrict__ mean, float* __restrict__ rstd,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        const unsigned char* __restrict__ mask, float* __restrict__ out, unsigned thr,
+                                                        unsigned seed0, float inv, const unsigned* sbase, int rows) {
+  constexpr int H = 256 * NC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned seed = thr ? eff_seed(seed0, sbase) : 0u;
+  for (int row = blockIdx.x * WAVES + wave; row < rows; row += gridDim.x * WAVES) {
+    f32x4 v[NC];
+    float mu, rs;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) v[c] = DT<T>::ld4(x + (long)row * ldx + c * 256 + lane * 4);
+    ln_inplace<T, NC>(v, g, b, eps, lane, mu, rs);
+    float a = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      if (thr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[c][j] = rt<T>(v[c][j] * drop_scale((unsigned)((long)row * H + c * 256 + lane * 4 + j), seed, thr, inv));
+      }
+      DT<T>::st4(hd + (long)row * H + c * 256 + lane * 4, v[c]);
+      const f32x4 ww = *(const f32x4*)(w + c * 256 + lane * 4);
+      a += v[c][0] * ww[0] + v[c][1] * ww[1] + v[c][2] * ww[2] + v[c][3] * ww[3];
+    }
+    a = wave_sum(a);
+    if (lane == 0) {
+      mean[row] = mu; rstd[row] = rs;
+      out[row] = (mask && mask[row]) ? -INFINITY : a + (bias ? bias[0] : 0.f);
+    }
+  }
+}
+
 int ln_grid(int rows) { return max(1, min(cdiv(rows, WAVES), 2048)); }
 int ln_bwd_grid(int rows) { return max(1, min(cdiv(rows, BWAVES), 128)); }
 
@@ -387,6 +551,52 @@ extern "C" int vlni_sum_layernorm_fwd(int dtype, int n, const void* const* src, 
     _Float16* yy = (_Float16*)y; _Float16* xs = (_Float16*)xsum;
     LN_DISPATCH(sum_ln_fwd_kernel, TT, sp, gamma, beta, eps, yy, ldy, xs, ldxs, mean, rstd, rows);
   }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// logits = masked(<dropout(LayerNorm(x)), w> + bias) in one launch (see ln_rowdot_kernel). hd [rows, H], mean / rstd [rows], out [rows] float32.
+extern "C" int vlni_ln_rowdot_fwd(int dtype, const void* x, long ldx, const float* gamma, const float* beta, float eps, void* hd, float* mean,
+                                  float* rstd, const float* w, const float* bias, const unsigned char* mask, float* out, float drop_p,
+                                  unsigned drop_seed, int rows, int H, void* stream) {
+  int rc = ln_check("ln_rowdot_fwd", dtype, rows, H, ldx);
+  if (rc) return rc;
+  VLNI_CHECK(x && gamma && beta && hd && mean && rstd && w && out, VLNI_EINVAL, "ln_rowdot_fwd: null pointer");
+  VLNI_CHECK(drop_p >= 0.f && drop_p < 1.f, VLNI_EINVAL, "ln_rowdot_fwd: dropout p=%f", drop_p);
+  const unsigned thr = drop_thr(drop_p);
+  const float inv = 1.0f / (1.0f - drop_p);
+  if (dtype == VLNI_F32) { using TT = float; LN_DISPATCH(ln_rowdot_kernel, TT, (const float*)x, ldx, gamma, beta, eps, (float*)hd, mean, rstd, w, bias, mask, out, thr, drop_seed, inv, vlni_seed_base(), rows); }
+  else if (dtype == VLNI_BF16) { using TT = __bf16; LN_DISPATCH(ln_rowdot_kernel, TT, (const __bf16*)x, ldx, gamma, beta, eps, (__bf16*)hd, mean, rstd, w, bias, mask, out, thr, drop_seed, inv, vlni_seed_base(), rows); }
+  else { using TT = _Float16; LN_DISPATCH(ln_rowdot_kernel, TT, (const _Float16*)x, ldx, gamma, beta, eps, (_Float16*)hd, mean, rstd, w, bias, mask, out, thr, drop_seed, inv, vlni_seed_base(), rows); }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
+// Fused embed-and-combine forward (see embed_combine_kernel). Optional parts are NULL: ga/ba (no LayerNorm on a), f (no small-K branch), extra,
+// row, table/idx, table2/idx2, go/bo (no outer LayerNorm: xsum / mean_o / rstd_o unused), drop_p 0. linb [rows, H], xsum [rows, H] dense.
+extern "C" int vlni_embed_combine_fwd(int dtype, const void* a, long lda, const float* ga, const float* ba, const float* f, long ldf, int K,
+                                      const float* Wb, const float* bb, const float* gb, const float* beb, const void* extra, long lde,
+                                      const float* row, const float* table, const long* idx, const float* table2, const long* idx2,
+                                      const float* go, const float* bo, float eps, void* linb, void* xsum, void* y, long ldy, float* mean_a,
+                                      float* rstd_a, float* mean_b, float* rstd_b, float* mean_o, float* rstd_o, float drop_p, unsigned drop_seed,
+                                      int rows, int H, void* stream) {
+  int rc = ln_check("embed_combine_fwd", dtype, rows, H, lda < ldy ? lda : ldy);
+  if (rc) return rc;
+  VLNI_CHECK(a && y, VLNI_EINVAL, "embed_combine_fwd: null a / y");
+  VLNI_CHECK((ga == nullptr) == (ba == nullptr) && (ga == nullptr || (mean_a && rstd_a)), VLNI_EINVAL, "embed_combine_fwd: LN_a parameters / statistics");
+  VLNI_CHECK(f == nullptr || (K >= 1 && K <= 16 && Wb && gb && beb && mean_b && rstd_b), VLNI_EINVAL, "embed_combine_fwd: small-K branch (K=%d)", K);
+  VLNI_CHECK((go == nullptr) == (bo == nullptr) && (go == nullptr || (xsum && mean_o && rstd_o)), VLNI_EINVAL, "embed_combine_fwd: outer LayerNorm");
+  VLNI_CHECK((table == nullptr) == (idx == nullptr) && (table2 == nullptr) == (idx2 == nullptr), VLNI_EINVAL, "embed_combine_fwd: table without index");
+  VLNI_CHECK(extra == nullptr || lde % 4 == 0, VLNI_EINVAL, "embed_combine_fwd: extra stride %ld", lde);
+  VLNI_CHECK(drop_p >= 0.f && drop_p < 1.f, VLNI_EINVAL, "embed_combine_fwd: dropout p=%f", drop_p);
+  EmbedP p;
+  p.a = a; p.lda = lda; p.ga = ga; p.ba = ba; p.f = f; p.ldf = ldf; p.K = K; p.Wb = Wb; p.bb = bb; p.gb = gb; p.beb = beb; p.extra = extra; p.lde = lde;
+  p.row = row; p.table = table; p.idx = idx; p.table2 = table2; p.idx2 = idx2; p.go = go; p.bo = bo; p.eps = eps; p.linb = linb; p.xsum = xsum; p.y = y;
+  p.ldy = ldy; p.mean_a = mean_a; p.rstd_a = rstd_a; p.mean_b = mean_b; p.rstd_b = rstd_b; p.mean_o = mean_o; p.rstd_o = rstd_o;
+  p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p); p.sbase = vlni_seed_base(); p.rows = rows;
+  if (dtype == VLNI_F32) { using TT = float; LN_DISPATCH(embed_combine_kernel, TT, p); }
+  else if (dtype == VLNI_BF16) { using TT = __bf16; LN_DISPATCH(embed_combine_kernel, TT, p); }
+  else { using TT = _Float16; LN_DISPATCH(embed_combine_kernel, TT, p); }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

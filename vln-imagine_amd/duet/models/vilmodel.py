@@ -57,6 +57,7 @@ class AlignWithContrastiveLossReverie(AlignWithContrastiveLoss):
 AlignWithContrastiveLossWithNegativeSamplesReverie = AlignWithContrastiveLossReverie
 
 
+FUSED_EMBED = os.environ.get("VLNI_FUSED_EMBED", "1") == "1"     # A/B switch (round 5): panorama / map-node / viewpoint embeddings through ops.embed_combine
 CACHE_TEXT_KV = os.environ.get("VLNI_CACHE_TEXT_KV", "1") == "1"
 DUAL_BRANCHES = os.environ.get("VLNI_DUET_DUAL", "1") == "1"      # global + local encoder layers as dual-problem launches
 
@@ -157,6 +158,8 @@ class ClsPrediction(nn.Module):
 
     def forward(self, x, neg_inf_mask=None):
         n = self.net
+        if FUSED_EMBED:              # LayerNorm + Linear(768 -> 1) (+ masked_fill): one launch (ops.ln_rowdot)
+            return ops.ln_rowdot(ops.linear(x, n[0].weight, n[0].bias, act=2), n[2].weight, n[2].bias, n[3].weight, n[3].bias, neg_inf_mask, eps=HID_EPS)
         h = ops.layer_norm(ops.linear(x, n[0].weight, n[0].bias, act=2), n[2].weight, n[2].bias, HID_EPS)
         return ops.row_dot(h, n[3].weight, n[3].bias, neg_inf_mask)
 
@@ -246,6 +249,16 @@ class GlocalTextPathNavCMT(nn.Module):
         that a captured step contains no length -> mask conversion of its own (duet.buckets)."""
         dt, ie = self.compute_dtype, self.img_embeddings
         B, S, _ = view_img_fts.shape
+        if FUSED_EMBED and obj_img_fts is None:        # LN(img linear) + LN(loc linear) + nav-type + token-type -> LN -> dropout: the GEMM + ONE launch
+            a = ops.linear(view_img_fts, ie.img_linear.weight, ie.img_linear.bias, out_dtype=dt)
+            x = ops.embed_combine(a, dt, ln_a=(ie.img_layer_norm.weight, ie.img_layer_norm.bias),
+                                  small=(loc_fts, ie.loc_linear.weight, ie.loc_linear.bias, ie.loc_layer_norm.weight, ie.loc_layer_norm.bias),
+                                  row=self.embeddings.token_type_embeddings.weight[1], table=(ie.nav_type_embedding.weight, nav_types.reshape(-1).contiguous()),
+                                  ln_o=(ie.layer_norm.weight, ie.layer_norm.bias), eps=HID_EPS, p_drop=self.config.hidden_dropout_prob, training=self.training)
+            masks = pano_masks if pano_masks is not None else torch.arange(S, device=x.device)[None, :] < view_lens[:, None]   # gen_seq_masks
+            if ie.pano_encoder is not None:
+                x = ie.pano_encoder(x, masks)
+            return x, masks
         ti = ops.layer_norm(ops.linear(view_img_fts, ie.img_linear.weight, ie.img_linear.bias, out_dtype=dt),
                             ie.img_layer_norm.weight, ie.img_layer_norm.bias, HID_EPS)
         pano_lens = view_lens
@@ -299,12 +312,18 @@ class GlocalTextPathNavCMT(nn.Module):
         c, dt = self.config, self.compute_dtype
         ge, le = self.global_encoder, self.local_encoder
         B, G = gmap_masks.shape
-        gmap = gmap_img_embeds.to(dt) + ge.gmap_step_embeddings.weight.index_select(0, gmap_step_ids.reshape(-1)).view(*gmap_step_ids.shape, -1).to(dt) \
-            + ge.gmap_pos_embeddings.embed(gmap_pos_fts, dt)
+        if FUSED_EMBED:                 # node image + step embedding + LN(Linear(position)) / view token + LN(Linear(position)): one launch each (:1140-1156)
+            gp, vpp = ge.gmap_pos_embeddings, le.vp_pos_embeddings
+            gmap = ops.embed_combine(gmap_img_embeds.to(dt), dt, small=(gmap_pos_fts, gp[0].weight, gp[0].bias, gp[1].weight, gp[1].bias),
+                                     table=(ge.gmap_step_embeddings.weight, gmap_step_ids.reshape(-1).contiguous()), eps=HID_EPS)
+            vp = ops.embed_combine(vp_img_embeds.to(dt), dt, small=(vp_pos_fts, vpp[0].weight, vpp[0].bias, vpp[1].weight, vpp[1].bias), eps=HID_EPS)
+        else:
+            gmap = gmap_img_embeds.to(dt) + ge.gmap_step_embeddings.weight.index_select(0, gmap_step_ids.reshape(-1)).view(*gmap_step_ids.shape, -1).to(dt) \
+                + ge.gmap_pos_embeddings.embed(gmap_pos_fts, dt)
+            vp = vp_img_embeds.to(dt) + le.vp_pos_embeddings.embed(vp_pos_fts, dt)
         sprels = None
         if ge.sprel_linear is not None:                                                     # reference :1145-1147
             sprels = torch.addcmul(ge.sprel_linear.bias[0], gmap_pair_dists, ge.sprel_linear.weight[0, 0])
-        vp = vp_img_embeds.to(dt) + le.vp_pos_embeddings.embed(vp_pos_fts, dt)
         def language_side():
             """text (+ imagination tokens) and its additive key mask (reference :1110-1125)"""
             txt, tm = txt_embeds.to(dt), txt_masks

@@ -311,6 +311,12 @@ class TapedEpisode:
                 if self.side is not None:
                     self.h_event = torch.cuda.Event()
                     self.h_event.record(self.side)
+        # teacher forcing holds the observation features of all T steps: ONE cast to the compute type per episode instead of one per step
+        # (sampled rollouts write step t + 1's observation after step t: they keep the per-step cast inside ops.linear)
+        self.ob_feats = et.full("ob_img_feats")
+        cdt = getattr(model, "compute_dtype", None)
+        if not self.lag and dev.type == "cuda" and cdt in (torch.bfloat16, torch.float16) and self.ob_feats.dtype != cdt:
+            self.ob_feats = self._ops.cast(self.ob_feats, cdt)
         # teacher forcing knows the masks of all T steps here: their additive / boolean forms once per episode, not once per step
         self.vm_full = self.nav0_full = None
         if not self.lag and dev.type == "cuda" and _EPISODE_MASKS:
@@ -377,7 +383,7 @@ class TapedEpisode:
                         hist_pano_img_feats=self._drop(f("hist_pano_img_feats")[sl]), hist_pano_ang_feats=f("hist_pano_ang_feats")[sl]), side)
             res = model(
                 "visual", txt_embeds=self.txt, txt_masks=et.txt_masks, hist_embeds=hb[t], hist_masks=hm,
-                ob_img_feats=self._drop(f("ob_img_feats")[sl]), ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
+                ob_img_feats=self._drop(self.ob_feats[sl]), ob_ang_feats=f("ob_ang_feats")[sl], ob_nav_types=f("ob_nav_types")[sl],
                 ob_masks=f("ob_masks")[sl], imagine_embeds=self.img, imagine_masks=self.im_masks, lang_side=self.ls,
                 vis_mask_add=self.vm_full[sl] if self.vm_full is not None else None,
                 ob_is_nav0=self.nav0_full[sl] if self.nav0_full is not None else None, **({"hist_step": hist_step} if lock else {}))
@@ -428,7 +434,7 @@ class TapedEpisode:
         with tape.ghost("visual", compute=self.ghost_compute):
             logits, txt_o, hist_o, ob_o = model(
                 "visual", txt_embeds=rep(self.txt), txt_masks=rep(et.txt_masks), hist_embeds=hist.reshape(T * B, T, H), hist_masks=hm_full,
-                ob_img_feats=self._drop(f("ob_img_feats")), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
+                ob_img_feats=self._drop(self.ob_feats), ob_ang_feats=f("ob_ang_feats"), ob_nav_types=f("ob_nav_types"),
                 ob_masks=f("ob_masks"), imagine_embeds=rep(self.img) if self.use_imagine else None,
                 imagine_masks=rep(self.im_masks) if self.use_imagine else None,
                 lang_side=self.ls.repeat(T) if self.ls is not None else None,

@@ -22,6 +22,7 @@ from vln_imagine_amd import ops
 
 HID_EPS = 1e-12
 LANG_QKV_ONCE = os.environ.get("VLNI_LANG_QKV_ONCE", "1") == "1"      # A/B switch (bench): x-layer 0's language Q / K / V once per episode
+FUSED_EMBED = os.environ.get("VLNI_FUSED_EMBED", "1") == "1"          # A/B switch (round 5): observation / history embeddings through ops.embed_combine
 
 
 def _att(m):
@@ -265,6 +266,12 @@ class ImageEmbeddings(_FeatEmbed):
 
     def forward(self, img, ang, type_row, nav_types, dt):
         B, S, _ = img.shape
+        if FUSED_EMBED:             # LN(img linear) + LN(angle linear) + type row + nav-type embedding -> LN -> dropout: the image GEMM + ONE launch
+            a = ops.linear(img, self.img_linear.weight, self.img_linear.bias, out_dtype=dt)
+            return ops.embed_combine(a, dt, ln_a=(self.img_layer_norm.weight, self.img_layer_norm.bias),
+                                     small=(ang, self.ang_linear.weight, self.ang_linear.bias, self.ang_layer_norm.weight, self.ang_layer_norm.bias),
+                                     row=type_row, table=(self.nav_type_embedding.weight, nav_types.reshape(-1).contiguous()) if nav_types is not None else None,
+                                     ln_o=(self.layer_norm.weight, self.layer_norm.bias), eps=HID_EPS, p_drop=self.p_drop, training=self.training)
         ti, ta = self._feat(img, ang, "", dt)
         srcs = [(ti, "dense", None), (ta, "dense", None), (type_row, "bcast", None)]
         if nav_types is not None:
@@ -308,6 +315,19 @@ class HistoryEmbeddings(_FeatEmbed):
         """First half of the step path (:596-610): the sources of the final sum-LayerNorm and the panorama encoder's input (None without
         hist_enc_pano). Split from combine() so that a lockstep step (NavCMT `visual` with hist_step=) can run the encoder's layers beside
         the cross-modal layers."""
+        if FUSED_EMBED:
+            a = ops.linear(img, self.img_linear.weight, self.img_linear.bias, out_dtype=dt)
+            if pos_ids.numel() == 1:                      # one step for the whole batch (the agent's per-step call)
+                row, table = self.position_embeddings.weight.index_select(0, pos_ids.reshape(-1)) + self.type_embedding.weight, None
+            else:                                         # per-row step ids (time-batched teacher forcing)
+                row, table = self.type_embedding.weight, (self.position_embeddings.weight, pos_ids.reshape(-1).contiguous())
+            pe = None
+            if self.pano_encoder is not None:             # LN(pano img linear) + LN(pano angle linear) -> dropout (:603-610): the GEMM + one launch
+                pa_ = ops.linear(pano_img, self.pano_img_linear.weight, self.pano_img_linear.bias, out_dtype=dt)
+                pe = ops.embed_combine(pa_, dt, ln_a=(self.pano_img_layer_norm.weight, self.pano_img_layer_norm.bias),
+                                       small=(pano_ang, self.pano_ang_linear.weight, self.pano_ang_linear.bias, self.pano_ang_layer_norm.weight,
+                                              self.pano_ang_layer_norm.bias), eps=HID_EPS, p_drop=self.p_drop, training=self.training)
+            return ("fused", a, ang, row, table), pe
         ti, ta = self._feat(img, ang, "", dt)
         if pos_ids.numel() == 1:                          # one step for the whole batch (the agent's per-step call)
             row = self.position_embeddings.weight.index_select(0, pos_ids.reshape(-1)) + self.type_embedding.weight
@@ -325,6 +345,12 @@ class HistoryEmbeddings(_FeatEmbed):
     def combine(self, srcs, pano_out, B, dt):
         """Second half (:611-618): mean over the encoded panorama, sum of the sources, LayerNorm, dropout."""
         g, b = self.layer_norm.weight, self.layer_norm.bias
+        if isinstance(srcs, tuple) and srcs[0] == "fused":
+            _, a, ang, row, table = srcs
+            return ops.embed_combine(a, dt, ln_a=(self.img_layer_norm.weight, self.img_layer_norm.bias),
+                                     small=(ang, self.ang_linear.weight, self.ang_linear.bias, self.ang_layer_norm.weight, self.ang_layer_norm.bias),
+                                     row=row, table=table, extra=ops.seq_mean(pano_out) if pano_out is not None else None, ln_o=(g, b), eps=HID_EPS,
+                                     p_drop=self.p_drop, training=self.training)
         if pano_out is not None:
             pm = ops.seq_mean(pano_out)
             if len(srcs) == 4:                            # the sum kernel takes 4 sources: fold the type row into the pano mean
@@ -501,6 +527,9 @@ class NextActionPrediction(nn.Module):
 
     def forward(self, x, neg_inf_mask):
         n = self.net
+        if FUSED_EMBED:              # LayerNorm + dropout + Linear(768 -> 1) + masked_fill: one launch (ops.ln_rowdot)
+            return ops.ln_rowdot(ops.linear(x, n[0].weight, n[0].bias, act=2), n[2].weight, n[2].bias, n[4].weight, n[4].bias, neg_inf_mask,
+                                 eps=HID_EPS, p_drop=n[3].p, training=n[3].training)
         h = ops.layer_norm(ops.linear(x, n[0].weight, n[0].bias, act=2), n[2].weight, n[2].bias, HID_EPS)
         return ops.row_dot(ops.dropout(h, n[3].p, n[3].training), n[4].weight, n[4].bias, neg_inf_mask)
 

@@ -2401,6 +2401,108 @@ class _SumLayerNorm(torch.autograd.Function):
         return (None, None, None, None, None, dg, db) + tuple(grads)
 
 
+class _EmbedCombine(torch.autograd.Function):
+    """y = dropout([LN_o]([LN_a](a) + LN_b(f W_b^T + b_b) + row + table[idx] + table2[idx2] + extra)) - the observation / history / panorama /
+    map-node embeddings in ONE launch (vlni_embed_combine_fwd; ImageEmbeddings vilmodel_cmt.py:535-544, HistoryEmbeddings :596-618, DUET
+    vilmodel.py:1087-1131,1140-1156). The backward runs the operators the unfused graph ran (dropout mask, LayerNorm backward x <= 3, the
+    small-K linear's weight gradient, column sum, row scatter): it is batched over the episode anyway. Optional parts are None."""
+
+    @staticmethod
+    def forward(ctx, a, f, extra, idx, idx2, eps, p_drop, seed, out_dtype, ga, ba, Wb, bb, gb, beb, row, table, table2, go, bo):
+        H = a.shape[-1]
+        a2 = _rows(_chk(a, "a"))
+        assert a2.dtype == out_dtype, "embed_combine: `a` must have the compute dtype"
+        rows, dev = a2.shape[0], a2.device
+        f2 = _rows(f).float() if f is not None else None
+        e2 = _rows(extra) if extra is not None else None
+        y = _new((rows, H), out_dtype, dev)
+        linb = _new((rows, H), out_dtype, dev) if f is not None else None
+        xs = _new((rows, H), out_dtype, dev) if go is not None else None
+        st = lambda on: (_new((rows,), torch.float32, dev), _new((rows,), torch.float32, dev)) if on else (None, None)
+        ma, ra = st(ga is not None)
+        mb, rb = st(f is not None)
+        mo, ro = st(go is not None)
+        dropping = p_drop > 0.0
+        if not _ghost():
+            row32 = row.reshape(-1) if row is not None else None
+            _lib.call("vlni_embed_combine_fwd", _DT[out_dtype], a2.data_ptr(), a2.stride(0), _p(ga), _p(ba), _p(f2), f2.stride(0) if f2 is not None else 0,
+                      f2.shape[1] if f2 is not None else 0, _p(Wb), _p(bb), _p(gb), _p(beb), _p(e2), e2.stride(0) if e2 is not None else 0, _p(row32),
+                      _p(table), _p(idx), _p(table2), _p(idx2), _p(go), _p(bo), eps, _p(linb), _p(xs), y.data_ptr(), H, _p(ma), _p(ra), _p(mb), _p(rb),
+                      _p(mo), _p(ro), p_drop if dropping else 0.0, _shift(seed, rows * H) if dropping else 0, rows, H, _st())
+        ctx.save_for_backward(a2, f2, linb, xs, ma, ra, mb, rb, mo, ro, idx, idx2)
+        ctx.P = (ga, ba, Wb, bb, gb, beb, row, table, table2, go, bo)
+        ctx.cfg = (p_drop if dropping else 0.0, seed, a.shape, extra.shape if extra is not None else None, extra.dtype if extra is not None else None)
+        return y.view(a.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a2, f2, linb, xs, ma, ra, mb, rb, mo, ro, idx, idx2 = ctx.saved_tensors
+        ga, ba, Wb, bb, gb, beb, row, table, table2, go, bo = ctx.P
+        p_drop, seed, ashape, eshape, edtype = ctx.cfg
+        ng = ctx.needs_input_grad
+        H = a2.shape[1]
+        d = _rows(dy)
+        if p_drop > 0.0:
+            d = dropout_apply(d, p_drop, seed)
+        g = [None] * 11                                # gradients of ctx.P in order
+        if go is not None:
+            d, g[9], g[10] = _ln_bwd_to(d, xs, go, bo, mo, ro, ng[18] or ng[19])
+        dsum = d
+        da = dsum
+        if ga is not None:
+            da, g[0], g[1] = _ln_bwd_to(dsum, a2, ga, ba, ma, ra, ng[9] or ng[10])
+        if f2 is not None:
+            dl, g[4], g[5] = _ln_bwd_to(dsum, linb, gb, beb, mb, rb, ng[13] or ng[14])
+            if ng[11] or ng[12]:
+                N, K = Wb.shape
+                if _direct(Wb) and (bb is None or _direct(bb)):
+                    _lib.call("vlni_smallk_linear_bwd", _dt(dl), dl.data_ptr(), dl.stride(0), f2.data_ptr(), f2.stride(0), Wb.grad.data_ptr(),
+                              _p(bb.grad if bb is not None else None), f2.shape[0], N, K, _st())
+                else:
+                    g[2] = torch.zeros_like(Wb)
+                    g[3] = torch.zeros((N,), dtype=torch.float32, device=Wb.device) if bb is not None else None
+                    _lib.call("vlni_smallk_linear_bwd", _dt(dl), dl.data_ptr(), dl.stride(0), f2.data_ptr(), f2.stride(0), g[2].data_ptr(), _p(g[3]),
+                              f2.shape[0], N, K, _st())
+        if row is not None and ng[15]:
+            g[6] = colsum(dsum).view(row.shape).to(row.dtype)
+        for k, (tab, ix) in ((7, (table, idx)), (8, (table2, idx2))):
+            if tab is not None and ng[9 + k]:
+                direct = _direct(tab) and tab.grad.is_contiguous()
+                tg = tab.grad if direct else torch.zeros(tab.shape, dtype=torch.float32, device=dsum.device)
+                if SMALL_TABLE_SCATTER and tab.shape[0] <= 8:
+                    _lib.call("vlni_scatter_add_rows_small", _dt(dsum), dsum.data_ptr(), dsum.stride(0), ix.data_ptr(), tg.data_ptr(), dsum.shape[0], H,
+                              tab.shape[0], _st())
+                else:
+                    _lib.call("vlni_scatter_add_rows", _dt(dsum), dsum.data_ptr(), dsum.stride(0), ix.data_ptr(), tg.data_ptr(), dsum.shape[0], H, _st())
+                g[k] = None if direct else tg
+        d_extra = None
+        if eshape is not None and ng[2]:
+            d_extra = (dsum if dsum.dtype == edtype else cast(dsum, edtype)).view(eshape)
+        return (da.view(ashape) if ng[0] else None, None, d_extra, None, None, None, None, None, None) + tuple(g)
+
+
+def embed_combine(a, out_dtype, ln_a=None, small=None, row=None, table=None, table2=None, extra=None, ln_o=None, eps=1e-12, p_drop=0.0, training=False):
+    """a: [.., H] activation in the compute dtype; ln_a = (gamma, beta); small = (features [.., K], W [H, K], bias, gamma, beta); row: a float32 [H] row;
+    table / table2 = (float32 table, int64 row index per output row); extra: one more dense activation; ln_o = (gamma, beta) of the outer LayerNorm;
+    dropout p_drop in training (counter-based mask: inside an episode tape the tape's seed, outside a fresh one)."""
+    p = float(p_drop) if (training and p_drop > 0.0) else 0.0
+    seed = 0
+    if p > 0.0:
+        seed = _TAPE.seed(1) if _TAPE is not None else next_seeds(1)
+    if small is not None and small[0].shape[-1] > 4 and extra is None:
+        # 7- / 14-d position features (DUET): a lane of the fused kernel would read 12 x K weights per row (its columns change with the lane, not
+        # with the row) - 43 KB of W per row and wave at K = 14; the stand-alone small-K kernel keeps a column's weights in registers over the
+        # rows. That branch stays two launches and joins as the dense extra source (measured: DUET 14.05 -> 14.38 ms with it fused).
+        extra = layer_norm(smallk_linear(small[0], small[1], small[2], out_dtype), small[3], small[4], eps).reshape(a.shape)
+        small = None
+    f, Wb, bb, gb, beb = small if small is not None else (None,) * 5
+    ga, ba = ln_a if ln_a is not None else (None, None)
+    go, bo = ln_o if ln_o is not None else (None, None)
+    tab, ix = table if table is not None else (None, None)
+    tab2, ix2 = table2 if table2 is not None else (None, None)
+    return _EmbedCombine.apply(a, f, extra, ix, ix2, eps, p, seed, out_dtype, ga, ba, Wb, bb, gb, beb, row, tab, tab2, go, bo)
+
+
 class _SeqMean(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, lens):
@@ -2456,6 +2558,58 @@ class _RowDot(torch.autograd.Function):
         _lib.call("vlni_rowdot_bwd", _dt(h2), dl.data_ptr(), h2.data_ptr(), h2.stride(0), w.data_ptr(), _p(m8),
                   dh.data_ptr(), dh.stride(0), dw.data_ptr(), _p(dbias), rows, H, _st())
         return dh.view(ctx.shp), dw.view(w.shape), dbias, None
+
+
+class _LnRowDot(torch.autograd.Function):
+    """logits[r] = mask[r] ? -inf : <dropout(LayerNorm(x[r])), w> + bias in ONE launch (vlni_ln_rowdot_fwd): the tail of NextActionPrediction
+    (vilmodel_cmt.py:953-963,1200) and of DUET's ClsPrediction (vilmodel.py:1009-1020). Backward: the row dot's, the mask, LayerNorm's."""
+
+    @staticmethod
+    def forward(ctx, x, g, b, eps, p_drop, seed, w, bias, mask):
+        shp = x.shape
+        x2 = _rows(_chk(x, "x"))
+        rows, H = x2.shape
+        m8 = _u8(mask).reshape(-1) if mask is not None else None
+        hd = _new((rows, H), x2.dtype, x.device)
+        mean = _new((rows,), torch.float32, x.device)
+        rstd = _new((rows,), torch.float32, x.device)
+        out = _new((rows,), torch.float32, x.device)
+        if not _ghost():
+            _lib.call("vlni_ln_rowdot_fwd", _dt(x2), x2.data_ptr(), x2.stride(0), g.data_ptr(), b.data_ptr(), eps, hd.data_ptr(), mean.data_ptr(),
+                      rstd.data_ptr(), w.data_ptr(), _p(bias), _p(m8), out.data_ptr(), p_drop, _shift(seed, rows * H) if p_drop > 0.0 else 0, rows, H, _st())
+        ctx.save_for_backward(x2, hd, mean, rstd, w, m8)
+        ctx.P, ctx.cfg = (g, b, bias), (shp, p_drop, seed)
+        return out.view(shp[:-1])
+
+    @staticmethod
+    def backward(ctx, dl):
+        x2, hd, mean, rstd, w, m8 = ctx.saved_tensors
+        g, b, bias = ctx.P
+        shp, p_drop, seed = ctx.cfg
+        ng = ctx.needs_input_grad
+        rows, H = x2.shape
+        dl = dl.reshape(-1).float().contiguous()
+        dh = torch.empty_like(hd)
+        dw = dbias = None
+        if _direct(w) and (bias is None or _direct(bias)):
+            _lib.call("vlni_rowdot_bwd", _dt(hd), dl.data_ptr(), hd.data_ptr(), hd.stride(0), w.data_ptr(), _p(m8), dh.data_ptr(), dh.stride(0),
+                      w.grad.data_ptr(), _p(bias.grad if bias is not None else None), rows, H, _st())
+        else:
+            dw = torch.zeros((H,), dtype=torch.float32, device=hd.device)
+            dbias = torch.zeros((1,), dtype=torch.float32, device=hd.device) if bias is not None else None
+            _lib.call("vlni_rowdot_bwd", _dt(hd), dl.data_ptr(), hd.data_ptr(), hd.stride(0), w.data_ptr(), _p(m8), dh.data_ptr(), dh.stride(0),
+                      dw.data_ptr(), _p(dbias), rows, H, _st())
+            dw = dw.view(w.shape)
+        if p_drop > 0.0:
+            dh = dropout_apply(dh, p_drop, seed)
+        dx, dg, db = _ln_bwd_to(dh, x2, g, b, mean, rstd, ng[1] or ng[2])
+        return dx.view(shp) if ng[0] else None, dg, db, None, None, None, dw, dbias, None
+
+
+def ln_rowdot(x, g, b, w, bias, mask, eps=1e-12, p_drop=0.0, training=False):
+    p = float(p_drop) if (training and p_drop > 0.0) else 0.0
+    seed = (_TAPE.seed(1) if _TAPE is not None else next_seeds(1)) if p > 0.0 else 0
+    return _LnRowDot.apply(x, g, b, eps, p, seed, w, bias, mask)
 
 
 class _DuetFuse(torch.autograd.Function):
