@@ -388,6 +388,9 @@ def main():
             except Exception as e:                      # one GPU: keep measuring with the eager step and say so
                 failed = f"{type(e).__name__}: {e}"
                 log(f"{what}: graph capture failed ({failed})")
+                if os.environ.get("VLNI_BENCH_TRACEBACK") == "1":
+                    import traceback
+                    traceback.print_exc()
             if world > 1 and agree(failed is not None):
                 # several ranks: a silent fall-back would time a different program (44 instead of 33 ms) under the same headline - stop
                 # instead (--no-graph asks for the eager step explicitly). Every rank reaches this decision BEFORE any replay runs (a

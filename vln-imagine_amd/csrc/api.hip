@@ -25,3 +25,12 @@ extern "C" int vlni_set_dropout_seed_base(const unsigned* device_ptr) {
   g_seed_base = device_ptr;
   return VLNI_OK;
 }
+
+// Host -> device copy of a small table on `stream`. From PINNED host memory this is legal while the stream is being captured (it becomes a
+// memcpy node that re-reads the host bytes on every replay: the caller keeps them alive and unchanged); torch's own copy_ is not.
+extern "C" int vlni_upload(void* dst, const void* src_host, long bytes, void* stream) {
+  VLNI_CHECK(dst && src_host && bytes > 0, VLNI_EINVAL, "upload: dst=%p src=%p bytes=%ld", dst, src_host, bytes);
+  hipError_t e = hipMemcpyAsync(dst, src_host, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+  VLNI_CHECK(e == hipSuccess, VLNI_ELAUNCH, "upload: %s", hipGetErrorString(e));
+  return VLNI_OK;
+}

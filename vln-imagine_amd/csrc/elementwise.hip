@@ -1083,6 +1083,19 @@ extern "C" int vlni_adamw_step(float* p, const float* g, float* m, float* v, voi
   return VLNI_OK;
 }
 
+// out[0] += sum_i slots[32 i]: folds vlni_reduce_parts_sq's spread accumulators into the one the optimizer kernels read
+__global__ __launch_bounds__(64) void sumsq_fold_kernel(const float* __restrict__ slots, int nslots, float* __restrict__ out) {
+  float a = 0.f;
+  for (int i = threadIdx.x; i < nslots; i += 64) a += slots[i * 32];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) out[0] += a;
+}
+extern "C" int vlni_sumsq_fold(const float* slots, int nslots, float* out, void* stream) {
+  VLNI_CHECK(slots && out && nslots >= 1, VLNI_EINVAL, "sumsq_fold: nslots=%d", nslots);
+  hipLaunchKernelGGL(sumsq_fold_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slots, nslots, out);
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
 // sumsq[0] += sum(g^2) (caller zeroes sumsq); then vlni_clip_coef turns it into the clip_grad_norm_ factor.
 extern "C" int vlni_sumsq(const float* g, long n, float* sumsq, void* stream) {
   VLNI_CHECK(n > 0 && n % 4 == 0, VLNI_EINVAL, "sumsq: n=%ld", n);

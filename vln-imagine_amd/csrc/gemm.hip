@@ -95,6 +95,9 @@ extern "C" int vlni_debug_pk_stamps(void* host_dst, int bytes) { return k_bf16::
 extern "C" int vlni_reduce_parts(const void* table, int n_entries, int n_blocks, void* stream) {
   return k_bf16::vlni_reduce_parts(table, n_entries, n_blocks, stream);
 }
+extern "C" int vlni_reduce_parts_sq(const void* table, int n_entries, int n_blocks, float* sumsq, int nslots, void* stream) {
+  return k_bf16::vlni_reduce_parts_sq(table, n_entries, n_blocks, sumsq, nslots, stream);
+}
 // weight gradients: the `_bf16` entry points keep their names; `_h16` take the 16-bit dtype (1 bfloat16, 2 float16) in front
 extern "C" int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb, float* C,
                                            long ldc, int N, int K, float* colsum, int split, int variant, void* stream) {

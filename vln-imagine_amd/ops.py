@@ -8,6 +8,7 @@ Granularity is one autograd node per transformer SUBLAYER (attention block, FFN 
 bidirectional cross-attention block) so that the backward pass is an explicit kernel
 sequence with fused epilogues (bias, GELU / GELU', residual) instead of ~40 tiny nodes.
 """
+import bisect
 import ctypes
 import os
 import weakref
@@ -1039,8 +1040,15 @@ def _split_rows(t, sizes):
 # pre-allocated `.grad` arena views (wgrad atomics, colsum, LayerNorm dgamma/dbeta, embedding scatter) and the
 # autograd functions return None for them: no zero-filled temporaries, no AccumulateGrad add kernels. The mark is per
 # parameter, so a second model in the same process keeps plain autograd accumulation.
-def _direct(*params):
-    return all(p is not None and p.grad is not None and getattr(p, "_vlni_direct", False) for p in params)
+def _direct(*params, queue=False):
+    ok = all(p is not None and p.grad is not None and getattr(p, "_vlni_direct", False) for p in params)
+    if ok and not queue and GRADS.arena is not None:
+        # a kernel is about to ADD into these gradients: one that the reduction also writes (GradArena) is zeroed now if the arena's
+        # zero fill skipped it, and kept out of the stored ranges from here on
+        for p in params:
+            if getattr(p, "_vlni_queued", False):
+                GRADS.mixed(p.grad)
+    return ok
 
 
 def _packed_grad(params):
@@ -1058,6 +1066,7 @@ def _packed_grad(params):
 def _wgrad_to(params, dy, x):
     """Weight gradient of a (possibly row-packed) projection. Returns per-parameter grads or Nones (direct mode)."""
     if _direct(*params):
+        _added(params, ())
         view = _packed_grad(params) if len(params) > 1 else params[0].grad
         if view is not None:
             wgrad(dy, x, out=view)
@@ -1073,6 +1082,7 @@ def _wgrad_to(params, dy, x):
 
 def _bgrad_to(params, dy):
     if _direct(*params):
+        _added(params, ())
         view = _packed_grad(params) if len(params) > 1 else params[0].grad
         if view is not None:
             colsum(dy, out=view)
@@ -1093,6 +1103,200 @@ RESERVE_CUS = 0          # > 0 (train.FlatTrainer with a gradient exchange): one
 TN_BIG = True            # 256 x 256 tiles for episode-long reductions (+10..26 % there, tools/tn_probe.py)
 TN_VARIANT = 5          # LDS-DMA 2-stage, 8 waves: fastest of the five on every episode-level shape (tools/tn_probe.py)
 _WQ = {}
+
+STORE_PARTS = os.environ.get("VLNI_STORE_PARTS", "1") == "1"
+PART_STORE, PART_NOWRITE, PART_SUMSQ = 1 << 16, 1 << 17, 1 << 18        # include/vlni.h VLNI_PART_*
+SUMSQ_SLOTS = 64
+
+
+class GradArena:
+    """Which parts of train.FlatTrainer's gradient arena the batched partial reduction of flush_wgrads() will WRITE this step (store mode).
+
+    The reduction used to add the row-split slabs onto a zero-filled arena: a 4 B / parameter fill, a 4 B / parameter read of the zeros
+    and a separate 4 B / parameter pass for the gradient norm, every step. The ranges one step reduced are what the next step's
+    begin() leaves out of the zero fill (`pending`); the flush stores into exactly those (no read), adds onto anything else, zero-fills
+    what is left of `pending` (a parameter without a gradient this step) and - one rank, first reduction of the step - also leaves each
+    stored range's sum of squares in the trainer's accumulator, so step() only adds the ranges no reduction wrote.
+    Anything else that adds into a pending range (an unsplit weight-gradient launch's float atomics, an immediate weight gradient)
+    goes through touch(), which zero-fills it first. begin() and the flush of one step are either both eager or both in the same
+    captured graph, so a replayed step is consistent with itself whatever ran in between."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.arena = None          # the flat float32 gradient tensor
+        self.known = {}            # element offset -> elements: what the last completed step's reductions stored or added
+        self.pending = {}          # left out of this step's zero fill, not written yet
+        self.seen = {}             # this step's reduction destinations (the next step's `known`)
+        self.sumsq = None          # accumulator the stored ranges' sums of squares go to (None: no folding this step)
+        self.slots = None
+        self.folded = {}           # ranges whose sum of squares is in it
+        self.fold_ok = False
+        self._starts = None
+        self._tables = {}
+        self._prebuilt = None
+        self.never = {}            # offset -> elements: gradients that something besides the reduction also adds into (never stored)
+
+    def _table(self, kind, ranges, flags):
+        """Device table of reduce_parts entries without partials over element ranges (zero fill / sum of squares)."""
+        key = (kind, tuple(ranges))
+        tab = self._tables.get(key)
+        if tab is None:
+            arr = np.zeros((len(ranges),), _PART_DT)
+            blk, base = 0, self.arena.data_ptr()
+            for i, (o, n) in enumerate(ranges):
+                arr[i] = (base + 4 * o, 0, n // 4, 0, flags, blk)
+                blk += -(-(n // 4) // 1024)
+            tab = self._tables[key] = (_dev_table(arr, self.arena.device), len(ranges), blk)
+        return tab
+
+    def _gaps(self, covered):
+        """Complement of `covered` ({offset: elements}, disjoint) in the arena, as (offset, elements) runs."""
+        out, at = [], 0
+        for o in sorted(covered):
+            if o > at:
+                out.append((at, o - at))
+            at = max(at, o + covered[o])
+        if at < self.arena.numel():
+            out.append((at, self.arena.numel() - at))
+        return out
+
+    def begin(self, arena, sumsq=None):
+        """Start of a step (FlatTrainer.zero_grad): zero the arena except what the last step's reductions covered. sumsq: float32
+        [32 (1 + SUMSQ_SLOTS)] - element 0 is the sum the optimizer reads, the slots follow 32 floats apart (vlni_reduce_parts_sq)."""
+        if self.arena is None or self.arena.data_ptr() != arena.data_ptr() or self.arena.numel() != arena.numel():
+            if self.arena is not None:
+                self.end()               # another trainer's arena: nothing of it stays un-zeroed
+            self.reset()
+            self.arena = arena
+        elif self.seen:
+            self.known = self.seen
+        self.seen, self.folded, self._starts = {}, {}, None
+        self.sumsq, self.fold_ok = sumsq, sumsq is not None
+        if sumsq is not None:
+            assert sumsq.numel() == 32 * (1 + SUMSQ_SLOTS)
+            self.slots = sumsq[32:]
+            sumsq.zero_()
+        if not (STORE_PARTS and WGRAD_PARTS and self.known):
+            self.pending = {}
+            arena.zero_()
+            return
+        self.pending = dict(self.known)
+        gaps = self._gaps(self.pending)
+        if gaps:
+            tab = self._table("zero", gaps, PART_STORE)
+            _lib.call("vlni_reduce_parts_sq", tab[0].data_ptr(), tab[1], tab[2], None, 1, _st())
+
+    def end(self):
+        """After the optimizer step: nothing is pending or folded until the next begin()."""
+        if self.pending:                 # a step without a flush (cannot happen through FlatTrainer.step): keep the arena consistent
+            for o, n in list(self.pending.items()):
+                self.arena[o:o + n].zero_()
+            self.pending = {}
+        self.sumsq, self.slots, self.fold_ok, self.folded = None, None, False, {}
+
+    def _overlapping(self, o, n):
+        if self._starts is None:             # sorted once per step: `pending` only shrinks until the next begin()
+            self._starts = sorted(self.pending)
+        st = self._starts
+        i = bisect.bisect_right(st, o) - 1
+        hit = []
+        if i >= 0 and st[i] in self.pending and st[i] + self.pending[st[i]] > o:
+            hit.append(st[i])
+        i += 1
+        while i < len(st) and st[i] < o + n:
+            if st[i] in self.pending:
+                hit.append(st[i])
+            i += 1
+        return hit
+
+    def offset(self, t):
+        return (t.data_ptr() - self.arena.data_ptr()) // 4
+
+    def touch(self, t):
+        """`t` (a view of the arena) is about to be accumulated into by something other than the reduction."""
+        if not self.pending or self.arena is None:
+            return
+        o = self.offset(t)
+        if not 0 <= o < self.arena.numel():
+            return
+        n = t.numel() if t.is_contiguous() else t.stride(0) * t.shape[0]
+        for h in self._overlapping(o, n):
+            self.arena[h:h + self.pending.pop(h)].zero_()
+        self.fold_ok = self.fold_ok and not any(f < o + n and f + m > o for f, m in self.folded.items())
+
+    def mixed(self, t):
+        """`t`'s gradient is both queued for the reduction and added into directly (the same projection called once with operands the
+        grouped launch takes and once without): it stays in the zero-filled, added-onto part of the arena for good."""
+        if self.arena is None:
+            return
+        o = self.offset(t)
+        if 0 <= o < self.arena.numel() and o not in self.never:
+            self.never[o] = t.numel() if t.is_contiguous() else t.stride(0) * t.shape[0]
+            self.touch(t)
+
+    def will_store(self, dst_ptr, n):
+        """Whether the next step stores into this destination if it has this step's structure (flush_wgrads pre-builds that step's table)."""
+        return self.arena is not None and self.seen.get((dst_ptr - self.arena.data_ptr()) // 4) == n
+
+    def claim(self, dst_ptr, n):
+        """Mode flags of a reduction entry for [dst_ptr, + n floats): stored into (left out of the zero fill, first write) or added onto."""
+        if self.arena is None:
+            return 0
+        o = (dst_ptr - self.arena.data_ptr()) // 4
+        if not 0 <= o < self.arena.numel():
+            return 0
+        if self.never and any(f < o + n and f + m > o for f, m in self.never.items()):
+            for h in self._overlapping(o, n):
+                self.arena[h:h + self.pending.pop(h)].zero_()
+            return 0
+        self.seen[o] = n
+        if self.pending.get(o) == n:
+            del self.pending[o]
+            if self.fold_ok:
+                self.folded[o] = n
+                return PART_STORE | PART_SUMSQ
+            return PART_STORE
+        for h in self._overlapping(o, n):                       # a differently shaped view of a skipped range (rare): zero it, then add
+            self.arena[h:h + self.pending.pop(h)].zero_()
+        if any(f < o + n and f + m > o for f, m in self.folded.items()):
+            self.fold_ok = False                                # second reduction onto a folded range: the folded sum is stale
+        return 0
+
+    def leftovers(self, lo=None, hi=None):
+        """Pending ranges (inside [lo, hi) byte addresses) that got no gradient this step: (offset, elements) to zero-fill."""
+        base = self.arena.data_ptr() if self.arena is not None else 0
+        out = []
+        for o in sorted(self.pending):
+            if lo is None or lo <= base + 4 * o < hi:
+                out.append((o, self.pending.pop(o)))
+        return out
+
+    def prebuild(self):
+        """After an eager flush: the device tables the NEXT step needs if it has this step's structure (its zero fill around `seen`, the
+        sum of squares outside it), so that a capture of that step finds them made - a table upload cannot be recorded into a graph."""
+        if self.arena is None or not (STORE_PARTS and WGRAD_PARTS) or not self.seen or self._prebuilt == self.seen:
+            return
+        gaps = self._gaps(self.seen)
+        if gaps:
+            self._table("zero", gaps, PART_STORE)
+            self._table("sumsq", gaps, PART_NOWRITE | PART_SUMSQ)
+        self._prebuilt = dict(self.seen)
+
+    def finish_sumsq(self):
+        """step(): True when the accumulator holds the stored ranges' sums of squares; adds the rest of the arena to it."""
+        if not (self.fold_ok and self.folded and self.sumsq is not None) or self.pending:
+            return False
+        gaps = self._gaps(self.folded)
+        if gaps:
+            tab = self._table("sumsq", gaps, PART_NOWRITE | PART_SUMSQ)
+            _lib.call("vlni_reduce_parts_sq", tab[0].data_ptr(), tab[1], tab[2], self.slots.data_ptr(), SUMSQ_SLOTS, _st())
+        _lib.call("vlni_sumsq_fold", self.slots.data_ptr(), SUMSQ_SLOTS, self.sumsq.data_ptr(), _st())
+        return True
+
+
+GRADS = GradArena()
 
 
 _TN_BEST = {}
@@ -1245,6 +1449,42 @@ def _flush_batch(members, entries):
     return True
 
 
+_PINNED = []          # [pinned uint8 tensor, bytes used]: staging for tables that have to be uploaded while a stream is capturing
+
+
+def reserve_staging(nbytes=1 << 20):
+    """Pinned staging for _dev_table's in-capture uploads; FlatTrainer calls this at construction (pinning is not allowed mid-capture)."""
+    if not _PINNED or _PINNED[-1][0].numel() - _PINNED[-1][1] < nbytes // 2:
+        _PINNED.append([torch.empty(nbytes, dtype=torch.uint8).pin_memory(), 0])
+
+
+def _dev_table(arr, dev):
+    """A host table (numpy) on the device. Outside a capture: an ordinary copy. While the stream is capturing (a launch table that no
+    eager step has needed yet): through a slice of the pinned staging buffer that is never written again, as a memcpy node of the graph."""
+    host = torch.from_numpy(arr.view(np.uint8).reshape(-1))
+    if not torch.cuda.is_current_stream_capturing():
+        return host.to(dev)
+    n = host.numel()
+    if not _PINNED or _PINNED[-1][0].numel() - _PINNED[-1][1] < n:
+        raise RuntimeError(f"a {n}-byte launch table is needed inside a hipGraph capture and the pinned staging buffer is full or missing "
+                           "(ops.reserve_staging() before capturing; one more eager warm-up step also avoids the upload)")
+    buf, used = _PINNED[-1]
+    _PINNED[-1][1] = used + (n + 63) // 64 * 64
+    buf[used:used + n].copy_(host)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    _lib.call("vlni_upload", out.data_ptr(), buf.data_ptr() + used, n, _st())
+    return out
+
+
+def _part_table(entries, dev):
+    arr = np.zeros((len(entries),), _PART_DT)
+    blk = 0
+    for i, (dst, part, n4, stride4, eff) in enumerate(entries):
+        arr[i] = (dst, part, n4, stride4, eff, blk)
+        blk += -(-n4 // 1024)
+    return _dev_table(arr, dev), len(entries), blk
+
+
 def flush_wgrads(lo=None, hi=None):
     """Runs the queued weight/bias gradient reductions (must precede any read of the .grad arena). With (lo, hi): only the
     gradients whose address lies in [lo, hi), in address order (train.FlatTrainer's flush -> all-reduce pipeline)."""
@@ -1306,29 +1546,49 @@ def flush_wgrads(lo=None, hi=None):
                 _lib.call("vlni_gemm_tn_h16_grouped_part", dtid, n, pa, pb, pm, N, K, buf.data_ptr() + 4 * z0 * N * K, N * K, N, K,
                           cpart + 4 * z0 * N, split, variant, _st())
             else:                                            # unsplit (or register-staged) launch: float atomics straight into the arena
+                GRADS.touch(wv); GRADS.touch(bv)
                 _lib.call("vlni_gemm_tn_h16_grouped_v", dtid, n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
                           split, variant, _st())
         if tot:
             # exactly ONE reduction entry per destination: reduce_parts_kernel's read-modify-write of dst is not atomic
             entries.append((wv.data_ptr(), buf.data_ptr(), N * K // 4, N * K // 4, tot))
             entries.append((bv.data_ptr(), cpart, N // 4, N // 4, tot))
+    if GRADS.arena is not None:
+        # store mode (GradArena): a destination the step's zero fill left out is written, not added to; what is left of those gets zeros
+        entries = [(dst, part, n4, stride4, eff | GRADS.claim(dst, 4 * n4)) for dst, part, n4, stride4, eff in entries]
+        base = GRADS.arena.data_ptr()
+        entries += [(base + 4 * o, 0, n // 4, 0, PART_STORE) for o, n in GRADS.leftovers(lo, hi)]
+        dev = GRADS.arena.device
     if entries:
         sig = tuple(entries)
         tab = _PART_TABLES.get(sig)
         if tab is None:
-            arr = np.zeros((len(entries),), _PART_DT)
-            blk = 0
-            for i, (dst, part, n4, stride4, eff) in enumerate(entries):
-                arr[i] = (dst, part, n4, stride4, eff, blk)
-                blk += -(-n4 // 1024)
-            tab = _PART_TABLES[sig] = (torch.from_numpy(arr.view(np.uint8)).to(dev), len(entries), blk)
-        _lib.call("vlni_reduce_parts", tab[0].data_ptr(), tab[1], tab[2], _st())
+            tab = _PART_TABLES[sig] = _part_table(sig, dev)
+        sq = GRADS.slots if GRADS.fold_ok and GRADS.sumsq is not None else None
+        _lib.call("vlni_reduce_parts_sq", tab[0].data_ptr(), tab[1], tab[2], None if sq is None else sq.data_ptr(), SUMSQ_SLOTS, _st())
+        if GRADS.arena is not None and STORE_PARTS and not torch.cuda.is_current_stream_capturing():
+            # the same reduction as the next step will issue it if it has this step's structure (every destination stored, see GradArena.prebuild)
+            flag = PART_STORE | (PART_SUMSQ if GRADS.sumsq is not None else 0)
+            nxt = tuple((dst, part, n4, stride4, (eff & 0xffff) | (flag if GRADS.will_store(dst, 4 * n4) else 0))
+                        for dst, part, n4, stride4, eff in entries if part)
+            if nxt and nxt not in _PART_TABLES:
+                _PART_TABLES[nxt] = _part_table(nxt, dev)
+    if not _WQ and not torch.cuda.is_current_stream_capturing():
+        GRADS.prebuild()
+
+
+def _added(ws, bs):
+    """An immediate (not queued) weight / bias gradient is about to be added into the arena (see GradArena.mixed)."""
+    for prm in list(ws) + list(bs):
+        prm._vlni_added = True
+        if getattr(prm, "_vlni_queued", False):
+            GRADS.mixed(prm.grad)
 
 
 def _wb_grad_to(ws, bs, dy, x):
     """Weight + bias gradients of one (possibly row-packed) projection in a single pass over dy / x."""
     rows = [w.shape[0] for w in ws]
-    if _direct(*ws, *bs):
+    if _direct(*ws, *bs, queue=True):
         wv = _packed_grad(ws) if len(ws) > 1 else ws[0].grad
         bv = _packed_grad(bs) if len(bs) > 1 else bs[0].grad
         if wv is not None and bv is not None:
@@ -1337,10 +1597,16 @@ def _wb_grad_to(ws, bs, dy, x):
                 ent = _WQ.get(wv.data_ptr())
                 if ent is None:
                     ent = _WQ[wv.data_ptr()] = (wv, bv, [])
+                    for prm in list(ws) + list(bs):
+                        prm._vlni_queued = True   # its gradient may sit in a range the arena's zero fill skips (GradArena)
+                        if getattr(prm, "_vlni_added", False):
+                            GRADS.mixed(prm.grad)
                 ent[2].append((dy, x))            # reduced later by flush_wgrads(): one grouped launch per parameter
             else:
+                _added(ws, bs)
                 wgrad(dy, x, out=wv, colsum_out=bv)
         else:
+            _added(ws, bs)
             gw, gb = wgrad(dy, x, want_colsum=True)
             for prm, t in zip(ws, _split_rows(gw, rows)):
                 prm.grad.add_(t)

@@ -217,7 +217,9 @@ class FlatTrainer:
         self.hp = (lr, betas[0], betas[1], eps, weight_decay)
         self.max_norm = max_norm
         self.step_no = 0
-        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        # [0]: sum of squares of the gradients (clip_grad_norm_); [32:]: the partial reduction's spread accumulators (ops.GradArena)
+        self._sumsq_all = torch.zeros(32 * (1 + ops.SUMSQ_SLOTS), dtype=torch.float32, device=dev)
+        self.sumsq = self._sumsq_all[:1]
         # everything that changes from step to step lives on the device, so a captured step replays correctly
         # (layouts: include/vlni.h, vlni_optim_prepare_groups)
         G = len(self.groups)
@@ -250,6 +252,7 @@ class FlatTrainer:
             self._reserve_before = ops.RESERVE_CUS
             ops.RESERVE_CUS = int(os.environ.get("VLNI_RESERVE_CUS", "8"))
         ops.SHADOWS.set_arena(self.flat_p, self.flat_b)
+        ops.reserve_staging()               # pinned staging for launch tables a capture may have to upload (ops._dev_table)
 
     # ---- replicas ---------------------------------------------------------------------------------------------------
     def broadcast_from(self, src=0):
@@ -300,10 +303,16 @@ class FlatTrainer:
     # ---- step -------------------------------------------------------------------------------------------------------
     def zero_grad(self):
         ops._WQ.clear()
-        self.flat_g.zero_()
+        # zero fill of what this step's partial reduction will not store over (ops.GradArena); one rank: the reduction also leaves the
+        # stored gradients' sum of squares in self.sumsq
+        ops.GRADS.begin(self.flat_g, None if _exchange() else self._sumsq_all)
 
-    def flush(self, lo=None, hi=None):
-        """Completes the gradient arena (deferred grouped weight-gradient GEMMs), optionally only elements [lo, hi)."""
+    def flush(self, lo=None, hi=None, fold=False):
+        """Completes the gradient arena (deferred grouped weight-gradient GEMMs), optionally only elements [lo, hi). fold: the caller is the
+        optimizer step (or the captured graph in front of it) - nothing touches the arena between this and the norm, so the reduction may
+        leave the sum of squares of what it stores in self.sumsq; after any other flush step() takes the norm from the arena itself."""
+        if not fold:
+            ops.GRADS.fold_ok = False
         if lo is None:
             ops.flush_wgrads()
         else:
@@ -366,13 +375,17 @@ class FlatTrainer:
                 "payload_dtype": str(self.grad_comm_dtype or torch.float32).replace("torch.", "")}
 
     def step(self):
-        self.flush()
+        self.flush(fold=True)
         st = ops._st()
         self.step_no += 1
         _, b1, b2, eps, wd = self.hp
         G = len(self.groups)
-        self.sumsq.zero_()
-        _lib.call("vlni_sumsq", self.flat_g.data_ptr(), self.n, self.sumsq.data_ptr(), st)
+        mine = ops.GRADS.arena is not None and ops.GRADS.arena.data_ptr() == self.flat_g.data_ptr()
+        if not (mine and ops.GRADS.finish_sumsq()):
+            self.sumsq.zero_()
+            _lib.call("vlni_sumsq", self.flat_g.data_ptr(), self.n, self.sumsq.data_ptr(), st)
+        if mine:
+            ops.GRADS.end()
         _lib.call("vlni_optim_prepare_groups", self.sumsq.data_ptr(), self.max_norm, b1, b2, self.state.data_ptr(),
                   self.gstate.data_ptr(), self.grp_lr.data_ptr(), G, self.growth_interval, st)
         _lib.call("vlni_adamw_step_groups", self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
@@ -447,8 +460,10 @@ class FlatTrainer:
         ops._PART_BUFS.clear()                 # row-split workspaces and reduction tables of this arena's gradients
         ops._PART_TABLES.clear()
         ops._KEEPALIVE.clear()                 # (replaced ones that older captured graphs of this trainer still pointed at)
+        if ops.GRADS.arena is not None and ops.GRADS.arena.data_ptr() == self.flat_g.data_ptr():
+            ops.GRADS.reset()
         for p in self.params:
-            p._vlni_direct = p._vlni_defer = False
+            p._vlni_direct = p._vlni_defer = p._vlni_queued = p._vlni_added = False
         if ops.SHADOWS.arena is not None and ops.SHADOWS.arena[0] is self.flat_p:
             ops.SHADOWS.set_arena(None, None)
         ops.set_seed_base(None)
@@ -528,12 +543,12 @@ class GraphedStep:
                 first()
             self.loss = fwd_bwd()
             if not split:
-                trainer.flush()
+                trainer.flush(fold=True)
         self.g_flush = []
         if split:
             base = trainer.flat_g.data_ptr()
             for lo, hi in trainer.comm_ranges():
-                if not any(base + 4 * lo <= k < base + 4 * hi for k in ops._WQ):
+                if not any(base + 4 * lo <= k < base + 4 * hi for k in list(ops._WQ) + [base + 4 * o for o in ops.GRADS.pending]):
                     self.g_flush.append(None)              # nothing deferred in this range (small parameters only)
                     continue
                 g = torch.cuda.CUDAGraph()
