@@ -199,6 +199,11 @@ int vlni_transpose(int src_dtype, int dst_dtype, const void* src, long lds, void
    DEVICE memory {const void* src; void* dst; long lds; long ldd; int R, C, Rpad, tile0, tiles_c, 0}, tile0 = running sum of
    ceil(C/64)*ceil(Rpad/64) over the entries before it; total_tiles = the grand total. dst (bfloat16) [c][r] = src[r][c]. */
 int vlni_transpose_batched(int src_dtype, const void* table_dev, int n, int total_tiles, void* stream);
+/* 16-bit shadows of many float32 parameters in one launch: table = device array of
+   { const float* src; void* dst; long lds, ldd; int R, C, mode, tile0, tiles_c, pad; } - mode 0: dst[r][c] = src[r][c], mode 1: dst[c][r] =
+   src[r][c]; tile0 = first 64 x 64 tile (= block) of the entry, tiles_c = tiles per row of tiles; entries sorted by tile0. The weights an
+   optimizer other than vlni_adamw_step_groups has just stepped (torch.optim.AdamW, r2r/agent_cmt.py:98) are re-cast in one launch. */
+int vlni_shadow_refresh(int dst_dtype, const void* table_dev, int n, int total_tiles, void* stream);
 /* out[n] += sum_r x[r][n]: bias gradients */
 int vlni_colsum(int dtype, const void* x, long ldx, int rows, int N, float* out, void* stream);
 /* y = x W^T + b with K <= 16 float32 features (angle 4-d R:537,599; DUET 7-/14-d position D:1093,1140-1150) */

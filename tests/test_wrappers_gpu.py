@@ -132,3 +132,81 @@ def test_duet_wrapper_dispatch_and_dropout():
     c = Critic(args).cuda().eval()
     s = torch.randn(7, 768).cuda()
     assert torch.allclose(c(s), c.state2value(s).squeeze(), atol=1e-5)
+
+
+@pytest.mark.parametrize("family", ["hamt", "duet"])
+def test_agent_backward_groups_weight_gradients_and_recasts_weights_in_one_launch(family):
+    """What an unchanged reference agent gets from the wrappers' models (vln_imagine_amd/dropin.py restates its iteration: agent_cmt.py:809-832,
+    agent_base.py:223-228): the weight gradients of every projection are computed over ALL steps in grouped launches by a callback at the end of
+    loss.backward() (ops._auto_flush) instead of one launch per step through autograd, and the 16-bit weight copies that torch.optim.AdamW's step
+    leaves stale are re-cast in one launch (ShadowCache._refresh_plain). Same gradients, same losses over iterations (set_to_none on and off, two
+    backward passes into one step), a fraction of the launches."""
+    from tests.golden.variants import DUET_C1, HAMT_C1
+    from vln_imagine_amd import dropin, ops, synth
+    if family == "hamt":
+        from tests.test_hamt_gpu import build_product
+        from vln_imagine_amd.hamt.config import HamtConfig
+        from vln_imagine_amd.hamt.episode import EpisodeTensors
+        cfg = HamtConfig(**HAMT_C1)
+        et = EpisodeTensors(synth.HamtEpisode(tag="agent", B=16, L=80, V=37, I=4, T=3, ragged=True), "cuda")
+        wrap, loss_of = dropin.wrap_hamt, dropin.hamt_agent_loss
+    else:
+        from tests.test_duet_gpu import build_product
+        from vln_imagine_amd.duet.config import DuetConfig
+        from vln_imagine_amd.duet.episode import DuetEpisodeTensors
+        cfg = DuetConfig(**DUET_C1)
+        et = DuetEpisodeTensors(synth.DuetEpisode(tag="agent", B=16, L=80, V=36, I=4, T=3, ragged=True), "cuda")
+        wrap, loss_of = dropin.wrap_duet, dropin.duet_agent_loss
+
+    def program(on):
+        was = ops.AUTO_DEFER, ops.BATCH_SHADOWS
+        ops.AUTO_DEFER = ops.BATCH_SHADOWS = on
+        calls, real = {}, ops._lib.call
+
+        def counting(name, *a):
+            calls[name] = calls.get(name, 0) + 1
+            return real(name, *a)
+        try:
+            ops.reseed(21)
+            torch.manual_seed(3)
+            m = build_product(cfg, torch.bfloat16).train()
+            w = wrap(m, feat_dropout=0.0)
+            tr = dropin.DropInTrainer(w, et, family, lr=1e-5)
+            out = []
+            for it in range(4):
+                if it == 3:
+                    ops._lib.call = counting
+                tr.opt.zero_grad(set_to_none=it != 1)
+                loss, _ = loss_of(w, et)
+                loss.backward()
+                if it == 2:
+                    loss_of(w, et)[0].backward()
+                out.append((float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+                # the weights move the same way in both programs (an optimizer would feed each program's own summation-order noise back
+                # through Adam's normalisation): the next iteration's loss shows whether every 16-bit copy followed
+                with torch.no_grad():
+                    for i, p in enumerate(tr.params):
+                        p.mul_(1.0 + 1e-3 * ((i % 5) - 2))
+            ops._lib.call = real
+            tr.opt.zero_grad()
+            loss_of(w, et)[0].backward()
+            torch.nn.utils.clip_grad_norm_(tr.params, 40.0)
+            tr.opt.step()                                  # torch.optim.AdamW on gradients that are views of the packed buffers
+            assert all(torch.isfinite(p).all() for p in tr.params)
+            return out, calls
+        finally:
+            ops._lib.call = real
+            ops.AUTO_DEFER, ops.BATCH_SHADOWS = was
+
+    (ref, c0), (got, c1) = program(False), program(True)
+    for it, ((l0, g0), (l1, g1)) in enumerate(zip(ref, got)):
+        assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)), (it, l0, l1)
+        assert set(g0) == set(g1), (it, set(g0) ^ set(g1))
+        top = max(v.abs().max().item() for v in g0.values())
+        for n in g0:
+            d = (g0[n].float() - g1[n].float()).abs().max().item()
+            assert d <= 1e-4 * top, (it, n, d, top)
+    wg = lambda c: sum(v for k, v in c.items() if "gemm_tn" in k)
+    recast = lambda c: sum(v for k, v in c.items() if k in ("vlni_cast", "vlni_transpose"))
+    assert wg(c1) <= 0.6 * wg(c0), (wg(c0), wg(c1))          # T = 3 steps here (and the text encoder's projections run once per episode anyway)
+    assert recast(c1) + 20 <= recast(c0) and c1.get("vlni_shadow_refresh", 0) in (1, 2), (recast(c0), recast(c1), c1.get("vlni_shadow_refresh"))

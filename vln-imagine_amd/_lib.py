@@ -29,6 +29,7 @@ SIGNATURES = {
     "vlni_reduce_parts_sq": [P, I, I, P, I, P],
     "vlni_sumsq_fold": [P, I, P, P],
     "vlni_upload": [P, P, L, P],
+    "vlni_shadow_refresh": [I, P, I, I, P],
     "vlni_gemm_tn_h16_grouped_v": [I, I, P, P, P, L, L, P, L, I, I, P, I, I, P],
     "vlni_gemm_tn_h16_grouped_part": [I, I, P, P, P, L, L, P, L, I, I, P, I, I, P],
     "vlni_attn_fwd": [I, P, L, P, L, P, L, P, P, P, L, P, I, I, I, I, F, F, U, P],

@@ -93,6 +93,50 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const TrEntry* _
   }
 }
 
+// 16-bit shadows of MANY float32 parameters in one launch (what an optimizer that is not the library's own leaves stale after its step):
+// entry = one parameter -> its place in a shadow; mode 0: dst[r][c] = src[r][c] (biases, LayerNorm vectors: R = 1), mode 1: dst[c][r] = src[r][c]
+// (the dgrad operand W^T). A block moves one 64 x 64 tile; row-packed shadows (Q | K | V) are one entry per parameter.
+struct ShEntry { const float* src; void* dst; long lds, ldd; int R, C, mode, tile0, tiles_c, pad_; };
+template <typename D>
+__global__ __launch_bounds__(256) void shadow_refresh_kernel(const ShEntry* __restrict__ tab, int n) {
+  __shared__ float tile[64][65];
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].tile0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ShEntry e = tab[lo];
+  const int t = blockIdx.x - e.tile0;
+  const int r0 = (t / e.tiles_c) * 64, c0 = (t % e.tiles_c) * 64;
+  D* dst = (D*)e.dst;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  if (e.mode == 0) {
+    for (int i = ty; i < 64; i += 4) {
+      const int r = r0 + i, c = c0 + tx;
+      if (r < e.R && c < e.C) DT<D>::st(dst + (long)r * e.ldd + c, e.src[(long)r * e.lds + c]);
+    }
+    return;
+  }
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < e.R && c < e.C) ? e.src[(long)r * e.lds + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < e.C && r < e.R) DT<D>::st(dst + (long)c * e.ldd + r, tile[tx][i]);
+  }
+}
+extern "C" int vlni_shadow_refresh(int dst_dtype, const void* table_dev, int n, int total_tiles, void* stream) {
+  VLNI_CHECK(table_dev && n > 0 && total_tiles > 0, VLNI_EINVAL, "shadow_refresh: n=%d tiles=%d", n, total_tiles);
+  const ShEntry* tab = (const ShEntry*)table_dev;
+  if (dst_dtype == VLNI_BF16) hipLaunchKernelGGL((shadow_refresh_kernel<__bf16>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
+  else if (dst_dtype == VLNI_F16) hipLaunchKernelGGL((shadow_refresh_kernel<_Float16>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
+  else { vlni_set_error("shadow_refresh: bad dtype %d", dst_dtype); return VLNI_EINVAL; }
+  VLNI_LAUNCH_CHECK();
+  return VLNI_OK;
+}
+
 // out[n] += sum_r x[r][n]      (bias gradients).  grid.x over column groups of 256, grid.y over row slabs.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long ldx, int rows, int N,

@@ -12,6 +12,8 @@ import argparse
 import torch
 import torch.nn as nn
 
+from . import ops
+
 
 def wrap_hamt(navcmt, feat_dropout=0.4):
     """A models.model_HAMT.VLNBertCMT around an existing NavCMT (the wrapper's own constructor builds a new model from run arguments)."""
@@ -22,6 +24,7 @@ def wrap_hamt(navcmt, feat_dropout=0.4):
     w.vln_bert = navcmt
     navcmt.visual_lang_rows = "cls"            # what VLNBertCMT.__init__ selects (it reads txt_embeds[:, 0] only)
     w.drop_env = nn.Dropout(p=feat_dropout)
+    ops.mark_agent_model(navcmt)                # as VLNBertCMT.__init__
     return w
 
 
@@ -32,6 +35,7 @@ def wrap_duet(model, feat_dropout=0.4):
     w.args = argparse.Namespace(feat_dropout=feat_dropout)
     w.vln_bert = model
     w.drop_env = nn.Dropout(p=feat_dropout)
+    ops.mark_agent_model(model)                 # as VLNBert.__init__
     return w
 
 

@@ -911,6 +911,7 @@ class ShadowCache:
         self._tr = {}                  # key -> (mirror view, transposed copy): refreshed together, one launch per optimizer step
         self._tr_table = None          # device table of vlni_transpose_batched (+ n, total tiles); None = rebuild needed
         self._tr_table_old = None      # the last table handed to a launch (kept alive when it is replaced)
+        self._plain_tables = {}        # (dtype, (parameter, copy) addresses) -> device table of vlni_shadow_refresh
 
     def set_arena(self, flat_p, flat_b):
         self.arena = (flat_p, flat_b) if flat_p is not None else None
@@ -982,6 +983,10 @@ class ShadowCache:
             return hit[1]
         if hit is not None and hit[0] == ver and key in self._tr and self._refresh_transposed():
             return hit[1]              # steady state: only the optimizer moved the parameters, the mirror is current
+        if hit is not None and hit[0] != ver and len(hit) > 5 and BATCH_SHADOWS and self._refresh_plain():
+            hit = self._c.get(key)     # another optimizer (torch.optim) stepped: every stale 16-bit copy re-cast in one launch
+            if hit is not None and hit[0] == ver:
+                return hit[1]
         live = False                   # True: `t` aliases memory the optimizer keeps current (never stale within an epoch)
         with torch.no_grad():
             for p in params:
@@ -1010,10 +1015,69 @@ class ShadowCache:
                     t = cast(src, dtype)
         if not any(p.requires_grad for p in params):
             live = True                # frozen parameters: no optimizer step ever touches them
-        self._c[key] = (ver, t, live, self.opt_epoch, weakref.ref(params[0]))
+        if mir is None and dtype in H16 and not live and all(p.dtype == torch.float32 and p.dim() == params[0].dim() <= 2 for p in params):
+            # a plain float32 parameter's own 16-bit copy: _refresh_plain() keeps it current in place
+            self._c[key] = (ver, t, live, self.opt_epoch, weakref.ref(params[0]), tuple(weakref.ref(p) for p in params))
+        else:
+            self._c[key] = (ver, t, live, self.opt_epoch, weakref.ref(params[0]))
         return t
 
+    def _refresh_plain(self):
+        """Re-casts, in ONE launch per dtype, every cached 16-bit copy of plain (not arena-resident) float32 parameters whose parameters
+        changed since it was made - the ~200 cast / transpose launches per iteration that an unchanged agent's own optimizer.step() used to
+        cost (each copy was rebuilt on its first use, with a new allocation). Copies are overwritten in place."""
+        if torch.cuda.is_current_stream_capturing() or _ghost():
+            return False
+        import struct
+        per = {}
+        for key, e in self._c.items():
+            if len(e) <= 5:
+                continue
+            ps = [r() for r in e[5]]
+            if any(p is None for p in ps) or e[4]() is not ps[0]:
+                continue
+            ver = (self.epoch, ps[0]._version, ps[0].data_ptr(), sum(p._version for p in ps[1:]))
+            if ver == e[0]:
+                continue
+            t, transposed = e[1], key[3]
+            R = sum(p.shape[0] for p in ps) if ps[0].dim() == 2 else 1
+            C = ps[0].shape[-1]
+            want = (C, R) if transposed else ((R, C) if ps[0].dim() == 2 else (sum(p.shape[0] for p in ps),))
+            if tuple(t.shape) != want or not t.is_contiguous() or any(not p.is_contiguous() for p in ps):
+                continue
+            per.setdefault(t.dtype, []).append((key, e, ps, ver, transposed))
+        if not per:
+            return False
+        for dt, lst in per.items():
+            sig = tuple((p.data_ptr(), e[1].data_ptr()) for _, e, ps, _, _ in lst for p in ps)
+            tab = self._plain_tables.get((dt, sig))
+            if tab is None:
+                buf, tile0 = bytearray(), 0
+                for _, e, ps, _, transposed in lst:
+                    t, off = e[1], 0
+                    for p in ps:
+                        if p.dim() == 1:
+                            r, c, lds, ldd, dst = 1, p.shape[0], p.shape[0], p.shape[0], t.data_ptr() + 2 * off
+                            off += p.shape[0]
+                        elif transposed:
+                            r, c, lds, ldd, dst = p.shape[0], p.shape[1], p.stride(0), t.stride(0), t.data_ptr() + 2 * off
+                            off += p.shape[0]
+                        else:
+                            r, c, lds, ldd, dst = p.shape[0], p.shape[1], p.stride(0), t.stride(0), t.data_ptr() + 2 * off * t.stride(0)
+                            off += p.shape[0]
+                        tiles_c = (c + 63) // 64
+                        buf += struct.pack("<QQqqiiiiii", p.data_ptr(), dst, lds, ldd, r, c, 1 if (transposed and p.dim() == 2) else 0, tile0, tiles_c, 0)
+                        tile0 += tiles_c * ((r + 63) // 64)
+                if len(self._plain_tables) > 64:
+                    self._plain_tables.clear()
+                tab = self._plain_tables[(dt, sig)] = (torch.frombuffer(buf, dtype=torch.uint8).to(lst[0][1][1].device), len(buf) // 56, tile0)
+            _lib.call("vlni_shadow_refresh", _DT[dt], tab[0].data_ptr(), tab[1], tab[2], _st())
+            for key, e, _, ver, _ in lst:
+                self._c[key] = (ver,) + tuple(e[1:])
+        return True
 
+
+BATCH_SHADOWS = os.environ.get("VLNI_BATCH_SHADOWS", "1") == "1"
 SHADOWS = ShadowCache()
 
 
@@ -1055,8 +1119,10 @@ def _packed_grad(params):
     """One [sum rows, ...] view over the .grad of parameters that sit back to back in the arena, else None."""
     g0 = params[0].grad
     ptr = g0.data_ptr()
+    st0 = g0.untyped_storage().data_ptr()
     for p in params:
-        if p.grad.data_ptr() != ptr or not p.grad.is_contiguous():
+        # neighbours in ONE allocation (separately allocated gradients can happen to sit back to back)
+        if p.grad.data_ptr() != ptr or not p.grad.is_contiguous() or p.grad.untyped_storage().data_ptr() != st0:
             return None
         ptr += p.grad.numel() * 4
     rows = sum(p.shape[0] for p in params)
@@ -1485,15 +1551,18 @@ def _part_table(entries, dev):
     return _dev_table(arr, dev), len(entries), blk
 
 
-def flush_wgrads(lo=None, hi=None):
+def flush_wgrads(lo=None, hi=None, queue=None, store=None):
     """Runs the queued weight/bias gradient reductions (must precede any read of the .grad arena). With (lo, hi): only the
-    gradients whose address lies in [lo, hi), in address order (train.FlatTrainer's flush -> all-reduce pipeline)."""
+    gradients whose address lies in [lo, hi), in address order (train.FlatTrainer's flush -> all-reduce pipeline).
+    queue / store: another queue than the trainer's (the end-of-backward flush of plain parameters, _auto_flush) and the set of its
+    destination addresses that hold no gradient yet (written, not added to)."""
     entries, dev = [], None
+    wq = _WQ if queue is None else queue
     if lo is None:
-        todo = list(_WQ)
+        todo = list(wq)
     else:
-        todo = sorted(k for k in _WQ if lo <= k < hi)
-    items = [(key,) + tuple(_WQ.pop(key)) for key in todo]
+        todo = sorted(k for k in wq if lo <= k < hi)
+    items = [(key,) + tuple(wq.pop(key)) for key in todo]
     if BATCH_WGRADS and WGRAD_PARTS and len(items) > 1:
         groups, rest = {}, []
         for it in items:
@@ -1541,19 +1610,27 @@ def flush_wgrads(lo=None, hi=None):
                     _KEEPALIVE.append(buf)     # a captured step (another shape bucket's graph) may still write its partials there
                 buf = _PART_BUFS[key] = torch.empty((tot * (N * K + N),), dtype=torch.float32, device=wv.device)
             cpart = buf.data_ptr() + 4 * tot * N * K         # [tot][N] column-sum partials behind the [tot][N][K] slabs
+        if store is not None and any(pl[6] < 0 for pl in plans):          # float atomics add: a destination without a gradient starts at zero
+            for t in (wv, bv):
+                if t.data_ptr() in store:
+                    t.zero_()
+                    store.discard(t.data_ptr())
         for n, pa, pb, pm, variant, split, z0, dtid in plans:
             if z0 >= 0:
                 _lib.call("vlni_gemm_tn_h16_grouped_part", dtid, n, pa, pb, pm, N, K, buf.data_ptr() + 4 * z0 * N * K, N * K, N, K,
                           cpart + 4 * z0 * N, split, variant, _st())
             else:                                            # unsplit (or register-staged) launch: float atomics straight into the arena
-                GRADS.touch(wv); GRADS.touch(bv)
+                if store is None:
+                    GRADS.touch(wv); GRADS.touch(bv)
                 _lib.call("vlni_gemm_tn_h16_grouped_v", dtid, n, pa, pb, pm, N, K, wv.data_ptr(), wv.stride(0), N, K, bv.data_ptr(),
                           split, variant, _st())
         if tot:
             # exactly ONE reduction entry per destination: reduce_parts_kernel's read-modify-write of dst is not atomic
             entries.append((wv.data_ptr(), buf.data_ptr(), N * K // 4, N * K // 4, tot))
             entries.append((bv.data_ptr(), cpart, N // 4, N // 4, tot))
-    if GRADS.arena is not None:
+    if store is not None:
+        entries = [(dst, part, n4, stride4, eff | (PART_STORE if dst in store else 0)) for dst, part, n4, stride4, eff in entries]
+    elif GRADS.arena is not None:
         # store mode (GradArena): a destination the step's zero fill left out is written, not added to; what is left of those gets zeros
         entries = [(dst, part, n4, stride4, eff | GRADS.claim(dst, 4 * n4)) for dst, part, n4, stride4, eff in entries]
         base = GRADS.arena.data_ptr()
@@ -1564,16 +1641,16 @@ def flush_wgrads(lo=None, hi=None):
         tab = _PART_TABLES.get(sig)
         if tab is None:
             tab = _PART_TABLES[sig] = _part_table(sig, dev)
-        sq = GRADS.slots if GRADS.fold_ok and GRADS.sumsq is not None else None
+        sq = GRADS.slots if store is None and GRADS.fold_ok and GRADS.sumsq is not None else None
         _lib.call("vlni_reduce_parts_sq", tab[0].data_ptr(), tab[1], tab[2], None if sq is None else sq.data_ptr(), SUMSQ_SLOTS, _st())
-        if GRADS.arena is not None and STORE_PARTS and not torch.cuda.is_current_stream_capturing():
+        if store is None and GRADS.arena is not None and STORE_PARTS and not torch.cuda.is_current_stream_capturing():
             # the same reduction as the next step will issue it if it has this step's structure (every destination stored, see GradArena.prebuild)
             flag = PART_STORE | (PART_SUMSQ if GRADS.sumsq is not None else 0)
             nxt = tuple((dst, part, n4, stride4, (eff & 0xffff) | (flag if GRADS.will_store(dst, 4 * n4) else 0))
                         for dst, part, n4, stride4, eff in entries if part)
             if nxt and nxt not in _PART_TABLES:
                 _PART_TABLES[nxt] = _part_table(nxt, dev)
-    if not _WQ and not torch.cuda.is_current_stream_capturing():
+    if store is None and not _WQ and not torch.cuda.is_current_stream_capturing():
         GRADS.prebuild()
 
 
@@ -1613,8 +1690,101 @@ def _wb_grad_to(ws, bs, dy, x):
             for prm, t in zip(bs, _split_rows(gb, rows)):
                 prm.grad.add_(t)
         return (None,) * len(ws), (None,) * len(bs)
+    if AUTO_DEFER and _auto_ok(ws, bs, dy, x):
+        key = (id(ws[0]), len(ws))
+        ent = _AQ.get(key)
+        if ent is None:
+            ent = _AQ[key] = (tuple(ws), tuple(bs), [])
+            if not _AQ_STATE["queued"]:                  # once per backward pass: the engine runs it when the pass has finished
+                _AQ_STATE["queued"] = True
+                torch.autograd.Variable._execution_engine.queue_callback(_auto_flush)
+        ent[2].append((dy, x))
+        return (None,) * len(ws), (None,) * len(bs)
     gw, gb = wgrad(dy, x, want_colsum=True)
     return tuple(_split_rows(gw, rows)), tuple(_split_rows(gb, rows))
+
+
+# ---- deferred weight gradients for PLAIN parameters (no FlatTrainer): what an unchanged reference agent gets -------------------------------
+# The agents call loss.backward() once per rollout (r2r/agent_cmt.py:827, map_nav_src/r2r/agent_base.py:223): through plain autograd every
+# projection's weight gradient was one launch per STEP plus zero fills and AccumulateGrad adds - 396 weight-gradient launches, 104 column
+# sums and their temporaries per HAMT iteration, all host-bound. Parameters the wrappers marked (enable_auto_defer) queue their (dY, X) pairs
+# instead, return no gradient to autograd, and a callback the autograd engine runs at the END of the backward pass computes each
+# parameter's gradient over all steps in one grouped launch (the trainer's flush_wgrads machinery) into a persistent float32 buffer that
+# becomes `.grad` (or is added to an existing `.grad`). What that changes for a caller: parameter hooks and DDP's reducer do not see these
+# gradients (the wrappers leave the mark off when torch.distributed runs more than one rank), torch.autograd.grad() does not return them,
+# and `.grad` tensors are reused from one iteration to the next (as with optimizer.zero_grad(set_to_none=False)).
+AUTO_DEFER = os.environ.get("VLNI_AUTO_DEFER", "1") == "1"
+_AQ = {}                      # (id(first parameter), parameters) -> (weights, biases, [(dY, X), ...])
+_AQ_STATE = {"queued": False}
+_AUTO_BUF = {}                # (id(first parameter), parameters) -> (weakref, packed float32 gradient buffer)
+
+
+def enable_auto_defer(params, on=True):
+    """Marks plain parameters for deferred, grouped weight gradients at the end of backward() (see above)."""
+    for p in params:
+        p._vlni_auto = bool(on)
+
+
+def mark_agent_model(module):
+    """What the reference-facing wrappers (hamt.models.model_HAMT.VLNBertCMT, duet.models.model.VLNBert) do at construction: deferred
+    weight gradients for the model an agent will train with loss.backward() + its own optimizer - unless several ranks run (the agent then
+    wraps the model in DistributedDataParallel, r2r/agent_cmt.py:61-63, whose reducer must see every gradient arrive through autograd)."""
+    import torch.distributed as dist
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    enable_auto_defer(module.parameters(), on=not multi)
+    return module
+
+
+def _auto_ok(ws, bs, dy, x):
+    return all(getattr(p, "_vlni_auto", False) for p in ws) and all(getattr(p, "_vlni_auto", False) for p in bs) \
+        and dy.dtype in H16 and dy.is_contiguous() and x.is_contiguous() and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 \
+        and not torch.cuda.is_current_stream_capturing() and ws[0].dtype == torch.float32
+
+
+def _auto_dst(params, store, late):
+    """Destination of one (row-packed) gradient: the parameters' adjacent `.grad`s if they exist, else the persistent buffer (whose row
+    blocks become the `.grad`s; `store` gets its address - it holds no gradient yet), else a temporary that `late` adds afterwards."""
+    grads = [p.grad for p in params]
+    if all(g is None for g in grads):
+        key = (id(params[0]), len(params))
+        hit = _AUTO_BUF.get(key)
+        shape = (sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:])
+        if hit is None or hit[0]() is not params[0] or hit[1].shape != shape or hit[1].device != params[0].device:
+            hit = _AUTO_BUF[key] = (weakref.ref(params[0]), torch.empty(shape, dtype=torch.float32, device=params[0].device))
+        buf, r = hit[1], 0
+        for p in params:
+            p.grad = buf[r:r + p.shape[0]]
+            r += p.shape[0]
+        store.add(buf.data_ptr())
+        return buf
+    if all(g is not None and g.dtype == torch.float32 for g in grads):
+        v = _packed_grad(params) if len(params) > 1 else (grads[0] if grads[0].is_contiguous() else None)
+        if v is not None:
+            return v
+    tmp = torch.zeros((sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:]), dtype=torch.float32, device=params[0].device)
+    late.append((params, tmp))
+    return tmp
+
+
+def _auto_flush():
+    """End of a backward pass: every queued parameter's weight / bias gradient over all its calls, grouped (flush_wgrads)."""
+    _AQ_STATE["queued"] = False
+    items = list(_AQ.values())
+    _AQ.clear()
+    if not items:
+        return
+    store, late, queue = set(), [], {}
+    with torch.no_grad():
+        for ws, bs, segs in items:
+            wv, bv = _auto_dst(ws, store, late), _auto_dst(bs, store, late)
+            queue[wv.data_ptr()] = (wv, bv, segs)
+        flush_wgrads(queue=queue, store=store)
+        for params, tmp in late:
+            for prm, t in zip(params, _split_rows(tmp, [q.shape[0] for q in params])):
+                if prm.grad is None:
+                    prm.grad = t.clone()
+                else:
+                    prm.grad.add_(t.to(prm.grad.dtype))
 
 
 def _ln_bwd_to(dy, x, g, b, mean, rstd, want, dres=None, drop=None):
