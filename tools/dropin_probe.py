@@ -55,6 +55,7 @@ if a.profile:
     for _ in range(3):
         tr.step()
     torch.cuda.synchronize()
+    torch.autograd.set_multithreading_enabled(False)     # backward on this thread: its Python (Function.backward bodies) shows in the profile
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(3):
@@ -62,5 +63,5 @@ if a.profile:
     torch.cuda.synchronize()
     pr.disable()
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
-    print(s.getvalue()[:9000])
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(70)
+    print(s.getvalue()[:16000])
