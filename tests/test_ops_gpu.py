@@ -480,6 +480,31 @@ def test_ln_rowdot_equals_layernorm_dropout_rowdot(ops, dtype, p_drop):
         assert (u.float() - v.float()).abs().max().item() <= max(tol, 1e-5) * max(1.0, u.float().abs().max().item())
 
 
+def test_launch_table_uploaded_inside_a_capture(ops):
+    """ops._dev_table while a stream is capturing: the table goes through the pinned staging buffer as a memcpy node of the graph (torch's own
+    host -> device copy is not capturable), so a captured step whose reduction table no eager step has built yet still captures and replays."""
+    import numpy as np
+    ops.reserve_staging()
+    n = 4096
+    dst = torch.zeros(n, device="cuda")
+    parts = torch.arange(3 * n, device="cuda", dtype=torch.float32).reshape(3, n)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g):
+            arr = np.zeros((1,), ops._PART_DT)
+            arr[0] = (dst.data_ptr(), parts.data_ptr(), n // 4, n // 4, 3 | ops.PART_STORE, 0)
+            tab = ops._dev_table(arr, dst.device)
+            ops._lib.call("vlni_reduce_parts_sq", tab.data_ptr(), 1, (n // 4 + 1023) // 1024, None, 1, ops._st())
+    want = parts.sum(0)
+    for _ in range(2):
+        dst.fill_(7.0)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(dst, want)
+
+
 def test_small_ops(ops):
     import torch.nn.functional as F
     torch.manual_seed(0)
