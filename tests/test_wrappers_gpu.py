@@ -138,7 +138,7 @@ def test_duet_wrapper_dispatch_and_dropout():
 def test_agent_backward_groups_weight_gradients_and_recasts_weights_in_one_launch(family):
     """What an unchanged reference agent gets from the wrappers' models (vln_imagine_amd/dropin.py restates its iteration: agent_cmt.py:809-832,
     agent_base.py:223-228): the weight gradients of every projection are computed over ALL steps in grouped launches by a callback at the end of
-    loss.backward() (ops._auto_flush) instead of one launch per step through autograd, and the 16-bit weight copies that torch.optim.AdamW's step
+    loss.backward() (ops.GradSession) instead of one launch per step through autograd, and the 16-bit weight copies that torch.optim.AdamW's step
     leaves stale are re-cast in one launch (ShadowCache._refresh_plain). Same gradients, same losses over iterations (set_to_none on and off, two
     backward passes into one step), a fraction of the launches."""
     from tests.golden.variants import DUET_C1, HAMT_C1
@@ -177,7 +177,8 @@ def test_agent_backward_groups_weight_gradients_and_recasts_weights_in_one_launc
                 if it == 3:
                     ops._lib.call = counting
                 tr.opt.zero_grad(set_to_none=it != 1)
-                loss, _ = loss_of(w, et)
+                # iteration 3 (HAMT): a rollout without the alignment head - its parameters get no gradient and must read None, as through autograd
+                loss, _ = loss_of(w, et, use_aux=False) if (it == 3 and family == "hamt") else loss_of(w, et)
                 loss.backward()
                 if it == 2:
                     loss_of(w, et)[0].backward()
@@ -202,6 +203,8 @@ def test_agent_backward_groups_weight_gradients_and_recasts_weights_in_one_launc
     for it, ((l0, g0), (l1, g1)) in enumerate(zip(ref, got)):
         assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)), (it, l0, l1)
         assert set(g0) == set(g1), (it, set(g0) ^ set(g1))
+        if it == 3 and family == "hamt":
+            assert not any(n.startswith("contrastive_alignment_model") for n in g1) and len(g1) > 100
         top = max(v.abs().max().item() for v in g0.values())
         for n in g0:
             d = (g0[n].float() - g1[n].float()).abs().max().item()

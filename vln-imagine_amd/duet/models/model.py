@@ -13,7 +13,7 @@ class VLNBert(nn.Module):
         self.args = args
         self.vln_bert = get_vlnbert_models(args, config=None)
         self.drop_env = nn.Dropout(p=args.feat_dropout)
-        ops.mark_agent_model(self.vln_bert)       # weight gradients grouped at the end of the agent's loss.backward() (ops._auto_flush)
+        ops.mark_agent_model(self.vln_bert)       # gradients accumulated directly / grouped at the end of the agent's loss.backward() (ops.GradSession)
 
     def forward(self, mode, batch):
         batch = collections.defaultdict(lambda: None, batch)

@@ -23,7 +23,7 @@ class VLNBertCMT(nn.Module):
         # compute the other language rows (NavCMT.visual_lang_rows; identical logits / states / gradients)
         self.vln_bert.visual_lang_rows = "cls"
         self.drop_env = nn.Dropout(p=args.feat_dropout)
-        ops.mark_agent_model(self.vln_bert)       # weight gradients grouped at the end of the agent's loss.backward() (ops._auto_flush)
+        ops.mark_agent_model(self.vln_bert)       # gradients accumulated directly / grouped at the end of the agent's loss.backward() (ops.GradSession)
 
     def forward(self, mode, txt_ids=None, txt_masks=None, txt_embeds=None, hist_img_feats=None, hist_ang_feats=None,
                 hist_pano_img_feats=None, hist_pano_ang_feats=None, hist_embeds=None, hist_lens=None, ob_step=None,

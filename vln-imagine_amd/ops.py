@@ -1105,6 +1105,8 @@ def _split_rows(t, sizes):
 # autograd functions return None for them: no zero-filled temporaries, no AccumulateGrad add kernels. The mark is per
 # parameter, so a second model in the same process keeps plain autograd accumulation.
 def _direct(*params, queue=False):
+    if params and getattr(params[0], "_vlni_auto", None) is not None:
+        _session(params)
     ok = all(p is not None and p.grad is not None and getattr(p, "_vlni_direct", False) for p in params)
     if ok and not queue and GRADS.arena is not None:
         # a kernel is about to ADD into these gradients: one that the reduction also writes (GradArena) is zeroed now if the arena's
@@ -1554,7 +1556,7 @@ def _part_table(entries, dev):
 def flush_wgrads(lo=None, hi=None, queue=None, store=None):
     """Runs the queued weight/bias gradient reductions (must precede any read of the .grad arena). With (lo, hi): only the
     gradients whose address lies in [lo, hi), in address order (train.FlatTrainer's flush -> all-reduce pipeline).
-    queue / store: another queue than the trainer's (the end-of-backward flush of plain parameters, _auto_flush) and the set of its
+    queue / store: another queue than the trainer's (the end-of-backward flush of an agent model's GradSession) and the set of its
     destination addresses that hold no gradient yet (written, not added to)."""
     entries, dev = [], None
     wq = _WQ if queue is None else queue
@@ -1671,9 +1673,11 @@ def _wb_grad_to(ws, bs, dy, x):
         if wv is not None and bv is not None:
             if getattr(ws[0], "_vlni_defer", False) and dy.dtype in H16 and dy.is_contiguous() and x.is_contiguous() \
                     and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0:
-                ent = _WQ.get(wv.data_ptr())
+                ses = getattr(ws[0], "_vlni_auto", None)
+                wq = ses.queue if (ses is not None and ses.active) else _WQ       # an agent model's open GradSession, or the trainer's queue
+                ent = wq.get(wv.data_ptr())
                 if ent is None:
-                    ent = _WQ[wv.data_ptr()] = (wv, bv, [])
+                    ent = wq[wv.data_ptr()] = (wv, bv, [])
                     for prm in list(ws) + list(bs):
                         prm._vlni_queued = True   # its gradient may sit in a range the arena's zero fill skips (GradArena)
                         if getattr(prm, "_vlni_added", False):
@@ -1690,101 +1694,132 @@ def _wb_grad_to(ws, bs, dy, x):
             for prm, t in zip(bs, _split_rows(gb, rows)):
                 prm.grad.add_(t)
         return (None,) * len(ws), (None,) * len(bs)
-    if AUTO_DEFER and _auto_ok(ws, bs, dy, x):
-        key = (id(ws[0]), len(ws))
-        ent = _AQ.get(key)
-        if ent is None:
-            ent = _AQ[key] = (tuple(ws), tuple(bs), [])
-            if not _AQ_STATE["queued"]:                  # once per backward pass: the engine runs it when the pass has finished
-                _AQ_STATE["queued"] = True
-                torch.autograd.Variable._execution_engine.queue_callback(_auto_flush)
-        ent[2].append((dy, x))
-        return (None,) * len(ws), (None,) * len(bs)
     gw, gb = wgrad(dy, x, want_colsum=True)
     return tuple(_split_rows(gw, rows)), tuple(_split_rows(gb, rows))
 
 
-# ---- deferred weight gradients for PLAIN parameters (no FlatTrainer): what an unchanged reference agent gets -------------------------------
-# The agents call loss.backward() once per rollout (r2r/agent_cmt.py:827, map_nav_src/r2r/agent_base.py:223): through plain autograd every
-# projection's weight gradient was one launch per STEP plus zero fills and AccumulateGrad adds - 396 weight-gradient launches, 104 column
-# sums and their temporaries per HAMT iteration, all host-bound. Parameters the wrappers marked (enable_auto_defer) queue their (dY, X) pairs
-# instead, return no gradient to autograd, and a callback the autograd engine runs at the END of the backward pass computes each
-# parameter's gradient over all steps in one grouped launch (the trainer's flush_wgrads machinery) into a persistent float32 buffer that
-# becomes `.grad` (or is added to an existing `.grad`). What that changes for a caller: parameter hooks and DDP's reducer do not see these
-# gradients (the wrappers leave the mark off when torch.distributed runs more than one rank), torch.autograd.grad() does not return them,
-# and `.grad` tensors are reused from one iteration to the next (as with optimizer.zero_grad(set_to_none=False)).
+# ---- gradients of PLAIN parameters (no FlatTrainer): what an unchanged reference agent gets ---------------------------------------------------
+# The agents call loss.backward() once per rollout (r2r/agent_cmt.py:827, map_nav_src/r2r/agent_base.py:223) and step their own optimizer.
+# Through plain autograd every projection's weight gradient was one launch per STEP plus zero fills and AccumulateGrad adds (396 weight-
+# gradient launches, 104 column sums per HAMT iteration), every LayerNorm's dgamma / dbeta a pair of zero-filled temporaries plus two adds -
+# all host-bound. A model the wrappers marked (mark_agent_model) gets what train.FlatTrainer's gradient arena gives, for one backward pass at
+# a time: the first operator of a backward pass that meets a marked parameter opens a GradSession - parameters without a gradient get views of
+# one persistent, zero-filled float32 buffer as `.grad` (Q | K | V neighbours, so packed projections accumulate through one view) and the
+# trainer's marks, so every kernel accumulates straight into them and the projections queue their (dY, X) pairs - and a callback the autograd
+# engine runs at the END of the pass computes the queued weight gradients over all steps in grouped launches (flush_wgrads), gives parameters
+# nothing touched their `None` back (an optimizer skips them, as it does in the reference) and takes the marks off again.
+# What that changes for a caller: tensor hooks on these parameters and DDP's reducer do not see the gradients (the wrappers leave the mark off
+# when torch.distributed runs more than one rank), torch.autograd.grad() does not return them, and `.grad` tensors are views of a buffer that
+# is reused from one iteration to the next (as with optimizer.zero_grad(set_to_none=False)).
 AUTO_DEFER = os.environ.get("VLNI_AUTO_DEFER", "1") == "1"
-_AQ = {}                      # (id(first parameter), parameters) -> (weights, biases, [(dY, X), ...])
-_AQ_STATE = {"queued": False}
-_AUTO_BUF = {}                # (id(first parameter), parameters) -> (weakref, packed float32 gradient buffer)
 
 
-def enable_auto_defer(params, on=True):
-    """Marks plain parameters for deferred, grouped weight gradients at the end of backward() (see above)."""
-    for p in params:
-        p._vlni_auto = bool(on)
+class GradSession:
+    def __init__(self, module):
+        units, seen = [], set()
+        for mod in module.modules():
+            if all(hasattr(mod, n) for n in ("query", "key", "value")):
+                for attr in ("weight", "bias"):
+                    unit = [getattr(getattr(mod, n), attr, None) for n in ("query", "key", "value")]
+                    if all(p is not None and id(p) not in seen for p in unit):
+                        units.append(unit)
+                        seen.update(id(p) for p in unit)
+        units += [[p] for p in module.parameters() if id(p) not in seen]
+        self.params, self.off, n = [], {}, 0
+        for unit in units:
+            for p in unit:
+                self.params.append(p)
+                self.off[id(p)] = n
+                n += (p.numel() + 7) // 8 * 8
+        self.n, self.flat, self.queue = n, None, {}
+        self.active, self.epoch, self.assigned = False, 0, []
+        ref = weakref.ref(self)
+        for p in self.params:
+            p._vlni_auto = self
+
+            def touched(prm, ref=ref):               # autograd itself accumulated into this parameter (an operator outside this library)
+                ses = ref()
+                if ses is not None:
+                    prm._vlni_touch = ses.epoch
+            p.register_post_accumulate_grad_hook(touched)
+
+    def begin(self):
+        """First marked parameter met in a backward pass: gradients to accumulate into, the trainer's marks, the end-of-pass callback."""
+        dev = self.params[0].device
+        if self.flat is None or self.flat.device != dev:
+            self.flat = torch.empty(self.n, dtype=torch.float32, device=dev)
+        self.epoch += 1
+        self.assigned = [p for p in self.params if p.grad is None and p.requires_grad and p.dtype == torch.float32 and p.device == dev]
+        with torch.no_grad():
+            if len(self.assigned) > len(self.params) // 2:
+                self.flat.zero_()
+                for p in self.assigned:
+                    o = self.off[id(p)]
+                    p.grad = self.flat[o:o + p.numel()].view(p.shape)
+            else:
+                for p in self.assigned:
+                    o = self.off[id(p)]
+                    p.grad = self.flat[o:o + p.numel()].view(p.shape).zero_()
+        for p in self.params:
+            ok = p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
+            p._vlni_direct = p._vlni_defer = ok
+        self.active = True
+        torch.autograd.Variable._execution_engine.queue_callback(self.end)
+
+    def end(self):
+        """End of the backward pass: the queued weight gradients over all their calls, `None` back where nothing arrived, marks off."""
+        try:
+            with torch.no_grad():
+                if self.queue:
+                    flush_wgrads(queue=self.queue, store=set())
+        finally:
+            self.queue.clear()
+            ep = self.epoch
+            for p in self.assigned:
+                if getattr(p, "_vlni_touch", -1) != ep:
+                    p.grad = None
+            for p in self.params:
+                p._vlni_direct = p._vlni_defer = False
+            self.assigned, self.active = [], False
+
+
+def enable_auto_defer(module, on=True):
+    """Marks (or unmarks) a model's plain parameters for GradSession (see above)."""
+    if on:
+        have = {id(getattr(p, "_vlni_auto", None)) for p in module.parameters()}
+        if len(have) == 1 and None not in {getattr(p, "_vlni_auto", None) for p in module.parameters()}:
+            return next(iter(module.parameters()))._vlni_auto        # marked before (wrapper constructor + dropin.wrap_*)
+        return GradSession(module)
+    for p in module.parameters():
+        p._vlni_auto = None
+    return None
 
 
 def mark_agent_model(module):
-    """What the reference-facing wrappers (hamt.models.model_HAMT.VLNBertCMT, duet.models.model.VLNBert) do at construction: deferred
-    weight gradients for the model an agent will train with loss.backward() + its own optimizer - unless several ranks run (the agent then
-    wraps the model in DistributedDataParallel, r2r/agent_cmt.py:61-63, whose reducer must see every gradient arrive through autograd)."""
+    """What the reference-facing wrappers (hamt.models.model_HAMT.VLNBertCMT, duet.models.model.VLNBert) do at construction: direct, grouped
+    gradients for the model an agent will train with loss.backward() + its own optimizer - unless several ranks run (the agent then wraps
+    the model in DistributedDataParallel, r2r/agent_cmt.py:61-63, whose reducer must see every gradient arrive through autograd)."""
     import torch.distributed as dist
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-    enable_auto_defer(module.parameters(), on=not multi)
+    enable_auto_defer(module, on=not multi)
     return module
 
 
-def _auto_ok(ws, bs, dy, x):
-    return all(getattr(p, "_vlni_auto", False) for p in ws) and all(getattr(p, "_vlni_auto", False) for p in bs) \
-        and dy.dtype in H16 and dy.is_contiguous() and x.is_contiguous() and dy.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 \
-        and not torch.cuda.is_current_stream_capturing() and ws[0].dtype == torch.float32
-
-
-def _auto_dst(params, store, late):
-    """Destination of one (row-packed) gradient: the parameters' adjacent `.grad`s if they exist, else the persistent buffer (whose row
-    blocks become the `.grad`s; `store` gets its address - it holds no gradient yet), else a temporary that `late` adds afterwards."""
-    grads = [p.grad for p in params]
-    if all(g is None for g in grads):
-        key = (id(params[0]), len(params))
-        hit = _AUTO_BUF.get(key)
-        shape = (sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:])
-        if hit is None or hit[0]() is not params[0] or hit[1].shape != shape or hit[1].device != params[0].device:
-            hit = _AUTO_BUF[key] = (weakref.ref(params[0]), torch.empty(shape, dtype=torch.float32, device=params[0].device))
-        buf, r = hit[1], 0
-        for p in params:
-            p.grad = buf[r:r + p.shape[0]]
-            r += p.shape[0]
-        store.add(buf.data_ptr())
-        return buf
-    if all(g is not None and g.dtype == torch.float32 for g in grads):
-        v = _packed_grad(params) if len(params) > 1 else (grads[0] if grads[0].is_contiguous() else None)
-        if v is not None:
-            return v
-    tmp = torch.zeros((sum(p.shape[0] for p in params),) + tuple(params[0].shape[1:]), dtype=torch.float32, device=params[0].device)
-    late.append((params, tmp))
-    return tmp
-
-
-def _auto_flush():
-    """End of a backward pass: every queued parameter's weight / bias gradient over all its calls, grouped (flush_wgrads)."""
-    _AQ_STATE["queued"] = False
-    items = list(_AQ.values())
-    _AQ.clear()
-    if not items:
-        return
-    store, late, queue = set(), [], {}
-    with torch.no_grad():
-        for ws, bs, segs in items:
-            wv, bv = _auto_dst(ws, store, late), _auto_dst(bs, store, late)
-            queue[wv.data_ptr()] = (wv, bv, segs)
-        flush_wgrads(queue=queue, store=store)
-        for params, tmp in late:
-            for prm, t in zip(params, _split_rows(tmp, [q.shape[0] for q in params])):
-                if prm.grad is None:
-                    prm.grad = t.clone()
-                else:
-                    prm.grad.add_(t.to(prm.grad.dtype))
+def _session(params):
+    """The open GradSession of these parameters (opening it if this is a backward pass and they are marked), else None."""
+    p0 = params[0]
+    ses = getattr(p0, "_vlni_auto", None)
+    if ses is None or not AUTO_DEFER:
+        return None
+    if not ses.active:
+        if torch._C._current_graph_task_id() < 0 or torch.cuda.is_current_stream_capturing() or getattr(p0, "_vlni_direct", False):
+            return None                    # not inside backward(); or a FlatTrainer owns these parameters
+        ses.begin()
+    ep = ses.epoch
+    for p in params:
+        if p is not None:
+            p._vlni_touch = ep
+    return ses
 
 
 def _ln_bwd_to(dy, x, g, b, mean, rstd, want, dres=None, drop=None):
