@@ -213,3 +213,49 @@ def test_agent_backward_groups_weight_gradients_and_recasts_weights_in_one_launc
     recast = lambda c: sum(v for k, v in c.items() if k in ("vlni_cast", "vlni_transpose"))
     assert wg(c1) <= 0.6 * wg(c0), (wg(c0), wg(c1))          # T = 3 steps here (and the text encoder's projections run once per episode anyway)
     assert recast(c1) + 20 <= recast(c0) and c1.get("vlni_shadow_refresh", 0) in (1, 2), (recast(c0), recast(c1), c1.get("vlni_shadow_refresh"))
+
+
+def test_gradient_session_survives_an_aborted_backward():
+    """A backward pass that raises half way never reaches the engine callback that closes ops.GradSession: the next pass must find the stale
+    session, drop what it queued, and produce the same gradients as plain autograd."""
+    from tests.golden.variants import HAMT_C1
+    from tests.test_hamt_gpu import build_product
+    from vln_imagine_amd import dropin, ops, synth
+    from vln_imagine_amd.hamt.config import HamtConfig
+    from vln_imagine_amd.hamt.episode import EpisodeTensors
+    cfg = HamtConfig(**HAMT_C1)
+    et = EpisodeTensors(synth.HamtEpisode(tag="abort", B=8, L=80, V=37, I=4, T=2, ragged=True), "cuda")
+
+    def grads(on, sabotage):
+        was = ops.AUTO_DEFER
+        ops.AUTO_DEFER = on
+        real = ops.ln_bwd
+        try:
+            ops.reseed(5)
+            m = build_product(cfg, torch.bfloat16)
+            w = dropin.wrap_hamt(m, feat_dropout=0.0)
+            if sabotage:
+                calls = [0]
+
+                def failing(*a, **k):
+                    calls[0] += 1
+                    if calls[0] == 3:
+                        raise RuntimeError("injected")
+                    return real(*a, **k)
+                ops.ln_bwd = failing
+                with pytest.raises(RuntimeError, match="injected"):
+                    dropin.hamt_agent_loss(w, et)[0].backward()
+                ops.ln_bwd = real
+                for p in m.parameters():
+                    p.grad = None
+            dropin.hamt_agent_loss(w, et)[0].backward()
+            return {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            ops.ln_bwd = real
+            ops.AUTO_DEFER = was
+
+    ref, got = grads(False, False), grads(True, True)
+    assert set(ref) == set(got)
+    top = max(v.abs().max().item() for v in ref.values())
+    for n in ref:
+        assert (ref[n].float() - got[n].float()).abs().max().item() <= 1e-4 * top, n

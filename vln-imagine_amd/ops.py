@@ -1732,7 +1732,7 @@ class GradSession:
                 self.off[id(p)] = n
                 n += (p.numel() + 7) // 8 * 8
         self.n, self.flat, self.queue = n, None, {}
-        self.active, self.epoch, self.assigned = False, 0, []
+        self.active, self.epoch, self.assigned, self.task = False, 0, [], -1
         ref = weakref.ref(self)
         for p in self.params:
             p._vlni_auto = self
@@ -1763,7 +1763,7 @@ class GradSession:
         for p in self.params:
             ok = p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
             p._vlni_direct = p._vlni_defer = ok
-        self.active = True
+        self.active, self.task = True, torch._C._current_graph_task_id()
         torch.autograd.Variable._execution_engine.queue_callback(self.end)
 
     def end(self):
@@ -1811,6 +1811,9 @@ def _session(params):
     ses = getattr(p0, "_vlni_auto", None)
     if ses is None or not AUTO_DEFER:
         return None
+    if ses.active and ses.task != torch._C._current_graph_task_id():
+        ses.queue.clear()                  # a backward pass that raised never reached its callback: drop what it left behind
+        ses.end()
     if not ses.active:
         if torch._C._current_graph_task_id() < 0 or torch.cuda.is_current_stream_capturing() or getattr(p0, "_vlni_direct", False):
             return None                    # not inside backward(); or a FlatTrainer owns these parameters
