@@ -357,7 +357,8 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
   const int c = blockIdx.x * 256 + threadIdx.x;
   const float wc = c < H ? w[c] : 0.f;
   float aw = 0.f, ab = 0.f;
-  for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+  int r = blockIdx.y;
+  for (; r < rows; r += gridDim.y) {
     const float g = (mask && mask[r]) ? 0.f : dl[r];
     if (c < H) {
       DT<T>::st(dh + (long)r * lddh + c, g * wc);
