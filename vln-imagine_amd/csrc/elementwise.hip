@@ -1004,7 +1004,10 @@ extern "C" int vlni_rowdot_fwd(int dtype, const void* h, long ldh, const float* 
 extern "C" int vlni_rowdot_bwd(int dtype, const float* dl, const void* h, long ldh, const float* w, const unsigned char* mask,
                                void* dh, long lddh, float* dw, float* dbias, int rows, int H, void* stream) {
   VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "rowdot_bwd: rows=%d H=%d", rows, H);
-  dim3 grid(cdiv(H, 256), std::max(1, std::min(rows / 4, 128))), block(256);   // rows strided over grid.y: each dh row written once
+  // rows strided over grid.y: each dh row written once. A thread's loop is a chain of dependent loads (one row per ~0.8 us): 512 row groups keep the
+  // episode's 14 k candidate rows at ~28 trips per thread (128 groups: 111 trips, 90 us) for 4 x the atomics of the column sums
+  static const int gy = [] { const char* e = getenv("VLNI_ROWDOT_BWD_GROUPS"); return e ? atoi(e) : 512; }();
+  dim3 grid(cdiv(H, 256), std::max(1, std::min(rows / 4, gy))), block(256);
   BY_DTYPE(dtype, hipLaunchKernelGGL((rowdot_bwd_kernel<float>), grid, block, 0, (hipStream_t)stream, dl, (const float*)h, ldh, w, mask, (float*)dh, lddh, dw, dbias, rows, H),
            hipLaunchKernelGGL((rowdot_bwd_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, dl, (const __bf16*)h, ldh, w, mask, (__bf16*)dh, lddh, dw, dbias, rows, H),
           hipLaunchKernelGGL((rowdot_bwd_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, dl, (const _Float16*)h, ldh, w, mask, (_Float16*)dh, lddh, dw, dbias, rows, H));
