@@ -9,7 +9,7 @@ OBJ=$R/vln-imagine_amd/build/variants/$(basename $OUT .so)_$(basename $SRC .hip)
 EXTRA=""; if [ "$SRC" == "attention.hip" ]; then EXTRA="-mllvm -amdgpu-mfma-vgpr-form"; fi    # as vln-imagine_amd/build.py:EXTRA
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-function $EXTRA "$@" -c $R/vln-imagine_amd/csrc/$SRC -o $OBJ
 OBJS=""
-for s in api gemm layernorm elementwise attention graphmap; do
+for s in api gemm layernorm elementwise attention graphmap blocks; do
   if [ "$s.hip" == "$SRC" ]; then OBJS="$OBJS $OBJ"; else OBJS="$OBJS $R/vln-imagine_amd/build/$s.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
