@@ -146,7 +146,11 @@ template <typename T> __device__ __forceinline__ float gelu_with_grad_t(float x,
 // (seed, element index) instead of storing it. idx = row * row_length + col of the tensor the mask applies to.
 constexpr unsigned DROP_MUL = 0x9E3779B1u;
 __host__ __device__ __forceinline__ unsigned drop_mix(unsigned x) {      // x = idx * DROP_MUL + seed
+#ifdef VLNI_DROP_ONE_MUL            // timing-only A/B build (tools/build_variant.sh): the bound of a cheaper hash, not a product option
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15;
+#else
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+#endif
   return x;
 }
 __host__ __device__ __forceinline__ unsigned drop_hash(unsigned idx, unsigned seed) { return drop_mix(idx * DROP_MUL + seed); }
