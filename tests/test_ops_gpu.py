@@ -505,6 +505,66 @@ def test_launch_table_uploaded_inside_a_capture(ops):
         assert torch.equal(dst, want)
 
 
+def test_reduce_parts_modes_and_spread_sum_of_squares(ops):
+    """vlni_reduce_parts_sq entry modes (include/vlni.h VLNI_PART_*): add onto dst, store, zero fill (store with no partials), sum of squares only
+    (no write), and the sum of squares of what each flagged entry leaves in dst, spread over the slots and folded by vlni_sumsq_fold."""
+    import numpy as np
+    torch.manual_seed(2)
+    n, sp = 8192 + 1024 + 4, 3                                  # not a multiple of a block's 4096 floats
+    parts = torch.randn(sp, n, device="cuda")
+    mk = lambda: torch.randn(n, device="cuda")
+    d_add, d_store, d_zero, d_ro = mk(), mk(), mk(), mk()
+    want = {"add": d_add + parts.sum(0), "store": parts[0] + parts[1] + parts[2], "zero": torch.zeros(n, device="cuda"), "ro": d_ro.clone()}
+    ents = [(d_add, parts, sp | ops.PART_SUMSQ), (d_store, parts, sp | ops.PART_STORE | ops.PART_SUMSQ), (d_zero, None, ops.PART_STORE),
+            (d_ro, None, ops.PART_NOWRITE | ops.PART_SUMSQ)]
+    arr, blk = np.zeros((len(ents),), ops._PART_DT), 0
+    for i, (dst, prt, flags) in enumerate(ents):
+        arr[i] = (dst.data_ptr(), prt.data_ptr() if prt is not None else 0, n // 4, n // 4, flags, blk)
+        blk += -(-(n // 4) // 1024)
+    tab = ops._dev_table(arr, d_add.device)
+    slots = torch.zeros(32 * ops.SUMSQ_SLOTS, device="cuda")
+    total = torch.zeros(1, device="cuda")
+    ops._lib.call("vlni_reduce_parts_sq", tab.data_ptr(), len(ents), blk, slots.data_ptr(), ops.SUMSQ_SLOTS, ops._st())
+    ops._lib.call("vlni_sumsq_fold", slots.data_ptr(), ops.SUMSQ_SLOTS, total.data_ptr(), ops._st())
+    for got, key in ((d_add, "add"), (d_store, "store"), (d_zero, "zero"), (d_ro, "ro")):
+        assert (got - want[key]).abs().max().item() <= 1e-5, key
+    ss = sum(float((want[k].double() ** 2).sum()) for k in ("add", "store", "ro"))
+    assert abs(total.item() - ss) <= 1e-5 * ss
+    assert int((slots.view(-1, 32)[:, 0] != 0).sum()) >= min(blk, ops.SUMSQ_SLOTS) // 2 and float(slots.view(-1, 32)[:, 1:].abs().sum()) == 0.0
+
+
+def test_stale_weight_copies_are_recast_in_one_launch(ops):
+    """ShadowCache._refresh_plain / vlni_shadow_refresh: after an in-place update of plain float32 parameters (what torch.optim's step is to the
+    cache) every cached 16-bit copy - single, row-packed Q | K | V, transposed, bias vectors - is rewritten in place by ONE launch and equals a
+    fresh cast; the tensors handed out before stay the same objects."""
+    torch.manual_seed(3)
+    mkp = lambda *s: torch.nn.Parameter(torch.randn(*s, device="cuda"))
+    q, k, v, o = mkp(768, 768), mkp(768, 768), mkp(768, 768), mkp(768, 3072)
+    bq, bk, bv = mkp(768), mkp(768), mkp(768)
+    dt = torch.bfloat16
+    was = ops.BATCH_SHADOWS
+    ops.BATCH_SHADOWS = True
+    calls, real = [], ops._lib.call
+    try:
+        get = lambda: (ops.SHADOWS.get((q, k, v), dt), ops.SHADOWS.get((q, k, v), dt, True), ops.SHADOWS.get((o,), dt), ops.SHADOWS.get((o,), dt, True),
+                       ops.SHADOWS.get((bq, bk, bv), dt))
+        first = get()
+        with torch.no_grad():
+            for p in (q, k, v, o, bq, bk, bv):
+                p.mul_(1.5).add_(0.25)
+        ops._lib.call = lambda name, *a: (calls.append(name), real(name, *a))[1]
+        second = get()
+    finally:
+        ops._lib.call = real
+        ops.BATCH_SHADOWS = was
+    assert calls.count("vlni_shadow_refresh") == 1 and not any(c in ("vlni_cast", "vlni_transpose") for c in calls), calls
+    assert all(a is b for a, b in zip(first, second))
+    W = torch.cat([q, k, v], 0).detach()
+    assert torch.equal(second[0], W.to(dt)) and torch.equal(second[1], W.to(dt).t().contiguous())
+    assert torch.equal(second[2], o.detach().to(dt)) and torch.equal(second[3], o.detach().to(dt).t().contiguous())
+    assert torch.equal(second[4], torch.cat([bq, bk, bv]).detach().to(dt))
+
+
 def test_small_ops(ops):
     import torch.nn.functional as F
     torch.manual_seed(0)
