@@ -511,6 +511,9 @@ def main():
                         n += t_.numel() * t_.element_size()
             return n
 
+        def _epi_tag(k):                # which epilogue kind the launch runs (the persistent kernels are instantiated per kind)
+            return (" res" if k.get("residual") is not None else "") + (" drop" if k.get("drop") is not None else "") + (" pre" if k.get("preact") is not None else "")
+
         def _n_of(b):
             return b.n if isinstance(b, ops.WT) else b.t.shape[1] if isinstance(b, ops.KN) else b.shape[0]      # WT / KN: dgrad operand handles
 
@@ -522,7 +525,7 @@ def main():
             r = orig(a, b, *p, **k)
             e1.record()
             rec.append((2.0 * a.shape[0] * _n_of(b) * a.shape[1], e0, e1, (a.shape[0], _n_of(b), a.shape[1]),
-                        ("nn" if isinstance(b, (ops.WT, ops.KN)) else "nt") + f" act{k.get('act', 0)} dact{k.get('dact', 0)}"))
+                        ("nn" if isinstance(b, (ops.WT, ops.KN)) else "nt") + f" act{k.get('act', 0)} dact{k.get('dact', 0)}" + _epi_tag(k), _epi_bytes(k)))
             epi[0] += _epi_bytes(k)
             return r
 
@@ -535,7 +538,8 @@ def main():
             e1.record()
             rows = a[0].shape[0] + a[1].shape[0]
             rec.append((2.0 * rows * _n_of(b[0]) * a[0].shape[1], e0, e1, (rows, _n_of(b[0]), a[0].shape[1]),
-                        ("nn" if isinstance(b[0], (ops.WT, ops.KN)) else "nt") + f" act{k.get('act', 0)} dact{k.get('dact', 0)} dual {a[0].shape[0]}+{a[1].shape[0]}"))
+                        ("nn" if isinstance(b[0], (ops.WT, ops.KN)) else "nt") + f" act{k.get('act', 0)} dact{k.get('dact', 0)}" + _epi_tag(k)
+                        + f" dual {a[0].shape[0]}+{a[1].shape[0]}", _epi_bytes(k)))
             epi[0] += _epi_bytes(k)
             return r
 
@@ -568,7 +572,7 @@ def main():
         tot_ms = sum(max(r[1].elapsed_time(r[2]) - pair_ms, 1e-4) for r in rec)
         if os.environ.get("VLNI_GEMM_BREAKDOWN"):
             agg = {}
-            for f, e0, e1, shp, kind in rec:
+            for f, e0, e1, shp, kind, _ in rec:
                 a_ = agg.setdefault((shp, kind), [0, 0.0, 0.0])
                 a_[0] += 1; a_[1] += max(e0.elapsed_time(e1) - pair_ms, 1e-4); a_[2] += f
             for (shp, kind), (n, ms_, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ["VLNI_GEMM_BREAKDOWN"])]:
@@ -613,7 +617,25 @@ def main():
             pass
         except Exception as e:                                  # never lets the reference measurement break the line
             log(f"large-GEMM ceiling not measured ({type(e).__name__}: {e})")
-        alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_), _ in rec)
+        alg = sum(2.0 * (m_ * k_ + n_ * k_ + m_ * n_) for _, _, _, (m_, n_, k_), _, _ in rec)
+        # Per shape: the launch's floor is max(MFMA time, HBM time) - M x 768 x 768 with a residual or GELU' operand is HBM-bound, not MFMA-bound
+        # (VERDICT round 5, item 5). flops / peak against bytes (A + B + C + the epilogue's tensors, element size of the timed dtype) / the HBM
+        # peak of the guide (8 TB/s; 6.29 TB/s is what a copy reaches: `hbm_achievable_us`).
+        es_b = 4 if args.dtype == "fp32" else 2
+        shp_agg = {}
+        for f, e0, e1, (m_, n_, k_), kind, eb in rec:
+            a_ = shp_agg.setdefault((m_, n_, k_, kind), [0, 0.0, 0.0, 0.0])
+            a_[0] += 1; a_[1] += max(e0.elapsed_time(e1) - pair_ms, 1e-4); a_[2] += f; a_[3] += es_b * (m_ * k_ + n_ * k_ + m_ * n_) + eb
+        per_shape, floor_ms, floor_ach_ms = [], 0.0, 0.0
+        for (m_, n_, k_, kind), (cnt, ms_, f, by) in sorted(shp_agg.items(), key=lambda kv: -kv[1][1]):
+            mfma_us, hbm_us, hbm_ach_us = f / cnt / (peak * 1e12) * 1e6, by / cnt / (HBM_PEAK_GBS * 1e9) * 1e6, by / cnt / 6.29e12 * 1e6
+            floor_ms += cnt * max(mfma_us, hbm_us) * 1e-3
+            floor_ach_ms += cnt * max(mfma_us, hbm_ach_us) * 1e-3
+            per_shape.append({"M": m_, "N": n_, "K": k_, "kind": kind, "launches": cnt, "us": round(ms_ / cnt * 1e3, 1), "tflops": round(f / ms_ / 1e9, 1),
+                              "mfma_us": round(mfma_us, 1), "hbm_us": round(hbm_us, 1), "bound": "hbm" if hbm_us > mfma_us else "mfma",
+                              "frac_of_floor": round(max(mfma_us, hbm_us) / (ms_ / cnt * 1e3), 3)})
+        if os.environ.get("VLNI_GEMM_SHAPES_OUT"):           # tools/gemm_shapes.py replays these shapes beside the vendor library
+            json.dump(per_shape, open(os.environ["VLNI_GEMM_SHAPES_OUT"], "w"), indent=1)
         def fam_sum(prefixes):
             sel = [f_ for f_ in fam if f_[0].startswith(prefixes)]
             t_ = sum(max(f_[2].elapsed_time(f_[3]) - pair_ms, 1e-4) for f_ in sel)
@@ -634,7 +656,11 @@ def main():
                                   "frac": round(by_ / (t_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                   "bytes": "q, k, v, out read/written once" + (" + dout read, dq, dk, dv written" if "bwd" in key_ else "")}
         roof = {"bound": "mfma", "kernel": "gemm_nt_* / gemm_nn_* <%s>" % {"bf16": "__bf16", "fp16": "_Float16", "fp32": "float"}[args.dtype],
-                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                # the family against the per-shape floor max(flops / MFMA peak, bytes / HBM peak): 1.0 = every launch at its own roofline
+                "frac_of_per_shape_floor": round(floor_ms / tot_ms, 4), "frac_of_per_shape_floor_hbm_6p29": round(floor_ach_ms / tot_ms, 4),
+                "hbm_bound_launches": sum(x["launches"] for x in per_shape if x["bound"] == "hbm"),
+                "bound_per_shape": per_shape[:12], "traffic": traffic,
                 "traffic_source": traffic_src, "traffic_ratio": round(traffic / (alg / len(rec)), 3) if traffic else None,
                 "algorithmic_bytes_per_launch": round(alg / len(rec)),
                 "algorithmic_bytes_per_launch_with_epilogue": round((alg + epi[0]) / len(rec)),

@@ -31,6 +31,11 @@ int vlni_version(void);
    captured hipGraph draw new masks on every replay: a node of the graph advances *device_ptr, forward and backward nodes of the
    same replay read the same value. The one piece of process-wide state besides the error string. */
 int vlni_set_dropout_seed_base(const unsigned* device_ptr);
+/* Optional: a device-resident int that counts rows whose table index was out of range. The entry points that take caller-supplied row
+   indices (vlni_embed_combine_fwd, vlni_scatter_add_rows, vlni_scatter_add_rows_small) never touch memory outside the table: such a row
+   adds nothing, and - once a counter is registered - is counted, so the host can raise the way nn.Embedding (R:535-544, R:596-618) would,
+   when it chooses to look (no per-call device-to-host sync). NULL / never called = skipped silently. */
+int vlni_set_index_error_counter(int* device_ptr);
 /* Host -> device copy of a small launch table on `stream` (hipMemcpyAsync). From pinned host memory it may be recorded into a hipGraph
    capture (a memcpy node; the host bytes must stay alive and unchanged for the graph's life). */
 int vlni_upload(void* dst, const void* src_host, long bytes, void* stream);
@@ -211,9 +216,9 @@ int vlni_smallk_linear_fwd(int dtype, const float* x, long ldx, const float* W, 
                            int N, int K, void* stream);
 int vlni_smallk_linear_bwd(int dtype, const void* dy, long lddy, const float* x, long ldx, float* dW, float* db, int rows,
                            int N, int K, void* stream);
-/* table_grad[idx[r]] += src[r] (nn.Embedding backward); idx NULL: all rows into row 0 */
+/* table_grad[idx[r]] += src[r] (nn.Embedding backward) for idx[r] in [0, table_rows); idx NULL: all rows into row 0 */
 int vlni_scatter_add_rows(int dtype, const void* src, long lds, const long* idx, float* table_grad, int rows, int H,
-                          void* stream);
+                          int table_rows, void* stream);
 /* the same for a table of <= 8 rows whose indices lie in [0, table_rows) (navigation-type / token-type embeddings): register
    accumulators per table row, block totals as atomics - thousands of rows on 2-3 table rows serialise the per-element atomics */
 int vlni_scatter_add_rows_small(int dtype, const void* src, long lds_, const long* idx, float* table_grad, int rows, int H,
@@ -342,8 +347,8 @@ int vlni_scale_cast(int dt_in, int dt_out, const void* src, void* dst, long n, f
  * Backward = the existing operators (vlni_dropout, vlni_layernorm_bwd x3, vlni_smallk_linear_bwd, vlni_colsum, vlni_scatter_add_rows). */
 int vlni_embed_combine_fwd(int dtype, const void* a, long lda, const float* ga, const float* ba, const float* f, long ldf, int K,
                            const float* Wb, const float* bb, const float* gb, const float* beb, const void* extra, long lde,
-                           const float* row, const float* table, const long* idx, const float* table2, const long* idx2,
-                           const float* go, const float* bo, float eps, void* linb, void* xsum, void* y, long ldy, float* mean_a,
+                           const float* row, const float* table, const long* idx, int table_rows, const float* table2, const long* idx2,
+                           int table2_rows, const float* go, const float* bo, float eps, void* linb, void* xsum, void* y, long ldy, float* mean_a,
                            float* rstd_a, float* mean_b, float* rstd_b, float* mean_o, float* rstd_o, float drop_p, unsigned drop_seed,
                            int rows, int H, void* stream);
 

@@ -49,7 +49,7 @@ SIGNATURES = {
     "vlni_colsum": [I, P, L, I, I, P, P],
     "vlni_smallk_linear_fwd": [I, P, L, P, P, P, L, I, I, I, P],
     "vlni_smallk_linear_bwd": [I, P, L, P, L, P, P, I, I, I, P],
-    "vlni_scatter_add_rows": [I, P, L, P, P, I, I, P],
+    "vlni_scatter_add_rows": [I, P, L, P, P, I, I, I, P],
     "vlni_scatter_add_rows_small": [I, P, L, P, P, I, I, I, P],
     "vlni_seqmean_fwd": [I, P, P, P, I, I, I, P],
     "vlni_seqmean_bwd": [I, P, P, P, I, I, I, P],
@@ -71,6 +71,7 @@ SIGNATURES = {
     "vlni_clip_coef": [P, F, P, P],
     "vlni_transpose_batched": [I, P, I, I, P],
     "vlni_set_dropout_seed_base": [P],
+    "vlni_set_index_error_counter": [P],
     "vlni_build_views": [I, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "vlni_graph_init": [P, P, P, I, I, P],
     "vlni_graph_observe": [P, P, P, P, P, P, P, P, P, P, I, I, I, P],
@@ -86,7 +87,7 @@ SIGNATURES = {
     "vlni_optim_prepare_groups": [P, F, F, F, P, P, P, I, I, P],
     "vlni_adamw_step_groups": [P, P, P, P, P, I, L, P, P, P, I, F, F, F, F, P, P],
     "vlni_scale_cast": [I, I, P, P, L, F, P],
-    "vlni_embed_combine_fwd": [I, P, L, P, P, P, L, I, P, P, P, P, P, L, P, P, P, P, P, P, P, F, P, P, P, L, P, P, P, P, P, P, F, U, I, I, P],
+    "vlni_embed_combine_fwd": [I, P, L, P, P, P, L, I, P, P, P, P, P, L, P, P, P, I, P, P, I, P, P, F, P, P, P, L, P, P, P, P, P, P, F, U, I, I, P],
     "vlni_ln_rowdot_fwd": [I, P, L, P, P, F, P, P, P, P, P, P, P, F, U, I, I, P],
     "vlni_self_att_block_fwd": [P, P], "vlni_self_att_block_bwd": [P, P], "vlni_ffn_block_fwd": [P, P], "vlni_ffn_block_bwd": [P, P],
 }

@@ -26,6 +26,17 @@ extern "C" int vlni_set_dropout_seed_base(const unsigned* device_ptr) {
   return VLNI_OK;
 }
 
+// Optional device-resident counter of out-of-range table indices (embedding gathers / scatters). The kernels that take caller-supplied
+// row indices (vlni_embed_combine_fwd, vlni_scatter_add_rows*) skip a row whose index is outside its table - no out-of-bounds access -
+// and count it here when a counter is registered, so the host can raise like nn.Embedding does (ops.index_errors()), at a time of
+// its choosing instead of a device-to-host sync per call.
+static int* g_index_errors = nullptr;
+int* vlni_index_error_counter() { return g_index_errors; }
+extern "C" int vlni_set_index_error_counter(int* device_ptr) {
+  g_index_errors = device_ptr;
+  return VLNI_OK;
+}
+
 // Host -> device copy of a small table on `stream`. From PINNED host memory this is legal while the stream is being captured (it becomes a
 // memcpy node that re-reads the host bytes on every replay: the caller keeps them alive and unchanged); torch's own copy_ is not.
 extern "C" int vlni_upload(void* dst, const void* src_host, long bytes, void* stream) {

@@ -23,9 +23,14 @@ extern "C" {
   } while (0)
 
 static inline const char* at(const void* p, long off_elems, int es) { return (const char*)p + off_elems * es; }
+// The attention kernels are built for 64-wide heads (H = 64 nh: every released HAMT / DUET checkpoint); another head size takes the caller's
+// launch-by-launch path (VLNI_EUNSUP), it is not scored with the wrong scale.
+#define BLK_HEADS(a) do { if ((a)->nh < 1 || (a)->H != 64 * (a)->nh) return VLNI_EUNSUP; } while (0)
 
 int vlni_self_att_block_fwd(const VlniBlockArgs* a, void* stream) {
   if (!a || a->n < 1 || a->n > 2) return VLNI_EINVAL;
+  BLK_HEADS(a);
+  const float scale = 0.125f;                                  // 1 / sqrt(64)
   const int n = a->n, H = a->H, es = a->dtype == VLNI_F32 ? 4 : 2;
   const void* A[2]; long lda[2]; const void* W[2]; long ldw[2]; void* C[2]; long ldc[2]; int M[2]; const float* bias[2];
   for (int i = 0; i < n; ++i) {
@@ -44,7 +49,7 @@ int vlni_self_att_block_fwd(const VlniBlockArgs* a, void* stream) {
       q[i] = s.mid; k[i] = at(s.mid, H, es); v[i] = at(s.mid, 2L * H, es); ld3[i] = 3L * H; km[i] = s.kmask;
       o[i] = s.aux; ldo[i] = H; lse[i] = s.lse; Sq[i] = s.S; seeds[i] = s.seed_attn;
     }
-    const int rc = vlni_attn_fwd_dual(a->dtype, q, ld3, k, ld3, v, ld3, km, bs, o, ldo, lse, a->s[0].B, a->nh, Sq, Sq, 0.125f, a->p_attn, seeds, stream);
+    const int rc = vlni_attn_fwd_dual(a->dtype, q, ld3, k, ld3, v, ld3, km, bs, o, ldo, lse, a->s[0].B, a->nh, Sq, Sq, scale, a->p_attn, seeds, stream);
     if (rc == VLNI_OK) done = 1;
     else if (rc != VLNI_EUNSUP) return rc;
   }
@@ -52,7 +57,7 @@ int vlni_self_att_block_fwd(const VlniBlockArgs* a, void* stream) {
     for (int i = 0; i < n; ++i) {
       const VlniBlockSide& s = a->s[i];
       BLK_TRY(vlni_attn_fwd(a->dtype, s.mid, 3L * H, at(s.mid, H, es), 3L * H, at(s.mid, 2L * H, es), 3L * H, s.kmask, i == 0 ? a->bias0 : nullptr,
-                            s.aux, H, s.lse, s.B, a->nh, s.S, s.S, 0.125f, a->p_attn, s.seed_attn, stream));
+                            s.aux, H, s.lse, s.B, a->nh, s.S, s.S, scale, a->p_attn, s.seed_attn, stream));
     }
   const void* res[2]; long ldr[2]; unsigned dseed[2];
   for (int i = 0; i < n; ++i) {
@@ -95,6 +100,8 @@ static int blk_ln_bwd(const VlniBlockArgs* a, const int* M, void* stream) {
 // activation gradients of the self-attention block; the weight / bias gradients (dWo = dmid_drop^T ctx, dWqkv = dqkv^T x) are the caller's
 int vlni_self_att_block_bwd(const VlniBlockArgs* a, void* stream) {
   if (!a || a->n < 1 || a->n > 2) return VLNI_EINVAL;
+  BLK_HEADS(a);
+  const float scale = 0.125f;                                  // 1 / sqrt(64)
   const int n = a->n, H = a->H, es = a->dtype == VLNI_F32 ? 4 : 2;
   int M[2];
   for (int i = 0; i < n; ++i) M[i] = a->s[i].B * a->s[i].S;
@@ -116,7 +123,7 @@ int vlni_self_att_block_bwd(const VlniBlockArgs* a, void* stream) {
       lse[i] = s.lse; dq[i] = s.dmid; dk[i] = (void*)at(s.dmid, H, es); dv[i] = (void*)at(s.dmid, 2L * H, es); Sq[i] = s.S; seeds[i] = s.seed_attn;
     }
     const int rc = vlni_attn_bwd_dual(a->dtype, q, ld3, k, ld3, v, ld3, km, bs, o, ldo, dO, ldo, lse, dq, ld3, dk, ld3, dv, ld3, a->dbias0, a->s[0].B,
-                                      a->nh, Sq, Sq, 0.125f, a->p_attn, seeds, stream);
+                                      a->nh, Sq, Sq, scale, a->p_attn, seeds, stream);
     if (rc == VLNI_OK) done = 1;
     else if (rc != VLNI_EUNSUP) return rc;
   }
@@ -125,7 +132,7 @@ int vlni_self_att_block_bwd(const VlniBlockArgs* a, void* stream) {
       const VlniBlockSide& s = a->s[i];
       BLK_TRY(vlni_attn_bwd(a->dtype, s.mid, 3L * H, at(s.mid, H, es), 3L * H, at(s.mid, 2L * H, es), 3L * H, s.kmask, i == 0 ? a->bias0 : nullptr, s.aux, H,
                             s.daux, H, s.lse, s.dmid, 3L * H, (void*)at(s.dmid, H, es), 3L * H, (void*)at(s.dmid, 2L * H, es), 3L * H,
-                            i == 0 ? a->dbias0 : nullptr, s.B, a->nh, s.S, s.S, 0.125f, a->p_attn, s.seed_attn, stream));
+                            i == 0 ? a->dbias0 : nullptr, s.B, a->nh, s.S, s.S, scale, a->p_attn, s.seed_attn, stream));
     }
   // dx = dqkv Wqkv (+ dpre: the residual path); streams whose input needs no gradient are left out
   const void* res[2]; long ldr[2]; int Md[2], m = 0;

@@ -19,6 +19,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 void vlni_set_error(const char* fmt, ...);
+int* vlni_index_error_counter();        // device counter of out-of-range table indices (or null), vlni_set_index_error_counter
 const unsigned* vlni_seed_base();      // device pointer set by vlni_set_dropout_seed_base (or null)
 
 #define VLNI_CHECK(cond, code, ...)                 \

@@ -230,9 +230,13 @@ __global__ __launch_bounds__(256) void smallk_bwd_kernel(const T* __restrict__ d
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const T* __restrict__ src, long lds_,
                                                                const long* __restrict__ idx, float* __restrict__ tab, int rows,
-                                                               int H) {
+                                                               int H, int table_rows, int* __restrict__ ierr) {
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const long t = idx ? idx[r] : 0;
+    if (t < 0 || t >= table_rows) {                           // an index outside the table: nothing is added, the row is counted
+      if (ierr && threadIdx.x == 0) atomicAdd(ierr, 1);
+      continue;
+    }
     for (int c = threadIdx.x; c < H; c += 256) atomicAdd(tab + t * H + c, DT<T>::ld(src + (long)r * lds_ + c));
   }
 }
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const T* __restri
 // every thread keeps one register accumulator per table row for its column and only the block totals go out as atomics.
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_add_rows_small_kernel(const T* __restrict__ src, long lds_, const long* __restrict__ idx,
-                                                                     float* __restrict__ tab, int rows, int H, int TR) {
+                                                                     float* __restrict__ tab, int rows, int H, int TR, int* __restrict__ ierr) {
   constexpr int RPB = 32;
   const int c = blockIdx.y * 256 + threadIdx.x, r0 = blockIdx.x * RPB;
   if (c >= H) return;
@@ -252,6 +256,7 @@ __global__ __launch_bounds__(256) void scatter_add_rows_small_kernel(const T* __
   const int r1 = min(rows, r0 + RPB);
   for (int r = r0; r < r1; ++r) {
     const int t = (int)idx[r];                                // uniform over the block
+    if ((t < 0 || t >= TR) && ierr && c == 0) atomicAdd(ierr, 1);      // matches no accumulator below: nothing is added
     const float v = DT<T>::ld(src + (long)r * lds_ + c);
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] += (t == k) ? v : 0.f;
@@ -927,12 +932,13 @@ extern "C" int vlni_smallk_linear_bwd(int dtype, const void* dy, long lddy, cons
 }
 
 extern "C" int vlni_scatter_add_rows(int dtype, const void* src, long lds_, const long* idx, float* table_grad, int rows,
-                                     int H, void* stream) {
-  VLNI_CHECK(rows > 0 && H > 0, VLNI_EINVAL, "scatter_add_rows: rows=%d H=%d", rows, H);
+                                     int H, int table_rows, void* stream) {
+  VLNI_CHECK(rows > 0 && H > 0 && table_rows > 0, VLNI_EINVAL, "scatter_add_rows: rows=%d H=%d table_rows=%d", rows, H, table_rows);
+  int* ierr = vlni_index_error_counter();
   dim3 grid(std::min(rows, 2048)), block(256);
-  BY_DTYPE(dtype, hipLaunchKernelGGL((scatter_add_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, lds_, idx, table_grad, rows, H),
-           hipLaunchKernelGGL((scatter_add_rows_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H),
-          hipLaunchKernelGGL((scatter_add_rows_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)src, lds_, idx, table_grad, rows, H));
+  BY_DTYPE(dtype, hipLaunchKernelGGL((scatter_add_rows_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, lds_, idx, table_grad, rows, H, table_rows, ierr),
+           hipLaunchKernelGGL((scatter_add_rows_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H, table_rows, ierr),
+          hipLaunchKernelGGL((scatter_add_rows_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)src, lds_, idx, table_grad, rows, H, table_rows, ierr));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }
@@ -944,9 +950,9 @@ extern "C" int vlni_scatter_add_rows_small(int dtype, const void* src, long lds_
   VLNI_CHECK(src && idx && table_grad, VLNI_EINVAL, "scatter_add_rows_small: null pointer");
   dim3 grid(cdiv(rows, 32), cdiv(H, 256)), block(256);
   BY_DTYPE(dtype,
-           hipLaunchKernelGGL((scatter_add_rows_small_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, lds_, idx, table_grad, rows, H, table_rows),
-           hipLaunchKernelGGL((scatter_add_rows_small_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H, table_rows),
-          hipLaunchKernelGGL((scatter_add_rows_small_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)src, lds_, idx, table_grad, rows, H, table_rows));
+           hipLaunchKernelGGL((scatter_add_rows_small_kernel<float>), grid, block, 0, (hipStream_t)stream, (const float*)src, lds_, idx, table_grad, rows, H, table_rows, vlni_index_error_counter()),
+           hipLaunchKernelGGL((scatter_add_rows_small_kernel<__bf16>), grid, block, 0, (hipStream_t)stream, (const __bf16*)src, lds_, idx, table_grad, rows, H, table_rows, vlni_index_error_counter()),
+          hipLaunchKernelGGL((scatter_add_rows_small_kernel<_Float16>), grid, block, 0, (hipStream_t)stream, (const _Float16*)src, lds_, idx, table_grad, rows, H, table_rows, vlni_index_error_counter()));
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;
 }

@@ -261,6 +261,7 @@ struct EmbedP {
   float* mean_a; float* rstd_a; float* mean_b; float* rstd_b; float* mean_o; float* rstd_o;
   unsigned drop_thr, drop_seed; float drop_inv; const unsigned* sbase;
   int rows;
+  int trows, trows2; int* ierr;      // rows of table / table2 (an index outside adds nothing and is counted in *ierr when set)
 };
 template <typename T> __device__ __forceinline__ float rt(float x) { return (float)(T)x; }       // round to the activation type and back
 template <> __device__ __forceinline__ float rt<float>(float x) { return x; }
@@ -350,13 +351,17 @@ __global__ __launch_bounds__(256) void embed_combine_kernel(EmbedP p) {
     }
     if (p.table) {
       const long r = p.idx[row];
+      if (r >= 0 && r < p.trows) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) v[c] += *(const f32x4*)(p.table + r * H + c * 256 + lane * 4);
+        for (int c = 0; c < NC; ++c) v[c] += *(const f32x4*)(p.table + r * H + c * 256 + lane * 4);
+      } else if (p.ierr && lane == 0) atomicAdd(p.ierr, 1);
     }
     if (p.table2) {
       const long r = p.idx2[row];
+      if (r >= 0 && r < p.trows2) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) v[c] += *(const f32x4*)(p.table2 + r * H + c * 256 + lane * 4);
+        for (int c = 0; c < NC; ++c) v[c] += *(const f32x4*)(p.table2 + r * H + c * 256 + lane * 4);
+      } else if (p.ierr && lane == 0) atomicAdd(p.ierr, 1);
     }
     if (p.extra) {
 #pragma unroll
@@ -592,8 +597,8 @@ extern "C" int vlni_ln_rowdot_fwd(int dtype, const void* x, long ldx, const floa
 // row, table/idx, table2/idx2, go/bo (no outer LayerNorm: xsum / mean_o / rstd_o unused), drop_p 0. linb [rows, H], xsum [rows, H] dense.
 extern "C" int vlni_embed_combine_fwd(int dtype, const void* a, long lda, const float* ga, const float* ba, const float* f, long ldf, int K,
                                       const float* Wb, const float* bb, const float* gb, const float* beb, const void* extra, long lde,
-                                      const float* row, const float* table, const long* idx, const float* table2, const long* idx2,
-                                      const float* go, const float* bo, float eps, void* linb, void* xsum, void* y, long ldy, float* mean_a,
+                                      const float* row, const float* table, const long* idx, int table_rows, const float* table2, const long* idx2,
+                                      int table2_rows, const float* go, const float* bo, float eps, void* linb, void* xsum, void* y, long ldy, float* mean_a,
                                       float* rstd_a, float* mean_b, float* rstd_b, float* mean_o, float* rstd_o, float drop_p, unsigned drop_seed,
                                       int rows, int H, void* stream) {
   int rc = ln_check("embed_combine_fwd", dtype, rows, H, lda < ldy ? lda : ldy);
@@ -603,6 +608,8 @@ extern "C" int vlni_embed_combine_fwd(int dtype, const void* a, long lda, const 
   VLNI_CHECK(f == nullptr || (K >= 1 && K <= 16 && Wb && gb && beb && mean_b && rstd_b), VLNI_EINVAL, "embed_combine_fwd: small-K branch (K=%d)", K);
   VLNI_CHECK((go == nullptr) == (bo == nullptr) && (go == nullptr || (xsum && mean_o && rstd_o)), VLNI_EINVAL, "embed_combine_fwd: outer LayerNorm");
   VLNI_CHECK((table == nullptr) == (idx == nullptr) && (table2 == nullptr) == (idx2 == nullptr), VLNI_EINVAL, "embed_combine_fwd: table without index");
+  VLNI_CHECK((table == nullptr || table_rows > 0) && (table2 == nullptr || table2_rows > 0), VLNI_EINVAL, "embed_combine_fwd: table rows %d / %d", table_rows,
+             table2_rows);
   VLNI_CHECK(extra == nullptr || lde % 4 == 0, VLNI_EINVAL, "embed_combine_fwd: extra stride %ld", lde);
   VLNI_CHECK(drop_p >= 0.f && drop_p < 1.f, VLNI_EINVAL, "embed_combine_fwd: dropout p=%f", drop_p);
   EmbedP p;
@@ -610,6 +617,7 @@ extern "C" int vlni_embed_combine_fwd(int dtype, const void* a, long lda, const 
   p.row = row; p.table = table; p.idx = idx; p.table2 = table2; p.idx2 = idx2; p.go = go; p.bo = bo; p.eps = eps; p.linb = linb; p.xsum = xsum; p.y = y;
   p.ldy = ldy; p.mean_a = mean_a; p.rstd_a = rstd_a; p.mean_b = mean_b; p.rstd_b = rstd_b; p.mean_o = mean_o; p.rstd_o = rstd_o;
   p.drop_thr = drop_thr(drop_p); p.drop_seed = drop_seed; p.drop_inv = 1.0f / (1.0f - drop_p); p.sbase = vlni_seed_base(); p.rows = rows;
+  p.trows = table_rows; p.trows2 = table2_rows; p.ierr = vlni_index_error_counter();
   if (dtype == VLNI_F32) { using TT = float; LN_DISPATCH(embed_combine_kernel, TT, p); }
   else if (dtype == VLNI_BF16) { using TT = __bf16; LN_DISPATCH(embed_combine_kernel, TT, p); }
   else { using TT = _Float16; LN_DISPATCH(embed_combine_kernel, TT, p); }

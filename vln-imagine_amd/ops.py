@@ -838,6 +838,33 @@ def set_seed_base(t):
     _SEED_BASE[0] = t
 
 
+_INDEX_ERRORS = [None]
+
+
+def watch_index_errors(device=None):
+    """Registers (once per process) the device counter of out-of-range table indices. The gather / scatter kernels that take caller-supplied
+    row indices (navigation types, step ids, positions: vlni_embed_combine_fwd, vlni_scatter_add_rows*) skip such a row instead of reading
+    or adding out of bounds, and count it here - nn.Embedding, which they replace, raised."""
+    if _INDEX_ERRORS[0] is None:
+        _INDEX_ERRORS[0] = torch.zeros(1, dtype=torch.int32, device=device or "cuda")
+        _lib.call("vlni_set_index_error_counter", _INDEX_ERRORS[0].data_ptr())
+    return _INDEX_ERRORS[0]
+
+
+def index_errors(reset=True, raise_=True):
+    """Rows skipped because their table index was out of range since the last call (one device-to-host read: call it where a sync is
+    acceptable - end of an iteration, a test). Raises IndexError like the reference's nn.Embedding lookups unless raise_=False."""
+    t = _INDEX_ERRORS[0]
+    if t is None:
+        return 0
+    n = int(t.item())
+    if n and reset:
+        t.zero_()
+    if n and raise_:
+        raise IndexError(f"{n} embedding row index(es) out of range (navigation-type / step / position ids): those rows contributed nothing")
+    return n
+
+
 def cast(x, dtype, tape=False):
     """tape=True: an ACTIVATION cast inside a forward operator (episode-tape aware); weights and gradients are never taped."""
     if x.dtype == dtype:
@@ -1750,8 +1777,13 @@ class GradSession:
             self.flat = torch.empty(self.n, dtype=torch.float32, device=dev)
         self.epoch += 1
         self.assigned = [p for p in self.params if p.grad is None and p.requires_grad and p.dtype == torch.float32 and p.device == dev]
+        # One fill of the whole buffer only when NO parameter still holds a view of it from an earlier pass (a second backward() without
+        # zero_grad - gradient accumulation, two losses back-propagated one after the other - keeps the first pass's gradients there;
+        # ADVICE round 5). Otherwise only the slots handed out now are zeroed.
+        base = self.flat.untyped_storage().data_ptr()
+        live = any(p.grad is not None and p.grad.is_cuda and p.grad.untyped_storage().data_ptr() == base for p in self.params)
         with torch.no_grad():
-            if len(self.assigned) > len(self.params) // 2:
+            if not live and len(self.assigned) > len(self.params) // 2:
                 self.flat.zero_()
                 for p in self.assigned:
                     o = self.off[id(p)]
@@ -1863,8 +1895,8 @@ class _BlkArgs(ctypes.Structure):            # VlniBlockArgs
                 ("v_in", ctypes.c_int), ("v_out", ctypes.c_int), ("bias0", ctypes.c_void_p), ("dbias0", ctypes.c_void_p), ("s", _BlkSide * 2)]
 
 
-_BLK = _BlkArgs()
-_BLK_REF = ctypes.addressof(_BLK)
+# One zero-initialised argument struct PER CALL: forward runs on the caller's thread and Function.backward on the autograd
+# engine's, so a module-global struct raced between a second model's forward and a backward pass, and kept the previous call's fields.
 
 
 def _known_variant(dt, Ms, N, K, act, dact, res, pre):
@@ -1900,8 +1932,8 @@ def _blk_self_att_fwd(sides, bias0, eps, nh=12):
     Ms = [s[0].shape[0] * s[0].shape[1] for s in sides]
     v_in = _known_variant(dt, Ms, 3 * H, H, 0, 0, False, False)
     v_out = _known_variant(dt, Ms, H, H, 0, 0, True, False)
-    if v_in is None or v_out is None or any(s[0].dtype != dt or s[0].shape[2] != H for s in sides):
-        return None
+    if v_in is None or v_out is None or H != 64 * nh or any(s[0].dtype != dt or s[0].shape[2] != H for s in sides):
+        return None               # (the C entry points score with 1 / sqrt(64): another head size takes the launch-by-launch path)
     pa = max(s[2][0] for s in sides)
     ph = max(s[2][1] for s in sides)
     x2 = [_rows(s[0]) for s in sides]
@@ -1918,7 +1950,7 @@ def _blk_self_att_fwd(sides, bias0, eps, nh=12):
     y = [_new((Ms[i], H), dt, dev) for i in range(n)]
     mean = [_new((Ms[i],), torch.float32, dev) for i in range(n)]
     rstd = [_new((Ms[i],), torch.float32, dev) for i in range(n)]
-    a = _BLK
+    a = _BlkArgs()
     a.dtype, a.n, a.H, a.FF, a.nh, a.eps, a.p_attn, a.p_hidden = _DT[dt], n, H, 0, nh, eps, pa, ph
     a.v_in, a.v_out, a.bias0, a.dbias0 = v_in, v_out, _p(bias0) or None, None
     for i, (x, kmask, drop, P) in enumerate(sides):
@@ -1930,7 +1962,7 @@ def _blk_self_att_fwd(sides, bias0, eps, nh=12):
         sd.seed_attn, sd.seed_dense = _blk_seed(drop[2], B * nh * S * S, pa > 0.0), _blk_seed(drop[2] + 1, Ms[i] * H, ph > 0.0)
         sd.mid, sd.aux, sd.lse, sd.pre = mid[i].data_ptr(), aux[i].data_ptr(), lse[i].data_ptr(), pre[i].data_ptr()
         sd.y, sd.mean, sd.rstd = y[i].data_ptr(), mean[i].data_ptr(), rstd[i].data_ptr()
-    _lib.call("vlni_self_att_block_fwd", _BLK_REF, _st())
+    _lib.call("vlni_self_att_block_fwd", ctypes.addressof(a), _st())
     return [(x2[i], mid[i], aux[i], lse[i], pre[i], y[i], mean[i], rstd[i]) for i in range(n)]
 
 
@@ -1952,11 +1984,11 @@ def _blk_self_att_bwd(sides, bias0, want_dbias, nh=12):
     nd = [i for i in range(n) if sides[i][12]]
     v_out = _known_variant(dt, Ms, H, H, 0, 0, False, False)
     v_in = _known_variant(dt, [Ms[i] for i in nd], H, 3 * H, 0, 0, True, False) if nd else 0
-    if v_in is None or v_out is None:
+    if v_in is None or v_out is None or H != 64 * nh:
         return None
     pa = max(s[9][0] for s in sides)
     ph = max(s[9][1] for s in sides)
-    a = _BLK
+    a = _BlkArgs()
     a.dtype, a.n, a.H, a.FF, a.nh, a.eps, a.p_attn, a.p_hidden = _DT[dt], n, H, 0, nh, 0.0, pa, ph
     dbias0 = torch.zeros_like(bias0) if (bias0 is not None and want_dbias) else None
     a.v_in, a.v_out, a.bias0, a.dbias0 = v_in, v_out, _p(bias0) or None, _p(dbias0) or None
@@ -1978,7 +2010,7 @@ def _blk_self_att_bwd(sides, bias0, want_dbias, nh=12):
         sd.dy, sd.lddy, sd.dpre, sd.dmid_drop, sd.daux, sd.dmid = dy2.data_ptr(), dy2.stride(0), dpre.data_ptr(), dmd.data_ptr(), dc.data_ptr(), dqkv.data_ptr()
         sd.dx, sd.dgamma, sd.dbeta = _p(dx) or None, _p(dg) or None, _p(db) or None
         keep.append((dy2, dpre, dmd, dc, dqkv, dx, dg, db, ret))
-    _lib.call("vlni_self_att_block_bwd", _BLK_REF, _st())
+    _lib.call("vlni_self_att_block_bwd", ctypes.addressof(a), _st())
     # weight gradients in the launch-by-launch backward's ORDER (out projections of all streams, then in projections): the deferred queue
     # keeps first-insertion order, and a captured flush must find the reduction table its warm-up step built
     g8s = [[None] * 8 for _ in range(n)]
@@ -2016,7 +2048,7 @@ def _blk_ffn_fwd(sides, eps):
     y = [_new((Ms[i], H), dt, dev) for i in range(n)]
     mean = [_new((Ms[i],), torch.float32, dev) for i in range(n)]
     rstd = [_new((Ms[i],), torch.float32, dev) for i in range(n)]
-    a = _BLK
+    a = _BlkArgs()
     a.dtype, a.n, a.H, a.FF, a.nh, a.eps, a.p_attn, a.p_hidden = _DT[dt], n, H, FF, 0, eps, 0.0, ph
     a.act, a.dact, a.v_in, a.v_out, a.bias0, a.dbias0 = act, dact, v_in, v_out, None, None
     for i, (x, drop, P) in enumerate(sides):
@@ -2027,7 +2059,7 @@ def _blk_ffn_fwd(sides, eps):
         sd.seed_attn, sd.seed_dense = 0, _blk_seed(drop[2], Ms[i] * H, ph > 0.0)
         sd.mid, sd.aux, sd.lse, sd.pre = h[i].data_ptr(), z[i].data_ptr(), None, pre[i].data_ptr()
         sd.y, sd.mean, sd.rstd = y[i].data_ptr(), mean[i].data_ptr(), rstd[i].data_ptr()
-    _lib.call("vlni_ffn_block_fwd", _BLK_REF, _st())
+    _lib.call("vlni_ffn_block_fwd", ctypes.addressof(a), _st())
     return [(x2[i], z[i], h[i], pre[i], y[i], mean[i], rstd[i]) for i in range(n)]
 
 
@@ -2044,7 +2076,7 @@ def _blk_ffn_bwd(sides):
     if v_in is None or v_out is None:
         return None
     ph = max(s[7][1] for s in sides)
-    a = _BLK
+    a = _BlkArgs()
     a.dtype, a.n, a.H, a.FF, a.nh, a.eps, a.p_attn, a.p_hidden = _DT[dt], n, H, FF, 0, 0.0, 0.0, ph
     a.act, a.dact, a.v_in, a.v_out, a.bias0, a.dbias0 = act, dact, v_in, v_out, None, None
     keep, out = [], []
@@ -2063,7 +2095,7 @@ def _blk_ffn_bwd(sides):
         sd.dy, sd.lddy, sd.dpre, sd.dmid_drop, sd.daux, sd.dmid = dy2.data_ptr(), dy2.stride(0), dpre.data_ptr(), dmd.data_ptr(), dz.data_ptr(), None
         sd.dx, sd.dgamma, sd.dbeta = _p(dx) or None, _p(dg) or None, _p(db) or None
         keep.append((dy2, dpre, dmd, dz, dx, dg, db, ret))
-    _lib.call("vlni_ffn_block_bwd", _BLK_REF, _st())
+    _lib.call("vlni_ffn_block_bwd", ctypes.addressof(a), _st())
     g4s = [[None] * 4 for _ in range(n)]                     # (same order as the launch-by-launch backward: see _blk_self_att_bwd)
     for i, sd_ in enumerate(sides):
         if sd_[9]:
@@ -2221,7 +2253,9 @@ class _XAttPairBlock(torch.autograd.Function):
         ng = ctx.needs_input_grad
         pa, ph, sd = ctx.drop
         wparams = any(ng[6:])
-        direct = wparams and _direct(wq, bq, wk, bk, wv, bv, wo, bo, g, b)
+        # capability check only for the projections (their gradients are QUEUED, not added to here: ADVICE round 5 - without queue=True the
+        # check moved every cross-attention weight out of the arena's stored ranges); the LayerNorm vectors are added to by the kernel
+        direct = wparams and _direct(wq, bq, wk, bk, wv, bv, wo, bo, queue=True) and _direct(g, b)
         dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = dg = db = None
         if direct or not wparams:
             (dpl, _, _, dml), (dpv, _, _, dmv) = _ln_bwd_to2((_rows(dyl), _rows(dyv)), (pre_l, pre_v), (g, g), (b, b), (mean_l, mean_v),
@@ -2312,7 +2346,9 @@ class _XAttPairGivenQBlock(torch.autograd.Function):
         ng = ctx.needs_input_grad
         pa, ph, sd = ctx.drop
         wparams = any(ng[7:])
-        direct = wparams and _direct(wq, bq, wk, bk, wv, bv, wo, bo, g, b)
+        # capability check only for the projections (their gradients are QUEUED, not added to here: ADVICE round 5 - without queue=True the
+        # check moved every cross-attention weight out of the arena's stored ranges); the LayerNorm vectors are added to by the kernel
+        direct = wparams and _direct(wq, bq, wk, bk, wv, bv, wo, bo, queue=True) and _direct(g, b)
         dwo = dbo = dwq = dwk = dwv = dbq = dbk = dbv = dg = db = None
         if direct or not wparams:
             (dpl, _, _, dml), (dpv, _, _, dmv) = _ln_bwd_to2((_rows(dyl), _rows(dyv)), (pre_l, pre_v), (g, g), (b, b), (mean_l, mean_v),
@@ -2870,7 +2906,7 @@ class _SumLayerNorm(torch.autograd.Function):
                               tg.data_ptr(), rows, H, shape[0], _st())
                 else:
                     _lib.call("vlni_scatter_add_rows", _dt(dsum), dsum.data_ptr(), dsum.stride(0), idxs[k].data_ptr(),
-                              tg.data_ptr(), rows, H, _st())
+                              tg.data_ptr(), rows, H, shape[0] if idxs[k] is not None else 1, _st())
                 grads.append(None if direct else tg)
         return (None, None, None, None, None, dg, db) + tuple(grads)
 
@@ -2899,9 +2935,12 @@ class _EmbedCombine(torch.autograd.Function):
         dropping = p_drop > 0.0
         if not _ghost():
             row32 = row.reshape(-1) if row is not None else None
+            if _INDEX_ERRORS[0] is None and (table is not None or table2 is not None) and not torch.cuda.is_current_stream_capturing():
+                watch_index_errors(dev)
             _lib.call("vlni_embed_combine_fwd", _DT[out_dtype], a2.data_ptr(), a2.stride(0), _p(ga), _p(ba), _p(f2), f2.stride(0) if f2 is not None else 0,
                       f2.shape[1] if f2 is not None else 0, _p(Wb), _p(bb), _p(gb), _p(beb), _p(e2), e2.stride(0) if e2 is not None else 0, _p(row32),
-                      _p(table), _p(idx), _p(table2), _p(idx2), _p(go), _p(bo), eps, _p(linb), _p(xs), y.data_ptr(), H, _p(ma), _p(ra), _p(mb), _p(rb),
+                      _p(table), _p(idx), table.shape[0] if table is not None else 0, _p(table2), _p(idx2), table2.shape[0] if table2 is not None else 0,
+                      _p(go), _p(bo), eps, _p(linb), _p(xs), y.data_ptr(), H, _p(ma), _p(ra), _p(mb), _p(rb),
                       _p(mo), _p(ro), p_drop if dropping else 0.0, _shift(seed, rows * H) if dropping else 0, rows, H, _st())
         ctx.save_for_backward(a2, f2, linb, xs, ma, ra, mb, rb, mo, ro, idx, idx2)
         ctx.P = (ga, ba, Wb, bb, gb, beb, row, table, table2, go, bo)
@@ -2947,7 +2986,8 @@ class _EmbedCombine(torch.autograd.Function):
                     _lib.call("vlni_scatter_add_rows_small", _dt(dsum), dsum.data_ptr(), dsum.stride(0), ix.data_ptr(), tg.data_ptr(), dsum.shape[0], H,
                               tab.shape[0], _st())
                 else:
-                    _lib.call("vlni_scatter_add_rows", _dt(dsum), dsum.data_ptr(), dsum.stride(0), ix.data_ptr(), tg.data_ptr(), dsum.shape[0], H, _st())
+                    _lib.call("vlni_scatter_add_rows", _dt(dsum), dsum.data_ptr(), dsum.stride(0), ix.data_ptr(), tg.data_ptr(), dsum.shape[0], H,
+                              tab.shape[0], _st())
                 g[k] = None if direct else tg
         d_extra = None
         if eshape is not None and ng[2]:

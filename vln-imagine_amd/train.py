@@ -471,6 +471,14 @@ class FlatTrainer:
             ops.RESERVE_CUS = self._reserve_before
             del self._reserve_before
 
+    def __del__(self):
+        # a trainer dropped without close(): the module-global arena bookkeeping must not keep its gradient arena alive
+        try:
+            if ops.GRADS.arena is not None and ops.GRADS.arena.data_ptr() == self.flat_g.data_ptr():
+                ops.GRADS.reset()
+        except Exception:
+            pass
+
     def set_defer(self, on):
         """Deferred (grouped, one launch per parameter and episode) vs immediate weight-gradient GEMMs."""
         for p in self.params:
