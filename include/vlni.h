@@ -100,12 +100,12 @@ int vlni_gemm_tn_bf16_grouped(int nseg, const void* const* A, const void* const*
                               long ldc, int N, int K, float* colsum, int split, void* stream);
 
 int vlni_gemm_tn_bf16_grouped_v(int nseg, const void* const* A, const void* const* B, const int* M, long lda, long ldb, float* C,
-                                long ldc, int N, int K, float* colsum, int split, int variant /* 0/1 register-staged, 2..5 LDS-DMA */,
+                                long ldc, int N, int K, float* colsum, int split, int variant /* 0/1 register-staged, 2..5 LDS-DMA 128 x 128, 6 = 256 x 256 two-stage, 7 / 8 = 256 x 256 ring (8: wave rows one barrier apart) */,
                                 void* stream);
 /* The same grouped launch in "partials" mode: row split z stores its share with PLAIN stores to part + z * part_stride (dense [N][K]
    float32) and its column sums to colsum_part + z * N (may be NULL); nothing is accumulated. Float atomics run at ~1.3 TB/s on MI355X
    against ~5 TB/s for stores and were 30-50 % of a weight-gradient launch. Splits actually written: ceil(T / ceil(T / split)) with
-   T = sum ceil(M_s / 64). Needs an LDS-DMA variant (2..7) and at least 3 row tiles per split (else -3).
+   T = sum ceil(M_s / 64). Needs an LDS-DMA variant (2..8) and at least 3 row tiles per split (else -3).
    vlni_reduce_parts then adds the partials into the gradients, MANY tensors per launch: table = device array of
    { float* dst; const float* part; long n4; long stride4; int split; int blk0; } (n4 = float4 per tensor, stride4 = float4 between
    splits, blk0 = first block of the entry, a block covers 1024 float4; entries sorted by blk0), n_blocks = total blocks. */

@@ -694,7 +694,7 @@ def test_wgrad_tn_bf16_exact_and_random(ops, M, N, K):
 
 
 @pytest.mark.parametrize("split", [1, 3, 5])
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8])
 def test_wgrad_tn_lds_dma_variants_exact(ops, variant, split):
     """LDS-DMA pipelines of the grouped transposing-read wgrad (zero page for row tails, MFMA-ones bias gradient): exact on
     small integers over several ragged segments."""
@@ -716,7 +716,7 @@ def test_wgrad_tn_lds_dma_variants_exact(ops, variant, split):
 
 
 @pytest.mark.parametrize("split", [2, 4])
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 7, 8])
 def test_wgrad_partials_then_batched_reduction_exact(ops, variant, split):
     """Partials mode: every row split stores its share (no atomics), vlni_reduce_parts adds all of them into gradients that already
     hold something - two tensors (weight + bias gradient) x two parameters in ONE reduction launch. Exact on small integers."""
@@ -1129,9 +1129,10 @@ def test_timed_gemm_kernels_against_float64_at_bench_shapes(ops, variant, dtype)
                         _chk(z[i], stored, t, (variant, M0, N, K, kind + " (z)", i))
 
 
+@pytest.mark.parametrize("variant", [7, 8])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_ring_weight_gradient_against_float64_at_bench_shapes(ops, dtype):
-    """gemm_tn_ring_kernel (variant 7, what the flush picks for the episode-long reductions) against float64: 49536 rows as the two
+def test_ring_weight_gradient_against_float64_at_bench_shapes(ops, dtype, variant):
+    """gemm_tn_ring_kernel (variants 7 and 8 = its two wave rows one barrier apart; what the flush picks for the episode-long reductions) against float64: 49536 rows as the two
     segments of a shared cross-attention weight, N x K in {2304, 3072, 768} x 768 and 768 x 3072, partial slabs + the batched reduction."""
     import ctypes
     import numpy as np
@@ -1150,7 +1151,7 @@ def test_ring_weight_gradient_against_float64_at_bench_shapes(ops, dtype):
         pa = (ctypes.c_void_p * n)(*[d.data_ptr() for d in dd]); pb = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xx])
         pm = (ctypes.c_int * n)(*Ms)
         cpart = part.data_ptr() + 4 * eff * N * K
-        _lib.call("vlni_gemm_tn_h16_grouped_part", ops._DT[dtype], n, pa, pb, pm, N, K, part.data_ptr(), N * K, N, K, cpart, split, 7, st)
+        _lib.call("vlni_gemm_tn_h16_grouped_part", ops._DT[dtype], n, pa, pb, pm, N, K, part.data_ptr(), N * K, N, K, cpart, split, variant, st)
         arr = np.zeros((2,), ops._PART_DT)
         arr[0] = (gw.data_ptr(), part.data_ptr(), N * K // 4, N * K // 4, eff, 0)
         arr[1] = (gb.data_ptr(), cpart, N // 4, N // 4, eff, -(-(N * K // 4) // 1024))
@@ -1243,3 +1244,51 @@ def test_dual_launch_with_mixed_epilogue_operands_takes_the_generic_kernel(ops, 
     finally:
         ops.AUTOTUNE, ops.GEMM_VARIANTS, ops.P8_MIN_ROWS, ops.P8H_MIN_ROWS = saved
         ops._GEMM_BEST.clear()
+
+
+def test_table_rows_out_of_range_are_skipped_and_counted(ops):
+    """vlni_embed_combine_fwd / vlni_scatter_add_rows* take the table's row count; a navigation-type / step id outside the table
+    adds nothing (no out-of-bounds read, no out-of-bounds scatter in the backward) and is counted in the registered device counter, from which
+    ops.index_errors() raises the IndexError the reference's nn.Embedding lookup (vilmodel_cmt.py:535-544, :596-618) would have raised."""
+    torch.manual_seed(4)
+    rows, H = 64, 768
+    a = torch.randn(rows, H).cuda()
+    table = (torch.randn(3, H) * 0.2).cuda().requires_grad_(True)
+    big = (torch.randn(40, H) * 0.2).cuda().requires_grad_(True)
+    idx = torch.randint(0, 3, (rows,)).cuda()
+    idx2 = torch.randint(0, 40, (rows,)).cuda()
+    ops.watch_index_errors("cuda")
+    assert ops.index_errors() == 0
+    good = ops.embed_combine(a, torch.float32, table=(table, idx), p_drop=0.0, training=False)
+    good2 = ops.embed_combine(a, torch.float32, table=(big, idx2), p_drop=0.0, training=False)
+    bad, bad2 = idx.clone(), idx2.clone()
+    bad[5], bad[9], bad2[7] = 3, -1, 40                                      # one past the end, negative, one past the end of the large table
+    y = ops.embed_combine(a, torch.float32, table=(table, bad), p_drop=0.0, training=False)
+    y2 = ops.embed_combine(a, torch.float32, table=(big, bad2), p_drop=0.0, training=False)
+    keep = torch.ones(rows, dtype=torch.bool, device="cuda")
+    keep[5] = keep[9] = False
+    assert torch.equal(y[keep], good[keep]) and torch.equal(y[~keep], a[~keep])      # the out-of-range rows got no table row
+    assert torch.equal(y2[7], a[7])
+    (y.sum() + y2.sum()).backward()                                           # backward: small-table and generic scatter kernels, both bounded
+    assert torch.isfinite(table.grad).all() and torch.isfinite(big.grad).all()
+    cnt = torch.bincount(idx[keep], minlength=3).float()
+    assert torch.allclose(table.grad.sum(1), cnt * H, rtol=1e-5)              # rows 5 and 9 scattered nowhere
+    assert ops.index_errors(raise_=False) == 6                                # 3 in the forward launches + 3 in the scatters
+    with pytest.raises(IndexError):
+        ops.embed_combine(a, torch.float32, table=(table, bad), p_drop=0.0, training=False)
+        ops.index_errors()
+    assert ops.index_errors() == 0                                            # reset by the raising call
+
+
+def test_block_entry_points_reject_other_head_sizes(ops):
+    """the block-level C entry points score with 1 / sqrt(64); H != 64 nh is VLNI_EUNSUP (-3) there and the Python side keeps such a
+    configuration on the launch-by-launch path."""
+    import ctypes
+    from vln_imagine_amd import _lib
+    a = ops._BlkArgs()
+    a.dtype, a.n, a.H, a.FF, a.nh = 1, 1, 768, 0, 8                          # 96-wide heads
+    lib = _lib.load()
+    assert lib.vlni_self_att_block_fwd(ctypes.addressof(a), 0) == -3
+    assert lib.vlni_self_att_block_bwd(ctypes.addressof(a), 0) == -3
+    x = torch.randn(2, 16, 768).cuda().bfloat16()
+    assert ops._blk_self_att_fwd([(x, None, (0.0, 0.0), None)], None, 1e-12, nh=8) is None

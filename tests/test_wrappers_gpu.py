@@ -158,9 +158,14 @@ def test_agent_backward_groups_weight_gradients_and_recasts_weights_in_one_launc
         et = DuetEpisodeTensors(synth.DuetEpisode(tag="agent", B=16, L=80, V=36, I=4, T=3, ragged=True), "cuda")
         wrap, loss_of = dropin.wrap_duet, dropin.duet_agent_loss
 
+    from vln_imagine_amd import graphed
+
     def program(on):
-        was = ops.AUTO_DEFER, ops.BATCH_SHADOWS
+        # (per-call graphs off: they draw their dropout masks from seeds fixed at capture time, and this test compares the two gradient
+        # protocols mask for mask; the graphs have their own tests below)
+        was = ops.AUTO_DEFER, ops.BATCH_SHADOWS, graphed.ENABLED
         ops.AUTO_DEFER = ops.BATCH_SHADOWS = on
+        graphed.ENABLED = False
         calls, real = {}, ops._lib.call
 
         def counting(name, *a):
@@ -197,7 +202,7 @@ def test_agent_backward_groups_weight_gradients_and_recasts_weights_in_one_launc
             return out, calls
         finally:
             ops._lib.call = real
-            ops.AUTO_DEFER, ops.BATCH_SHADOWS = was
+            ops.AUTO_DEFER, ops.BATCH_SHADOWS, graphed.ENABLED = was
 
     (ref, c0), (got, c1) = program(False), program(True)
     for it, ((l0, g0), (l1, g1)) in enumerate(zip(ref, got)):
@@ -259,3 +264,123 @@ def test_gradient_session_survives_an_aborted_backward():
     top = max(v.abs().max().item() for v in ref.values())
     for n in ref:
         assert (ref[n].float() - got[n].float()).abs().max().item() <= 1e-4 * top, n
+
+
+def test_second_backward_without_zero_grad_keeps_the_first_pass_gradients():
+    """a backward pass that touches FEW parameters (here: the `language` call alone - the text encoder) hands every other
+    parameter its `None` back at the end; the next pass without zero_grad then assigns most parameters anew, and GradSession.begin() must not
+    zero-fill the whole persistent buffer, because the first pass's gradients are views of it. Both programs (session on / off) must hold the SUM."""
+    from tests.golden.variants import HAMT_C1
+    from tests.test_hamt_gpu import build_product
+    from vln_imagine_amd import dropin, ops, synth
+    from vln_imagine_amd.hamt.config import HamtConfig
+    from vln_imagine_amd.hamt.episode import EpisodeTensors
+    cfg = HamtConfig(**HAMT_C1)
+    et = EpisodeTensors(synth.HamtEpisode(tag="twice", B=8, L=80, V=37, I=4, T=2, ragged=True), "cuda")
+
+    def program(on):
+        was = ops.AUTO_DEFER
+        ops.AUTO_DEFER = on
+        try:
+            ops.reseed(5)
+            torch.manual_seed(1)
+            m = build_product(cfg, torch.float32).eval()
+            w = dropin.wrap_hamt(m, feat_dropout=0.0)
+            txt = w("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
+            (txt.float() ** 2).mean().backward()                       # pass 1: text-encoder parameters only
+            first = {n for n, p in m.named_parameters() if p.grad is not None}
+            loss, _ = dropin.hamt_agent_loss(w, et)
+            loss.backward()                                            # pass 2, no zero_grad in between
+            return first, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+        finally:
+            ops.AUTO_DEFER = was
+
+    (f0, g0), (f1, g1) = program(False), program(True)
+    assert f0 == f1 and 0 < len(f1) < len(g1) / 2, (len(f0), len(f1), len(g1))      # the case of the finding: most parameters untouched by pass 1
+    assert set(g0) == set(g1)
+    top = max(v.abs().max().item() for v in g0.values())
+    for n in g0:
+        d = (g0[n] - g1[n]).abs().max().item()
+        assert d <= 1e-4 * top and d <= 2e-3 * max(g0[n].abs().max().item(), 1e-4 * top), (n, n in f1, d, top)
+
+
+def _graphed_program(on, iters, p_drop, T=3, adam=False, family="hamt"):
+    """iters agent iterations (dropin.*_agent_loss + backward [+ torch.optim.AdamW]) on a wrapper with the per-call graphs on / off."""
+    from tests.golden.variants import DUET_C1, HAMT_C1
+    from vln_imagine_amd import dropin, graphed, ops, synth
+    drops = dict(hidden_dropout_prob=p_drop, attention_probs_dropout_prob=p_drop)
+    if family == "hamt":
+        from tests.test_hamt_gpu import build_product
+        from vln_imagine_amd.hamt.config import HamtConfig
+        from vln_imagine_amd.hamt.episode import EpisodeTensors
+        cfg = HamtConfig(**HAMT_C1, pred_head_dropout_prob=p_drop, **drops)
+        et = EpisodeTensors(synth.HamtEpisode(tag="graphed", B=8, L=80, V=37, I=4, T=T, ragged=True), "cuda")
+        wrap, loss_of = dropin.wrap_hamt, dropin.hamt_agent_loss
+    else:
+        from tests.test_duet_gpu import build_product
+        from vln_imagine_amd.duet.config import DuetConfig
+        from vln_imagine_amd.duet.episode import DuetEpisodeTensors
+        cfg = DuetConfig(**DUET_C1, **drops)
+        et = DuetEpisodeTensors(synth.DuetEpisode(tag="graphed", B=8, L=80, V=36, I=4, T=T, ragged=True), "cuda")
+        wrap, loss_of = dropin.wrap_duet, dropin.duet_agent_loss
+    was = graphed.ENABLED
+    graphed.ENABLED = on
+    try:
+        ops.reseed(9)
+        torch.manual_seed(2)
+        m = build_product(cfg, torch.bfloat16).train()
+        w = wrap(m, feat_dropout=0.0)
+        tr = dropin.DropInTrainer(w, et, family, lr=2e-5)
+        out = []
+        for it in range(iters):
+            tr.opt.zero_grad()
+            loss, logits = loss_of(w, et)
+            logits = logits or []
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(tr.params, 40.0)
+            out.append((float(loss.detach()), [lg.detach().float().clone() for lg in logits],
+                        {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+            if adam:
+                tr.opt.step()
+            else:
+                # the weights move the same way in both programs (an optimizer would feed each program's own summation-order noise back through
+                # Adam's normalisation): whether every 16-bit weight copy INSIDE the graphs followed shows in the next iteration
+                with torch.no_grad():
+                    for i, p in enumerate(tr.params):
+                        p.mul_(1.0 + 1e-3 * ((i % 5) - 2))
+        return out, dict(graphed.of(m).stats)
+    finally:
+        graphed.ENABLED = was
+        ops.set_seed_base(None)
+
+
+@pytest.mark.parametrize("family", ["hamt", "duet"])
+def test_one_autograd_node_per_wrapper_call_equals_the_eager_calls(family):
+    """vln_imagine_amd/graphed.py: from the second sighting of a (mode, shapes, occurrence) on, a wrapper call is ONE autograd node that replays
+    captured forward / backward hipGraphs. Dropout off: losses, logits and every gradient of four agent iterations with moving weights
+    (the 16-bit weight copies inside the graphs must follow) equal the eager calls' to 16-bit summation-order noise."""
+    (ref, _), (got, stats) = _graphed_program(False, 4, 0.0, family=family), _graphed_program(True, 4, 0.0, family=family)
+    assert stats["captured"] >= 2 * 3 + 2 and stats["replayed"] >= 3 * stats["captured"] - 3 * (2 * 3 + 2), stats
+    for it, ((l0, lg0, g0), (l1, lg1, g1)) in enumerate(zip(ref, got)):
+        assert abs(l0 - l1) <= 2e-3 * max(1.0, abs(l0)), (it, l0, l1)
+        for a, b in zip(lg0, lg1):
+            fin = torch.isfinite(a)
+            assert torch.equal(fin, torch.isfinite(b)) and (a[fin] - b[fin]).abs().max().item() <= 3e-2, it
+        assert set(g0) == set(g1), (it, sorted(set(g0) ^ set(g1))[:5])
+        top = max(v.abs().max().item() for v in g0.values())
+        for n in g0:
+            d = (g0[n].float() - g1[n].float()).abs().max().item()
+            assert d <= 2e-2 * top, (it, n, d, top)
+
+
+def test_graphed_wrapper_calls_draw_new_dropout_masks_every_iteration():
+    """In-kernel dropout inside replayed graphs: the seeds are constants of the graphs, the device-resident base advances once per backward pass,
+    so two consecutive replayed iterations at the SAME weights (lr = 0 would be needed for equality anyway) differ, and training still converges
+    like the eager path: the loss after a few steps stays within the spread of the eager program's."""
+    (ref, _), (got, stats) = _graphed_program(False, 5, 0.1, adam=True), _graphed_program(True, 5, 0.1, adam=True)
+    assert stats["replayed"] > 0
+    l_ref, l_got = [r[0] for r in ref], [g[0] for g in got]
+    assert all(abs(a - b) <= 0.15 * abs(a) for a, b in zip(l_ref, l_got)), (l_ref, l_got)
+    # replayed iterations 3 and 4 (both from the same graphs): logits differ by more than an optimizer step of 2e-5 would move them
+    d = max((a - b)[torch.isfinite(a)].abs().max().item() for a, b in zip(got[3][1], got[4][1]))
+    assert d > 1e-3, d

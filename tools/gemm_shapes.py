@@ -7,7 +7,7 @@ the per-shape floor max(MFMA time, HBM time).
   3. the table:              python tools/gemm_shapes.py report run.json <dir> "title" > profiles/r06_gemm_shapes.md
 
 `run`: per shape, a marker kernel (torch fill), N eager launches of the product's autotuned pick with the step's epilogue kind, a marker, N calls
-of torch.matmul on the concatenated rows (plain contraction, no epilogue: what the vendor kernel costs before bias / GELU / residual passes);
+of torch.matmul (closed by a third marker) on the concatenated rows (plain contraction, no epilogue: what the vendor kernel costs before bias / GELU / residual passes);
 also HIP-event times of 20 launches replayed from one graph (both). `report`: rocprofv3's kernel durations between the markers (median of
 the product's launches, total / calls for the vendor's, which may be several kernels per call)."""
 import csv
@@ -89,12 +89,13 @@ def run(shapes_path, out_path):
         ours(); vendor()                       # autotune + warm
         ev_ours, ev_vendor = graph_us(ours), graph_us(vendor)
         torch.cuda.synchronize()
-        marker.fill_(float(2 * i))
+        marker.fill_(float(3 * i))
         for _ in range(NREP):
             ours()
-        marker.fill_(float(2 * i + 1))
+        marker.fill_(float(3 * i + 1))
         for _ in range(NREP):
             vendor()
+        marker.fill_(float(3 * i + 2))            # closes the vendor segment (what follows is the next shape's set-up and autotune)
         torch.cuda.synchronize()
         variant = ops._GEMM_BEST.get(key)
         out.append(dict(sh, rows=rows, variant=variant, event_us=round(ev_ours, 1), vendor_event_us=round(ev_vendor, 1)))
@@ -113,16 +114,19 @@ def report(run_path, trace_dir, title):
         ks = []
         for f in files:
             for r in csv.DictReader(open(f)):
-                ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]))
+                ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"],
+                           (r["Grid_Size_X"], r["SGPR_Count"], r["VGPR_Count"])))
         ks.sort()
+        fills = [k for k in ks if "FillFunctor" in k[2]]
+        mark = fills[-1][3]                           # the marker tensor's fill kernel (the run ends with one); other fills (zeros, masks) have other grids
         cur = None
-        for _, d, name in ks:
-            if "FillFunctor" in name:
+        for _, d, name, sig in ks:
+            if "FillFunctor" in name and sig == mark:
                 cur = []
                 segs.append(cur)
             elif cur is not None:
                 cur.append((d / 1e3, name))
-        segs = segs[-(2 * len(rows) + 1):]            # the markers of the replay loop (fills before it belong to warm-up allocations)
+        assert len(segs) == 3 * len(rows) + 1, (len(segs), len(rows))
     print(f"# {title}\n")
     print("One row per (shape, epilogue kind) of the instrumented step (`bench.py`, `roofline.bound_per_shape`), replayed on its own by `tools/gemm_shapes.py`. "
           "`us` = rocprofv3 kernel duration (median of 10 eager launches between marker kernels; `event` = HIP events around 20 launches replayed from one graph). "
@@ -135,11 +139,11 @@ def report(run_path, trace_dir, title):
     tot = [0.0, 0.0, 0.0, 0.0]
     for i, r in enumerate(rows):
         ours_us, ven_us = r["event_us"], r["vendor_event_us"]
-        if len(segs) >= 2 * i + 2:
-            mine = sorted(d for d, n in segs[2 * i] if "gemm" in n)
+        if len(segs) >= 3 * i + 3:
+            mine = sorted(d for d, n in segs[3 * i] if "gemm" in n)
             if mine:
                 ours_us = mine[len(mine) // 2]
-            v = [d for d, n in segs[2 * i + 1]]
+            v = [d for d, n in segs[3 * i + 1] if "Fill" not in n]
             if v:
                 ven_us = sum(v) / NREP
         fl = 2.0 * r["M"] * r["N"] * r["K"]

@@ -132,6 +132,7 @@ extern "C" int vlni_shadow_refresh(int dst_dtype, const void* table_dev, int n, 
   const ShEntry* tab = (const ShEntry*)table_dev;
   if (dst_dtype == VLNI_BF16) hipLaunchKernelGGL((shadow_refresh_kernel<__bf16>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
   else if (dst_dtype == VLNI_F16) hipLaunchKernelGGL((shadow_refresh_kernel<_Float16>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);
+  else if (dst_dtype == VLNI_F32) hipLaunchKernelGGL((shadow_refresh_kernel<float>), dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, tab, n);   // packed float32 copies (Q | K | V biases)
   else { vlni_set_error("shadow_refresh: bad dtype %d", dst_dtype); return VLNI_EINVAL; }
   VLNI_LAUNCH_CHECK();
   return VLNI_OK;

@@ -1042,8 +1042,9 @@ class ShadowCache:
                     t = cast(src, dtype)
         if not any(p.requires_grad for p in params):
             live = True                # frozen parameters: no optimizer step ever touches them
-        if mir is None and dtype in H16 and not live and all(p.dtype == torch.float32 and p.dim() == params[0].dim() <= 2 for p in params):
-            # a plain float32 parameter's own 16-bit copy: _refresh_plain() keeps it current in place
+        if mir is None and (dtype in H16 or dtype == torch.float32) and not live \
+                and all(p.dtype == torch.float32 and p.dim() == params[0].dim() <= 2 for p in params):
+            # a plain float32 parameter's own 16-bit copy (or the float32 row-pack of several: Q | K | V biases): _refresh_plain() keeps it current in place
             self._c[key] = (ver, t, live, self.opt_epoch, weakref.ref(params[0]), tuple(weakref.ref(p) for p in params))
         else:
             self._c[key] = (ver, t, live, self.opt_epoch, weakref.ref(params[0]))
@@ -1083,14 +1084,15 @@ class ShadowCache:
                 for _, e, ps, _, transposed in lst:
                     t, off = e[1], 0
                     for p in ps:
+                        es = t.element_size()
                         if p.dim() == 1:
-                            r, c, lds, ldd, dst = 1, p.shape[0], p.shape[0], p.shape[0], t.data_ptr() + 2 * off
+                            r, c, lds, ldd, dst = 1, p.shape[0], p.shape[0], p.shape[0], t.data_ptr() + es * off
                             off += p.shape[0]
                         elif transposed:
-                            r, c, lds, ldd, dst = p.shape[0], p.shape[1], p.stride(0), t.stride(0), t.data_ptr() + 2 * off
+                            r, c, lds, ldd, dst = p.shape[0], p.shape[1], p.stride(0), t.stride(0), t.data_ptr() + es * off
                             off += p.shape[0]
                         else:
-                            r, c, lds, ldd, dst = p.shape[0], p.shape[1], p.stride(0), t.stride(0), t.data_ptr() + 2 * off * t.stride(0)
+                            r, c, lds, ldd, dst = p.shape[0], p.shape[1], p.stride(0), t.stride(0), t.data_ptr() + es * off * t.stride(0)
                             off += p.shape[0]
                         tiles_c = (c + 63) // 64
                         buf += struct.pack("<QQqqiiiiii", p.data_ptr(), dst, lds, ldd, r, c, 1 if (transposed and p.dim() == 2) else 0, tile0, tiles_c, 0)
@@ -1101,6 +1103,28 @@ class ShadowCache:
             _lib.call("vlni_shadow_refresh", _DT[dt], tab[0].data_ptr(), tab[1], tab[2], _st())
             for key, e, _, ver, _ in lst:
                 self._c[key] = (ver,) + tuple(e[1:])
+        return True
+
+
+    def current_for_replay(self):
+        """For captured graphs that hold the copies' ADDRESSES (vln_imagine_amd/graphed.py): re-casts every stale refreshable copy in place and
+        says whether every cached copy is now current - False when one could only be rebuilt by a new allocation (the graphs are then dropped)."""
+        self._refresh_plain()
+        for key, e in self._c.items():
+            if e[2]:
+                continue                                   # aliases memory that is current by construction
+            p0 = e[4]()
+            if p0 is None:
+                continue
+            if len(e) > 5:
+                ps = [r() for r in e[5]]
+                if any(p is None for p in ps):
+                    continue
+                ver = (self.epoch, ps[0]._version, ps[0].data_ptr(), sum(p._version for p in ps[1:]))
+                if ver != e[0]:
+                    return False
+            elif (self.epoch, p0._version, p0.data_ptr()) != e[0][:3]:
+                return False
         return True
 
 
@@ -1395,6 +1419,8 @@ GRADS = GradArena()
 
 
 _TN_BEST = {}
+# 256 x 256 weight-gradient tiles: 6 = two 64-KiB stages, 7 = ring of 32-row half-steps, 8 = the ring with its wave rows one barrier apart (round 6)
+_RING_VARIANTS = (6, 7, 8) if os.environ.get("VLNI_TN_RING8", "1") == "1" else (6, 7)
 
 
 SMALL_TABLE_SCATTER = os.environ.get("VLNI_SMALL_SCATTER", "1") == "1"
@@ -1437,7 +1463,7 @@ def _tn_choice(n, pa, pb, pm, N, K, nmt, dev, dtid=BF16):
     if TN_BIG and N >= 256 and K >= 256 and nmt >= 32:
         t256 = ((N + 255) // 256) * ((K + 255) // 256)
         s6 = max(1, min(nmt // 4, round((252 - RESERVE_CUS) / t256)))
-        cands |= {(v, sp) for v in (6, 7) for sp in (s6, max(1, s6 // 2), max(1, (3 * s6) // 4), min(nmt // 4, 2 * s6))}
+        cands |= {(v, sp) for v in _RING_VARIANTS for sp in (s6, max(1, s6 // 2), max(1, (3 * s6) // 4), min(nmt // 4, 2 * s6))}
     smax = max(_eff_split(nmt, sp)[0] for _, sp in cands)
     scratch = torch.zeros((smax * (N * K + N),), dtype=torch.float32, device=dev)
     timed = []
@@ -1481,7 +1507,7 @@ def _tn_batch_choice(P, n, pa, pb, pm, N, K, nmt_p, dev, dtid):
         return best or default
     t128, t256 = -(-N // 128) * -(-K // 128), -(-N // 256) * -(-K // 256)
     cands = set()
-    for v, tiles in ((TN_VARIANT, t128),) + (((6, t256), (7, t256)) if TN_BIG and N >= 256 and K >= 256 else ()):
+    for v, tiles in ((TN_VARIANT, t128),) + (tuple((v_, t256) for v_ in _RING_VARIANTS) if TN_BIG and N >= 256 and K >= 256 else ()):
         want = max(1.0, ((512 if v == TN_VARIANT else 250) - (2 if v == TN_VARIANT else 1) * RESERVE_CUS) / (P * tiles))   # ~ one round of blocks
         near = sorted(divs, key=lambda d: abs(d - want))[:3]
         cands |= {(v, d) for d in near}
@@ -1760,6 +1786,9 @@ class GradSession:
                 n += (p.numel() + 7) // 8 * 8
         self.n, self.flat, self.queue = n, None, {}
         self.active, self.epoch, self.assigned, self.task = False, 0, [], -1
+        # vln_imagine_amd/graphed.py: `hold` keeps the session open across the nested autograd pass of a backward-graph capture, `recorder`
+        # collects the parameters that pass touches, `on_end` callbacks run once at the end of the agent's backward pass
+        self.hold, self.recorder, self.on_end = False, None, []
         ref = weakref.ref(self)
         for p in self.params:
             p._vlni_auto = self
@@ -1770,8 +1799,9 @@ class GradSession:
                     prm._vlni_touch = ses.epoch
             p.register_post_accumulate_grad_hook(touched)
 
-    def begin(self):
-        """First marked parameter met in a backward pass: gradients to accumulate into, the trainer's marks, the end-of-pass callback."""
+    def begin(self, register=True):
+        """First marked parameter met in a backward pass: gradients to accumulate into, the trainer's marks, the end-of-pass callback.
+        register=False (graphed.py, capturing a backward graph outside any backward pass): the caller closes the session with end(quiet=True)."""
         dev = self.params[0].device
         if self.flat is None or self.flat.device != dev:
             self.flat = torch.empty(self.n, dtype=torch.float32, device=dev)
@@ -1796,23 +1826,28 @@ class GradSession:
             ok = p.grad is not None and p.grad.dtype == torch.float32 and p.grad.is_contiguous()
             p._vlni_direct = p._vlni_defer = ok
         self.active, self.task = True, torch._C._current_graph_task_id()
-        torch.autograd.Variable._execution_engine.queue_callback(self.end)
+        if register:
+            torch.autograd.Variable._execution_engine.queue_callback(self.end)
 
-    def end(self):
-        """End of the backward pass: the queued weight gradients over all their calls, `None` back where nothing arrived, marks off."""
+    def end(self, quiet=False):
+        """End of the backward pass: the queued weight gradients over all their calls, `None` back where nothing arrived, marks off.
+        quiet=True: a session opened only to CAPTURE a backward graph - nothing ran, every gradient handed out goes back to None."""
         try:
             with torch.no_grad():
-                if self.queue:
+                if self.queue and not quiet:
                     flush_wgrads(queue=self.queue, store=set())
         finally:
             self.queue.clear()
             ep = self.epoch
             for p in self.assigned:
-                if getattr(p, "_vlni_touch", -1) != ep:
+                if quiet or getattr(p, "_vlni_touch", -1) != ep:
                     p.grad = None
             for p in self.params:
                 p._vlni_direct = p._vlni_defer = False
             self.assigned, self.active = [], False
+            cbs, self.on_end = self.on_end, []
+            for cb in cbs:
+                cb(self)
 
 
 def enable_auto_defer(module, on=True):
@@ -1843,7 +1878,7 @@ def _session(params):
     ses = getattr(p0, "_vlni_auto", None)
     if ses is None or not AUTO_DEFER:
         return None
-    if ses.active and ses.task != torch._C._current_graph_task_id():
+    if ses.active and ses.task != torch._C._current_graph_task_id() and not ses.hold:
         ses.queue.clear()                  # a backward pass that raised never reached its callback: drop what it left behind
         ses.end()
     if not ses.active:
@@ -1854,6 +1889,8 @@ def _session(params):
     for p in params:
         if p is not None:
             p._vlni_touch = ep
+    if ses.recorder is not None:
+        ses.recorder.extend(params)
     return ses
 
 
