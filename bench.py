@@ -901,32 +901,49 @@ def main():
     # agent_cmt.py:400-700,827-832 / agent.py:409-500 + agent_base.py:223-228). Host-bound: wall clock over whole iterations.
     if world == 1 and not forced and not args.no_extras and not shipped:
         import gc
-        from vln_imagine_amd import dropin
+        from vln_imagine_amd import dropin, graphed
         drop = {}
         for fam, bsz in ((("hamt", args.batch), ("duet", 32)) if (args.model == "hamt" and args.dtype == "bf16") else ((args.model, args.batch),)):
-            gc.collect()
-            torch.cuda.empty_cache()
-            wx = Workload(fam, args, False, dev, dtype, batch=bsz, tag=f"bench{rank}")
-            if args.train_mode:
-                wx.model.train()
-            tr = dropin.DropInTrainer((dropin.wrap_hamt if fam == "hamt" else dropin.wrap_duet)(wx.model, feat_dropout=0.4 if args.train_mode else 0.0),
-                                      wx.et, fam)
-            for _ in range(3):
-                tr.step()
-            torch.cuda.synchronize()
-            kx = 6
-            t0 = time.perf_counter()
-            for _ in range(kx):
-                loss_x = tr.step()
-            torch.cuda.synchronize()
-            sx = (time.perf_counter() - t0) / kx
-            log(f"drop-in eager ({fam}, batch {bsz}): {1e3 * sx:.2f} ms per iteration, loss {float(loss_x):.4f}")
-            drop[fam] = {"value": round(bsz / sx, 2), "unit": "episodes/s", "ms_per_step": round(1e3 * sx, 3), "batch": bsz, "iterations": kx,
-                         "step_algorithmic_tflops": round(wx.flops / sx / 1e12, 2)}
-            del tr, wx
-        drop["note"] = ("an unchanged reference agent on the drop-in modules: wrappers called eagerly per mode / step, plain autograd, clip_grad_norm_, "
-                        "torch.optim.AdamW (host-bound: every kernel is a Python -> C-ABI crossing; the optimizer's writes invalidate the 16-bit weight "
-                        "shadows each step); the headline needs the trainer of INTEGRATION.md section 4")
+            for per_call_graphs in (True, False):
+                # True = what the wrappers do by default since round 6 (vln_imagine_amd/graphed.py: one autograd node per wrapper call, replaying
+                # captured forward / backward graphs); False = the same agent code with VLNI_GRAPHED_MODES=0 (rounds 4-5: every kernel a Python ->
+                # C-ABI crossing, host-bound)
+                gc.collect()
+                torch.cuda.empty_cache()
+                was_g, graphed.ENABLED = graphed.ENABLED, per_call_graphs and graphed.ENABLED
+                try:
+                    wx = Workload(fam, args, False, dev, dtype, batch=bsz, tag=f"bench{rank}")
+                    if args.train_mode:
+                        wx.model.train()
+                    tr = dropin.DropInTrainer((dropin.wrap_hamt if fam == "hamt" else dropin.wrap_duet)(wx.model, feat_dropout=0.4 if args.train_mode else 0.0),
+                                              wx.et, fam)
+                    for _ in range(4):
+                        tr.step()
+                    torch.cuda.synchronize()
+                    kx = 8
+                    t0 = time.perf_counter()
+                    for _ in range(kx):
+                        loss_x = tr.step()
+                    torch.cuda.synchronize()
+                    sx = (time.perf_counter() - t0) / kx
+                    st_g = dict(graphed.of(wx.model).stats)
+                finally:
+                    graphed.ENABLED = was_g
+                    ops.set_seed_base(None)
+                log(f"drop-in ({fam}, batch {bsz}, per-call graphs {'on' if per_call_graphs else 'off'}): {1e3 * sx:.2f} ms per iteration, "
+                    f"loss {float(loss_x):.4f}, {st_g}")
+                e_ = {"value": round(bsz / sx, 2), "unit": "episodes/s", "ms_per_step": round(1e3 * sx, 3), "batch": bsz, "iterations": kx,
+                      "step_algorithmic_tflops": round(wx.flops / sx / 1e12, 2)}
+                if per_call_graphs:
+                    drop[fam] = dict(e_, wrapper_calls=st_g)
+                else:
+                    drop[fam]["without_per_call_graphs"] = e_
+                del tr, wx
+        drop["note"] = ("an unchanged reference agent on the drop-in modules (Seq2SeqCMTAgent / GMapNavAgent call pattern, vln_imagine_amd/dropin.py): wrappers "
+                        "called per mode / step, loss.backward(), clip_grad_norm_, torch.optim.AdamW. Round 6: each wrapper call is one autograd node that "
+                        "replays captured forward / backward graphs from its second sighting on (fixed shapes; ragged batches stay eager); "
+                        "`without_per_call_graphs` = VLNI_GRAPHED_MODES=0, the host-bound path of rounds 4-5. The headline needs the trainer of "
+                        "INTEGRATION.md section 4")
         extras["drop_in_eager"] = drop
 
     cpu = None

@@ -32,7 +32,7 @@ def pytest_terminal_summary(terminalreporter):
     tr.section("parity against the reference-made fixtures: max |error| per test (bounds: 1e-4 absolute; gradient entries 2e-4 relative)")
     worst = {}
     for tid, d in sorted(PARITY.items()):
-        tr.write_line(tid.split("::", 1)[-1] + "  " + "  ".join(f"{k} {v:.2e}" for k, v in sorted(d.items())))
+        tr.write_line(tid.split("/")[-1] + "  " + "  ".join(f"{k} {v:.2e}" for k, v in sorted(d.items())))
         for k, v in d.items():
             worst[k] = max(worst.get(k, 0.0), v)
     tr.write_line("WORST  " + "  ".join(f"{k} {v:.2e}" for k, v in sorted(worst.items())))

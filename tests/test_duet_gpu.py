@@ -26,7 +26,8 @@ def build_product(cfg, dtype=torch.float32):
 # The episode drivers, each against the reference's fixtures directly (see tests/test_hamt_gpu.py): stepwise = GMapNavAgent.rollout's call
 # pattern (agent.py:409-500 + one backward), taped = step-by-step forward on maps padded to the episode's largest + one episode-batched
 # backward (what bench.py --model duet times), time_batched = forward batched over time too, graph = the taped step captured and REPLAYED.
-DRIVERS = ("stepwise", "taped", "time_batched", "graph")
+# dropin = the same calls through the reference-facing VLNBert wrapper (models/model.py: what an unchanged GMapNavAgent.rollout talks to)
+DRIVERS = ("stepwise", "taped", "time_batched", "graph", "dropin")
 
 
 def run_driver(driver, model, et):
@@ -34,6 +35,11 @@ def run_driver(driver, model, et):
     kw = dict(criterion=ops.cross_entropy_sum)
     if driver == "stepwise":
         out = run_episode(model, et, **kw)
+        out["loss"].backward()
+        return out, None
+    if driver == "dropin":
+        from vln_imagine_amd import dropin
+        out = run_episode(dropin.wrap_duet(model, feat_dropout=0.0), et, **kw)
         out["loss"].backward()
         return out, None
     if driver == "time_batched":
@@ -65,7 +71,7 @@ def run_driver(driver, model, et):
 def test_product_fp32_matches_reference_golden(name, driver, golden_dir):
     g = np.load(os.path.join(golden_dir, f"duet_{name}.npz"))
     cfg, ep = duet_variant_setup(name)
-    if driver != "stepwise" and getattr(ep, "O", 0) > 0:
+    if driver not in ("stepwise", "dropin") and getattr(ep, "O", 0) > 0:
         pytest.skip("REVERIE object tokens: the padded-map drivers carry view tokens only (duet/episode.py:TapedEpisode)")
     model = build_product(cfg)
     tr = None

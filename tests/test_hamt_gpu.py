@@ -56,7 +56,8 @@ def _check_grads_against_golden(model, g):
 # stepwise HIP run). stepwise = the reference agent's own call pattern (T calls, one backward: r2r/agent_cmt.py:806-832); taped = step-by-step
 # forward into episode-wide buffers + ONE episode-batched backward (what bench.py times); time_batched = forward batched over time as well;
 # graph = the taped step captured by FlatTrainer.capture and REPLAYED (the program bench.py times, at lr = 0 so the weights stay put).
-DRIVERS = ("stepwise", "taped", "time_batched", "graph")
+# dropin = the reference agent's own call pattern through the VLNBertCMT wrapper (vln_imagine_amd/dropin.py: what an unchanged Seq2SeqCMTAgent gets)
+DRIVERS = ("stepwise", "taped", "time_batched", "graph", "dropin")
 # no_lang_ca hands a LIST of per-layer text states to `visual` (vilmodel_cmt.py:1022-1030): the batched drivers repeat one tensor over time
 _BATCHED_UNSUPPORTED = {"c1_no_lang_ca"}
 
@@ -73,6 +74,15 @@ def run_driver(driver, model, et, cfg, name):
     if driver == "time_batched":
         out = run_episode_time_batched(model, et, **kw)
         out["loss"].backward()
+        return out, None
+    if driver == "dropin":
+        from vln_imagine_amd import dropin
+        keep, akw = {}, {k: v for k, v in kw.items() if k != "criterion"}
+        loss, logits = dropin.hamt_agent_loss(dropin.wrap_hamt(model, feat_dropout=0.0), et, keep=keep, **akw)
+        loss.backward()
+        out = dict(keep, loss=loss, logits=logits)
+        if name in _BATCHED_UNSUPPORTED:
+            out.pop("states")                         # no_lang_ca: the wrapper's state is hist[CLS] alone (model_HAMT.py:84), the fixture holds txt * hist
         return out, None
     states = []
     on_step = lambda t, lg, st: states.append(st.clone())
@@ -104,7 +114,7 @@ def run_driver(driver, model, et, cfg, name):
 @pytest.mark.parametrize("name", list(HAMT_VARIANTS))
 def test_product_fp32_matches_reference_golden(name, driver, golden_dir):
     from vln_imagine_amd import ops
-    if driver != "stepwise" and name in _BATCHED_UNSUPPORTED:
+    if driver not in ("stepwise", "dropin") and name in _BATCHED_UNSUPPORTED:
         pytest.skip("no_lang_ca: `language` returns per-layer text states, which only the step-by-step driver feeds")
     g = np.load(os.path.join(golden_dir, f"hamt_{name}.npz"))
     cfg, ep = hamt_variant_setup(name)

@@ -39,14 +39,17 @@ def wrap_duet(model, feat_dropout=0.4):
     return w
 
 
-def hamt_agent_loss(w, et, train_ml=0.2, cosine_weight=0.5, use_aux=True):
-    """One teacher-forced rollout through the VLNBertCMT wrapper, the agent's own call sequence; returns (loss, per-step logits)."""
+def hamt_agent_loss(w, et, train_ml=0.2, cosine_weight=0.5, use_aux=True, bypass=True, use_imagine=True, keep=None):
+    """One teacher-forced rollout through the VLNBertCMT wrapper, the agent's own call sequence; returns (loss, per-step logits).
+    bypass / use_imagine: as hamt.episode.run_episode (agent_cmt.py:419-462 guards the imagination calls with args.imagine_enc_pano);
+    keep: a dict that receives what the golden tests compare (aux, states, history tokens, text / imagination embeddings)."""
     ep = et.ep
     B = et.B
     criterion = nn.CrossEntropyLoss(ignore_index=-100, reduction="sum")           # agent_cmt.py:105
     txt = w("language", txt_ids=et.txt_ids, txt_masks=et.txt_masks)
-    img = w("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=et.imagine_masks)
+    img = w("imagine", imagine_pano_img_feats=et.imagine_feats, imagine_masks=None if bypass else et.imagine_masks) if use_imagine else None
     aux = None
+    use_aux = use_aux and use_imagine
     if use_aux:
         aux, img = w("align_with_contrastive_loss", align_txt_embeds=txt, txt_masks=et.txt_masks, align_imagine_embeds=img,
                      imagine_masks=et.imagine_masks, sub_instr_segs=ep.sub_instr_segs, sub_instr_imag_flag=ep.sub_instr_imag_flag,
@@ -57,15 +60,20 @@ def hamt_agent_loss(w, et, train_ml=0.2, cosine_weight=0.5, use_aux=True):
     for t, s in enumerate(et.steps):
         lg, _states = w("visual", txt_embeds=txt, txt_masks=et.txt_masks, hist_embeds=hist, hist_lens=hist_lens,
                         ob_img_feats=s["ob_img_feats"], ob_ang_feats=s["ob_ang_feats"], ob_nav_types=s["ob_nav_types"], ob_masks=s["ob_masks"],
-                        return_states=True, imagine_embeds=img, imagine_masks=et.imagine_masks)
+                        return_states=True, imagine_embeds=img, imagine_masks=et.imagine_masks if use_imagine else None)
         ml_loss = ml_loss + criterion(lg.float(), s["target"])
         logits.append(lg)
         hist.append(w("history", hist_img_feats=s["hist_img_feats"], hist_ang_feats=s["hist_ang_feats"],
                       hist_pano_img_feats=s["hist_pano_img_feats"], hist_pano_ang_feats=s["hist_pano_ang_feats"], ob_step=t))
         hist_lens = [n + 1 for n in hist_lens]
+        if keep is not None:
+            keep.setdefault("states", []).append(_states)
+            keep.setdefault("hist", []).append(hist[-1])
     loss = ml_loss * train_ml / B                                                  # :746-752
     if use_aux and torch.is_tensor(aux):
         loss = loss + cosine_weight * aux
+    if keep is not None:
+        keep.update(aux=aux, txt_embeds=txt, imagine_embeds=img, hist_cls=hist[0])
     return loss, logits
 
 

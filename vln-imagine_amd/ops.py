@@ -1797,7 +1797,8 @@ class GradSession:
                 ses = ref()
                 if ses is not None:
                     prm._vlni_touch = ses.epoch
-            p.register_post_accumulate_grad_hook(touched)
+            if p.requires_grad:                      # (frozen parameters - the shipped fix_* configurations - never accumulate)
+                p.register_post_accumulate_grad_hook(touched)
 
     def begin(self, register=True):
         """First marked parameter met in a backward pass: gradients to accumulate into, the trainer's marks, the end-of-pass callback.
