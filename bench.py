@@ -46,6 +46,23 @@ def log(msg):
 # =====================================================================================================================
 #  N ranks from one command line
 # =====================================================================================================================
+def comm_self_check(dev, world, rank, local, device_name):
+    """What the COMMUNICATOR says about the job, measured through it: the sum of one 1 per rank (= how many ranks the collective really spans),
+    each rank's (rank, local rank, device) as gathered over it, and how many distinct devices those are."""
+    one = torch.ones(1, device=dev, dtype=torch.float32)
+    dist.all_reduce(one)
+    got = [None] * world
+    dist.all_gather_object(got, (rank, local, device_name))
+    return {"comm_size": int(round(float(one.item()))), "comm_ranks": sorted(got), "distinct_devices": len({g[2] for g in got})}
+
+
+def gather_floats(x, world, dev):
+    t = torch.tensor([float(x)], device=dev, dtype=torch.float64)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [round(float(o.item()), 3) for o in out]
+
+
 def launch_ranks(n):
     """Starts n copies of this command line as rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), waits, and returns
     the worst exit code. This parent makes no GPU call (a process that holds the device must not start others on these boxes);
@@ -287,8 +304,13 @@ def main():
         dist.init_process_group("gloo", rank=rank, world_size=world)
         seen = [None] * world
         dist.all_gather_object(seen, (rank, local))
+        chk = comm_self_check(torch.device("cpu"), world, rank, local, f"cpu:{local}")
+        per_rank = gather_floats(0.0, world, torch.device("cpu"))
         if rank == 0:
-            print(json.dumps({"n_gpus": world, "ranks": seen}), flush=True)
+            # the keys of the real line's config.rccl (tests/test_host_cpu.py asserts them): the first `--gpus 8` run checks itself
+            rccl = dict(chk, backend="gloo (dry run)", world_size=dist.get_world_size(), per_rank_ms_per_step=per_rank, allreduce_ms_exposed=None,
+                        ms_per_step_without_exchange=None, payload_bytes_per_step=None, payload_dtype=args.grad_comm, exchange=None)
+            print(json.dumps({"n_gpus": world, "ranks": seen, "config": {"rccl": rccl}}), flush=True)
         dist.destroy_process_group()
         return
     if not torch.cuda.is_available():
@@ -320,8 +342,13 @@ def main():
             sys.stdout.flush()
             os.dup2(keep_fd, 1)
             os.close(keep_fd)
+        props = torch.cuda.get_device_properties(dev)
+        dev_name = f"{socket.gethostname()}/{getattr(props, 'uuid', None) or getattr(props, 'pci_bus_id', local)}/{local}"
         rccl = {"backend": backend, "world_size": dist.get_world_size(),
                 "forced_single_rank": True if forced else None}
+        rccl.update(comm_self_check(dev, dist.get_world_size(), rank, local, dev_name))
+        if rccl["comm_size"] != world or rccl["distinct_devices"] != (1 if (forced or os.environ.get("VLNI_ONE_GPU")) else world):
+            raise SystemExit(f"bench.py: the communicator spans {rccl['comm_size']} ranks on {rccl['distinct_devices']} devices, --gpus says {world}")
 
     from vln_imagine_amd import ops
     from vln_imagine_amd.compare import compare_runs
@@ -423,7 +450,7 @@ def main():
             loss = step()
             marks[i_ + 1].record()
         fence()
-        dt = time.perf_counter() - t0
+        dt = dt_local = time.perf_counter() - t0
         per = sorted(marks[i_].elapsed_time(marks[i_ + 1]) for i_ in range(steps))
         median_ms[what] = round(per[len(per) // 2], 3)
         if world > 1:
@@ -437,6 +464,29 @@ def main():
             torch.cuda.synchronize()
             trainer.time_exchange = False
             rccl["exchange"] = trainer.exchange_report()
+            # self-checks of the first real multi-GPU line: every rank's own step time, and what the collective costs the
+            # step = timed step - the same pipeline (pack, side stream, unpack, graphs) with the all-reduce itself left out
+            rccl["per_rank_ms_per_step"] = gather_floats(1e3 * dt_local / steps, world, dev) if world > 1 \
+                else [round(1e3 * dt_local / steps, 3)]
+            trainer.skip_exchange = True
+            k2 = max(3, min(steps, 10))
+            step(); fence()
+            t1 = time.perf_counter()
+            for _ in range(k2):
+                step()
+            fence()
+            d2 = time.perf_counter() - t1
+            trainer.skip_exchange = False
+            if world > 1:
+                t2 = torch.tensor([d2], device=dev, dtype=torch.float64)
+                dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+                d2 = float(t2.item())
+            ex = rccl["exchange"] or {}
+            rccl["ms_per_step_without_exchange"] = round(1e3 * d2 / k2, 3)
+            rccl["allreduce_ms_exposed"] = round(1e3 * (dt / steps - d2 / k2), 3)
+            rccl["payload_bytes_per_step"] = sum(ex.get("payload_bytes_per_range", [])) or None
+            rccl["payload_dtype"] = ex.get("payload_dtype")
+            step()                                      # gradients of every rank agree again before anything else runs
         return dt / steps, launch, float(loss.detach()), eager
 
     if args.load_tune:

@@ -64,21 +64,18 @@ def test_fp32_full_depth_fwd_bwd_matches_cpu_oracle(family, B):
     assert r["params_compared"] > 100
 
 
-# bounds = 1.3 x the largest value this test has printed on MI355X over rounds 2 - 4 (loss: 2 x - it is a difference of two sums of B x T terms
-# and moves by an order of magnitude with the kernels the autotune happens to pick):   loss_abs, logit_max_abs, grad_rel_l2, worst single parameter
-# measured, round 4: hamt bf16 2.4e-6 / 0.0295 / 0.0858 / 0.184 (encoder.x_layers.1.lang_self_att.self.key.weight: a gradient that is small by
-# softmax shift invariance), duet bf16 3.3e-5 / 0.0196 / 0.0831 / 0.134; rounds 2 - 3: 2.3e-4 / 0.033 / 0.089 / 0.147 and 0.9 - 2.4e-4 / 0.0155 - 0.0195 / 0.083 - 0.085 / 0.127 - 0.134
-# round 5 (the taped + graph-replayed program; HAMT's history tokens of all steps from ONE batched call, i.e. other kernels per launch shape than the
-# float32 stepwise run's): hamt bf16 3.5e-4 / 0.0451 / 0.0937 / 0.149 - the logit bound follows (1.3 x 0.0451); the gradient figures did not move
-BF16_BOUNDS = {"hamt": (7e-4, 0.059, 0.122, 0.24), "duet": (5e-4, 0.026, 0.11, 0.175)}
-# float16 with the trainer's loss scale S = 2^14, round 4: 5.9e-5 / 0.0041 / 0.0281 / 0.050 and 4.5e-5 / 0.0025 / 0.0271 / 0.041 (round 3: 2.7e-5 / 0.0044 / 0.027 / 0.052; 4.6e-5 / 0.0025 / 0.027 / 0.046)
-# HAMT's worst single parameter after the attention forward moved to base-2 exponentials: 8.0e-5 / 0.0035 / 0.0278 / 0.0753, now on
-# encoder.x_layers.1.lang_self_att.self.query.weight (the same shift-invariant projection whose KEY weight is bfloat16's worst at 0.18); with the
-# previous forward kernel in the same build: 0.0289 / 0.048 on next_action.net.0.bias - every other figure moved by < 4 %, the whole gradient improved
-# DUET's worst single parameter after the GEMM kernels became one instantiation per epilogue kind (other fused-multiply-add contractions, other autotune
-# winners): 5.3e-5 / 0.0020 / 0.0298 / 0.0703 on global_encoder.sprel_linear.weight - ONE number, the sum of every attention-bias gradient of the
-# episode (it was 0.041 - 0.046 on other parameters; whole-gradient error unchanged)
-F16_BOUNDS = {"hamt": (1.2e-4, 0.0057, 0.037, 0.098), "duet": (1e-4, 0.0033, 0.039, 0.092)}
+# REQUIREMENTS, not 1.3 x the last measurement. profiles/r06_bf16_ablation.md: the 16-bit paths' distance from the float32
+# path is the storage format's rounding spread over every activation - no single spot (stored GELU', the language Q / K / V reduced once, the taped
+# against the stepwise program, the batch) moves the bf16 gradient error by more than 0.004, float16 on the SAME kernels is 2.8 x closer
+# (8 against 11 significand bits), and 300 optimizer steps in bf16 / fp16 / fp32 reach the same loss. So the bound is the format's own yardstick:
+#   gradient rel-L2 <= 0.112 for bf16 = what plain PyTorch gives with torch.autocast(bfloat16) on the CPU oracle at this depth,
+#   a quarter of it (two more... three more significand bits = 8 x finer, sqrt-summed over the path) <= 0.04 for float16;
+#   worst single parameter <= 0.25 / 0.10 (gradients that are small by softmax shift invariance sit there);
+#   logits <= 2^-4 / 2^-7 (half an ulp of a 16-bit value of magnitude 16 / of a float16 value of magnitude 8), loss <= 1e-3 / 2.5e-4.
+# Measured, rounds 2 - 6 (loss, logits, gradient, worst parameter): hamt bf16 2.4e-6 ... 3.5e-4 / 0.030 - 0.045 / 0.086 - 0.094 / 0.15 - 0.18, duet bf16
+# 3.3e-5 ... 2.4e-4 / 0.016 - 0.020 / 0.083 - 0.085 / 0.13; float16 (loss scale 2^14) 2.7e-5 ... 8e-5 / 0.0020 - 0.0044 / 0.027 - 0.030 / 0.041 - 0.075.
+BF16_BOUNDS = {"hamt": (1e-3, 0.0625, 0.112, 0.25), "duet": (1e-3, 0.0625, 0.112, 0.25)}
+F16_BOUNDS = {"hamt": (2.5e-4, 0.0078125, 0.04, 0.10), "duet": (2.5e-4, 0.0078125, 0.04, 0.10)}
 
 
 @pytest.mark.parametrize("family,B,low", [("hamt", 64, torch.bfloat16), ("duet", 32, torch.bfloat16), ("hamt", 64, torch.float16),

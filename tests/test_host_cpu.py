@@ -286,7 +286,7 @@ def test_bench_starts_its_own_ranks():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line == {"n_gpus": 2, "ranks": [[0, 0], [1, 1]]}
+    assert line["n_gpus"] == 2 and line["ranks"] == [[0, 0], [1, 1]] and line["config"]["rccl"]["comm_size"] == 2, line
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=dict(env, WORLD_SIZE="2", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
@@ -305,12 +305,19 @@ def test_bench_eight_rank_launch_paths_dry_run():
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["n_gpus"] == 8 and sorted(map(tuple, line["ranks"])) == [(i, i) for i in range(8)], line
+        # the self-checks the first real 8-GPU line carries in config.rccl: the communicator's own size (a sum of ones
+        # over it), the ranks and devices as gathered through it, every rank's step time, the cost of the exchange, its bytes and payload type
+        rc = line["config"]["rccl"]
+        assert rc["comm_size"] == 8 and rc["distinct_devices"] == 8 and [r_[:2] for r_ in rc["comm_ranks"]] == [[i, i] for i in range(8)], rc
+        assert len(rc["per_rank_ms_per_step"]) == 8
+        for key in ("allreduce_ms_exposed", "ms_per_step_without_exchange", "payload_bytes_per_step", "payload_dtype", "exchange", "world_size", "backend"):
+            assert key in rc, key
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
                        env=dict(env, VLNI_BENCH_DRY_RUN="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert line == {"n_gpus": 2, "ranks": [[0, 0], [1, 1]]}
+    assert line["n_gpus"] == 2 and line["ranks"] == [[0, 0], [1, 1]] and line["config"]["rccl"]["comm_size"] == 2, line
 
 
 def test_duet_static_episode_buffers_hold_the_padded_episode():

@@ -535,8 +535,9 @@ def test_reduce_parts_modes_and_spread_sum_of_squares(ops):
 
 def test_stale_weight_copies_are_recast_in_one_launch(ops):
     """ShadowCache._refresh_plain / vlni_shadow_refresh: after an in-place update of plain float32 parameters (what torch.optim's step is to the
-    cache) every cached 16-bit copy - single, row-packed Q | K | V, transposed, bias vectors - is rewritten in place by ONE launch and equals a
-    fresh cast; the tensors handed out before stay the same objects."""
+    cache) every cached copy - single, row-packed Q | K | V, transposed, bias vectors, and (round 6) the float32 row-pack of the Q | K | V biases
+    that the GEMM epilogue reads - is rewritten in place by ONE launch per destination type and equals a fresh cast; the tensors handed out
+    before stay the same objects (captured graphs hold their addresses, vln_imagine_amd/graphed.py)."""
     torch.manual_seed(3)
     mkp = lambda *s: torch.nn.Parameter(torch.randn(*s, device="cuda"))
     q, k, v, o = mkp(768, 768), mkp(768, 768), mkp(768, 768), mkp(768, 3072)
@@ -545,9 +546,10 @@ def test_stale_weight_copies_are_recast_in_one_launch(ops):
     was = ops.BATCH_SHADOWS
     ops.BATCH_SHADOWS = True
     calls, real = [], ops._lib.call
+    ops.SHADOWS._c.clear()                     # (copies of other tests' parameters would be refreshed by the same launches)
     try:
         get = lambda: (ops.SHADOWS.get((q, k, v), dt), ops.SHADOWS.get((q, k, v), dt, True), ops.SHADOWS.get((o,), dt), ops.SHADOWS.get((o,), dt, True),
-                       ops.SHADOWS.get((bq, bk, bv), dt))
+                       ops.SHADOWS.get((bq, bk, bv), dt), ops.SHADOWS.get((bq, bk, bv), torch.float32))
         first = get()
         with torch.no_grad():
             for p in (q, k, v, o, bq, bk, bv):
@@ -557,12 +559,14 @@ def test_stale_weight_copies_are_recast_in_one_launch(ops):
     finally:
         ops._lib.call = real
         ops.BATCH_SHADOWS = was
-    assert calls.count("vlni_shadow_refresh") == 1 and not any(c in ("vlni_cast", "vlni_transpose") for c in calls), calls
+    assert calls.count("vlni_shadow_refresh") == 2 and not any(c in ("vlni_cast", "vlni_transpose") for c in calls), calls      # bf16 + float32
     assert all(a is b for a, b in zip(first, second))
     W = torch.cat([q, k, v], 0).detach()
     assert torch.equal(second[0], W.to(dt)) and torch.equal(second[1], W.to(dt).t().contiguous())
     assert torch.equal(second[2], o.detach().to(dt)) and torch.equal(second[3], o.detach().to(dt).t().contiguous())
     assert torch.equal(second[4], torch.cat([bq, bk, bv]).detach().to(dt))
+    assert second[5].dtype == torch.float32 and torch.equal(second[5], torch.cat([bq, bk, bv]).detach())
+    assert ops.SHADOWS.current_for_replay()
 
 
 def test_small_ops(ops):

@@ -239,6 +239,7 @@ class FlatTrainer:
         self.overlap_chunks = max(1, int(overlap_chunks))
         self._side = None
         self.time_exchange = False          # True: allreduce_grads records HIP events for exchange_report()
+        self.skip_exchange = False          # True: the pipeline runs without the collective itself (what the exchange costs = step - this)
         self.graph_epoch = 0
         # compute-dtype mirror of the parameter arena, kept current by the AdamW kernel (ops.ShadowCache hands out views of it):
         # bfloat16, or float16 when the model computes in float16 (then pair it with loss_scale / growth_interval)
@@ -324,6 +325,8 @@ class FlatTrainer:
         return cut_ranges(self._units, self.n, self.overlap_chunks)
 
     def _reduce_range(self, lo, hi, ws):
+        if self.skip_exchange:              # measurement only (bench.py `allreduce_ms_exposed`): the step without its collective - every rank keeps its
+            return                          # own gradients; never set in training
         reduce_range_(self.flat_g, lo, hi, ws, self.chunk, self.grad_comm_dtype)
 
     def allreduce_grads(self, flushers=None):
