@@ -22,6 +22,7 @@ shipped freeze, at T = 1, in fp16 and in fp32. Default = the reference's trainin
 """
 import argparse
 import json
+import socket
 import os
 import subprocess
 import sys

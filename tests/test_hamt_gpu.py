@@ -58,8 +58,9 @@ def _check_grads_against_golden(model, g):
 # graph = the taped step captured by FlatTrainer.capture and REPLAYED (the program bench.py times, at lr = 0 so the weights stay put).
 # dropin = the reference agent's own call pattern through the VLNBertCMT wrapper (vln_imagine_amd/dropin.py: what an unchanged Seq2SeqCMTAgent gets)
 DRIVERS = ("stepwise", "taped", "time_batched", "graph", "dropin")
-# no_lang_ca hands a LIST of per-layer text states to `visual` (vilmodel_cmt.py:1022-1030): the batched drivers repeat one tensor over time
-_BATCHED_UNSUPPORTED = {"c1_no_lang_ca"}
+# no_lang_ca hands a LIST of per-layer text states to `visual` (vilmodel_cmt.py:1022-1030): round 6 - the batched drivers repeat every entry over time
+_BATCHED_UNSUPPORTED = set()
+_NO_LANG_CA = {"c1_no_lang_ca"}
 
 
 def run_driver(driver, model, et, cfg, name):
@@ -81,7 +82,7 @@ def run_driver(driver, model, et, cfg, name):
         loss, logits = dropin.hamt_agent_loss(dropin.wrap_hamt(model, feat_dropout=0.0), et, keep=keep, **akw)
         loss.backward()
         out = dict(keep, loss=loss, logits=logits)
-        if name in _BATCHED_UNSUPPORTED:
+        if name in _NO_LANG_CA:
             out.pop("states")                         # no_lang_ca: the wrapper's state is hist[CLS] alone (model_HAMT.py:84), the fixture holds txt * hist
         return out, None
     states = []

@@ -111,7 +111,7 @@ def _taped_inputs(et):
         return hit
     import numpy as np
     ep, B, T, dev = et.ep, et.B, et.T, et.device
-    assert all("obj_img_fts" not in s for s in et.steps), "the DUET episode tape covers R2R-style episodes (no object tokens)"
+    has_obj = "obj_img_fts" in et.steps[0]             # REVERIE / SOON: object tokens behind each sample's views (reverie/agent_obj.py:52-107, 381-384)
     Gs = [s["gmap_masks"].shape[1] for s in et.steps]
     Gmax, P = max(Gs), et.pano_widths[0]
     assert all(w == P for w in et.pano_widths)
@@ -128,9 +128,13 @@ def _taped_inputs(et):
         pdp = pd.new_zeros((B, Gmax, Gmax))
         pdp[:, :G, :G] = pd
         ones = torch.ones(B, 1, dtype=torch.bool, device=dev)
-        plen = s["view_lens"]
+        plen = s["view_lens"] + s["obj_lens"] if has_obj else s["view_lens"]      # tokens of the panorama: views (+ objects)
+        extra = {}
+        if has_obj:
+            extra = dict(obj_img_fts=s["obj_img_fts"], obj_lens=s["obj_lens"], obj_target=s["obj_target"], pano_lens=plen.contiguous(),
+                         vp_obj_masks=torch.cat([~ones, s["nav_types"] == 2], 1))                  # agent_obj.py:150-152
         steps.append(dict(
-            view_img_fts=s["view_img_fts"], loc_fts=s["loc_fts"], nav_types=s["nav_types"], view_lens=plen,
+            extra, view_img_fts=s["view_img_fts"], loc_fts=s["loc_fts"], nav_types=s["nav_types"], view_lens=s["view_lens"],
             gmap_step_ids=pad2(s["gmap_step_ids"], G), gmap_pos_fts=pad2(s["gmap_pos_fts"], G), gmap_masks=pad2(s["gmap_masks"], G),
             gmap_pair_dists=pdp, gmap_visited_masks=pad2(s["gmap_visited_masks"], G),
             gmap_vpids=[list(v) + [None] * (Gmax - len(v)) for v in s["gmap_vpids"]],
@@ -140,7 +144,8 @@ def _taped_inputs(et):
     idx = torch.from_numpy(off).to(dev)                                                  # rows of the flattened [T * B * (P + 1) + 1, H] bank
     cat = lambda k: torch.cat([st[k] for st in steps], 0).contiguous()
     full = {k: cat(k) for k in ("view_img_fts", "loc_fts", "nav_types", "view_lens", "gmap_step_ids", "gmap_pos_fts", "gmap_masks",
-                                "gmap_pair_dists", "gmap_visited_masks", "vp_pos_fts", "vp_masks", "vp_nav_masks", "pano_masks", "target")}
+                                "gmap_pair_dists", "gmap_visited_masks", "vp_pos_fts", "vp_masks", "vp_nav_masks", "pano_masks", "target")
+            + (("obj_img_fts", "obj_lens", "obj_target", "pano_lens", "vp_obj_masks") if has_obj else ())}
     full["gmap_vpids"] = [v for st in steps for v in st["gmap_vpids"]]
     full["vp_cand_vpids"] = [v for st in steps for v in st["vp_cand_vpids"]]
     et._taped = (steps, full, idx, Gmax, P, ZERO)
@@ -152,7 +157,7 @@ def _nav_batch(st, gmap_img, vp_img, kvg, kvl, mask):
             "gmap_step_ids": st["gmap_step_ids"], "gmap_pos_fts": st["gmap_pos_fts"], "gmap_masks": st["gmap_masks"],
             "gmap_pair_dists": st["gmap_pair_dists"], "gmap_visited_masks": st["gmap_visited_masks"], "gmap_vpids": st["gmap_vpids"],
             "vp_img_embeds": vp_img, "vp_pos_fts": st["vp_pos_fts"], "vp_masks": st["vp_masks"], "vp_nav_masks": st["vp_nav_masks"],
-            "vp_obj_masks": None, "vp_cand_vpids": st["vp_cand_vpids"], "imagine_embeds": None, "imagine_masks": None,
+            "vp_obj_masks": st.get("vp_obj_masks"), "vp_cand_vpids": st["vp_cand_vpids"], "imagine_embeds": None, "imagine_masks": None,
             "fuse_plan": st.get("fuse_plan"), "masks_add": st.get("masks_add")}
 
 
@@ -196,12 +201,20 @@ class TapedEpisode:
         img = model("imagine", {"imagine_feats": et.imagine_feats, "imagine_masks": et.imagine_masks})
         self.aux = None
         if self.use_aux:
-            self.aux, img = model("align_with_contrastive_loss", {
-                "align_txt_embeds": self.txt, "txt_masks": et.txt_masks, "align_imagine_embeds": img, "imagine_masks": et.imagine_masks,
-                "obs_instr_ids": [f"i{b}" for b in range(B)], "sub_instr_segs": ep.sub_instr_segs,
-                "sub_instr_imag_flag": ep.sub_instr_imag_flag, "noun_phrase_segs": ep.noun_phrase_segs})
+            batch = {"align_txt_embeds": self.txt, "txt_masks": et.txt_masks, "align_imagine_embeds": img, "imagine_masks": et.imagine_masks,
+                     "obs_instr_ids": [f"i{b}" for b in range(B)]}
+            if getattr(ep, "O", 0) == 0:             # REVERIE aligns with the whole instruction: no sub-instruction annotations (run_episode)
+                batch.update(sub_instr_segs=ep.sub_instr_segs, sub_instr_imag_flag=ep.sub_instr_imag_flag, noun_phrase_segs=ep.noun_phrase_segs)
+            self.aux, img = model("align_with_contrastive_loss", batch)
         self.img = img
         self.kv_g, self.kv_l, self.lm = model.project_text(self.txt, et.txt_masks, img, et.imagine_masks)   # once per episode, with autograd
+
+    def _pano_batch(self, st):
+        """Arguments of a `panorama` call on the step inputs `st` (one step's, or all T x B samples'): views, object tokens where the episode
+        has them (each sample's objects follow its views: one row gather inside the model, vilmodel.py:1096-1114)."""
+        return {"view_img_fts": self._drop(st["view_img_fts"]), "obj_img_fts": self._drop(st["obj_img_fts"]) if "obj_img_fts" in st else None,
+                "loc_fts": st["loc_fts"], "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": st.get("obj_lens"),
+                "pano_masks": st["pano_masks"]}
 
     def begin(self):
         et, tape, B, T = self.et, self.tape, self.B, self.T
@@ -225,12 +238,10 @@ class TapedEpisode:
             self.full = full = dict(full, masks_add=(gm_all, vm_all))
             self.steps = [dict(st, masks_add=(gm_all[t * B:(t + 1) * B], vm_all[t * B:(t + 1) * B])) for t, st in enumerate(self.steps)]
             with tape.record_steps("panorama", T):               # the call the ghost pass repeats (_batched)
-                pano_all, _ = model("panorama", {"view_img_fts": self._drop(full["view_img_fts"]), "obj_img_fts": None, "loc_fts": full["loc_fts"],
-                                                 "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None,
-                                                 "pano_masks": full["pano_masks"]})
+                pano_all, _ = model("panorama", self._pano_batch(full))
             with torch.no_grad():
                 pano4 = pano_all.view(T, B, P, H)
-                self.bank4[:, :, 0] = ops.seq_mean(pano_all, full["view_lens"]).view(T, B, H)     # masked mean, agent.py:468-469
+                self.bank4[:, :, 0] = ops.seq_mean(pano_all, full.get("pano_lens", full["view_lens"])).view(T, B, H)     # masked mean, agent.py:468-469
                 self.bank4[:, :, 1:] = pano4
                 self.vpbuf[:, :, 1:] = pano4
 
@@ -239,12 +250,10 @@ class TapedEpisode:
         model, tape, B, st = self.model, self.tape, self.B, self.steps[t]
         if not self.upfront:
             with tape.record("panorama", t):
-                pano, pmask = model("panorama", {"view_img_fts": self._drop(st["view_img_fts"]), "obj_img_fts": None, "loc_fts": st["loc_fts"],
-                                                 "nav_types": st["nav_types"], "view_lens": st["view_lens"], "obj_lens": None,
-                                                 "pano_masks": st["pano_masks"]})
+                pano, pmask = model("panorama", self._pano_batch(st))
         with torch.no_grad():
             if not self.upfront:
-                self.bank4[t, :, 0] = ops.seq_mean(pano, st["view_lens"])             # masked mean, agent.py:468-469
+                self.bank4[t, :, 0] = ops.seq_mean(pano, st.get("pano_lens", st["view_lens"]))             # masked mean, agent.py:468-469
                 self.bank4[t, :, 1:] = pano
                 self.vpbuf[t][:, 1:] = pano
             gmap_img = self.bank.index_select(0, self.idx[t].reshape(-1)).view(B, self.Gmax, -1)
@@ -261,10 +270,8 @@ class TapedEpisode:
         kv_g, kv_l, lm = self.kv_g, self.kv_l, self.lm
         H = self.txt.shape[-1]
         with ctx_pano:
-            pano_all, pmask_all = model("panorama", {"view_img_fts": self._drop(full["view_img_fts"]), "obj_img_fts": None, "loc_fts": full["loc_fts"],
-                                                     "nav_types": full["nav_types"], "view_lens": full["view_lens"], "obj_lens": None,
-                                                     "pano_masks": full["pano_masks"]})
-        avg_all = ops.seq_mean(pano_all, full["view_lens"])                                     # [T * B, H]
+            pano_all, pmask_all = model("panorama", self._pano_batch(full))
+        avg_all = ops.seq_mean(pano_all, full.get("pano_lens", full["view_lens"]))              # [T * B, H]
         rows = F.pad(torch.cat([avg_all.unsqueeze(1), pano_all], 1).reshape(ZERO, H), (0, 0, 0, 1))   # the full bank, with autograd
         gmap_all = rows.index_select(0, self.idx.reshape(-1)).view(T * B, Gmax, H)              # step t's nodes only point at steps <= t
         vp_all = F.pad(pano_all, (0, 0, 1, 0))
@@ -275,12 +282,17 @@ class TapedEpisode:
             nav = model("navigation", _nav_batch(full, gmap_all, vp_all, [repkv(k) for k in kv_g], [repkv(k) for k in kv_l], rep(lm)))
         ml_loss = self.criterion(nav["fused_logits"], full["target"])
         loss = ml_loss * self.train_ml / B
+        Tn = lambda x: list(x.view((T, B) + tuple(x.shape[1:])))
+        og = {}
+        if "obj_target" in full:                                                                # object grounding CE, agent_obj.py:461-463, 544-546
+            og_loss = self.criterion(nav["obj_logits"], full["obj_target"])
+            loss = loss + og_loss * self.train_ml / B
+            og = {"og_loss": og_loss, "obj": Tn(nav["obj_logits"])}
         if self.use_aux and torch.is_tensor(self.aux):
             loss = loss + self.cosine_weight * self.aux
-        Tn = lambda x: list(x.view((T, B) + tuple(x.shape[1:])))
-        return {"loss": loss, "ml_loss": ml_loss, "aux": self.aux, "fused": Tn(nav["fused_logits"]), "global": Tn(nav["global_logits"]),
-                "local": Tn(nav["local_logits"]), "pano": Tn(pano_all), "step_logits": self.step_logits, "txt_embeds": self.txt,
-                "imagine_embeds": self.img, "tape": self.tape, "gmax": Gmax}
+        return dict(og, loss=loss, ml_loss=ml_loss, aux=self.aux, fused=Tn(nav["fused_logits"]), **{"global": Tn(nav["global_logits"])},
+                    local=Tn(nav["local_logits"]), pano=Tn(pano_all), step_logits=self.step_logits, txt_embeds=self.txt,
+                    imagine_embeds=self.img, tape=self.tape, gmax=Gmax)
 
     def finish(self):
         return self._batched(self.tape.ghost("panorama", compute=self.ghost_compute), self.tape.ghost("navigation", compute=self.ghost_compute))

@@ -229,6 +229,7 @@ class ModeGraphs:
         self.static_ptrs = set()
         self.seed_base = None
         self.anchor = None
+        self._ids = None
         self.stream, self.depth = None, 0
         self.epoch = -1               # the gradient session's epoch at the last call: a backward pass in between starts a new iteration
         self.capturing = False        # inside a forward capture (model code that shares per-episode state between calls builds its own copy then)
@@ -270,7 +271,7 @@ class ModeGraphs:
             self.counts.clear()
             if self.seed_base is not None:
                 self.seed_base.add_(1)
-            if self.entries and not ops.SHADOWS.current_for_replay():
+            if self.entries and not ops.SHADOWS.current_for_replay(self.param_ids(ses)):
                 self.reset()
         sig = (mode, consts, tuple((tuple(t.shape), t.dtype, t.requires_grad) for t in tensors))
         k = self.counts.get(sig, 0)
@@ -308,6 +309,11 @@ class ModeGraphs:
             self.anchor = torch.zeros(1, device=tensors[0].device, requires_grad=True)   # makes the node differentiable when no INPUT needs a gradient
         outs = _Call.apply(e, self.anchor, *tensors)
         return outs if len(outs) > 1 else outs[0]
+
+    def param_ids(self, ses):
+        if self._ids is None or self._ids[0] != len(ses.params):
+            self._ids = (len(ses.params), {id(p) for p in ses.params})
+        return self._ids[1]
 
     def _grads_in_place(self, ses):
         """The backward graphs accumulate into the session's flat buffer at fixed addresses: every parameter's .grad must be absent (the session

@@ -181,7 +181,8 @@ def run_episode_time_batched(model, et, bypass=True, use_aux=True, train_ml=0.2,
     hist = prefix.permute(1, 0, 2).unsqueeze(0).expand(T, B, T, H).reshape(T * B, T, H)
     hist_masks = (torch.arange(T, device=dev)[None, :] <= torch.arange(T, device=dev)[:, None])    # [t, entry]
     hist_masks = hist_masks.unsqueeze(1).expand(T, B, T).reshape(T * B, T)
-    rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+    rep1 = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+    rep = lambda x: [rep1(v) for v in x] if isinstance(x, list) else rep1(x)          # no_lang_ca: `language` returns the per-layer text states (:1022-1030)
     kw = {}
     if hasattr(model, "language_side") and not isinstance(txt, list):      # product model: the episode's language side built once (see TapedEpisode)
         kw["lang_side"] = model.language_side(txt, et.txt_masks, img, im_masks).repeat(T)
@@ -428,7 +429,8 @@ class TapedEpisode:
             hist = prefix.permute(1, 0, 2).unsqueeze(0).expand(T, B, T, H)
         else:
             hist = prefix.permute(1, 0, 2).unsqueeze(0) * valid.to(h_all.dtype)[:, :, :, None]        # zeros beyond the valid entries
-        rep = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+        rep1 = lambda x: x.unsqueeze(0).expand((T,) + tuple(x.shape)).reshape((T * x.shape[0],) + tuple(x.shape[1:]))
+        rep = lambda x: [rep1(v) for v in x] if isinstance(x, list) else rep1(x)      # no_lang_ca: the per-layer text states (vilmodel_cmt.py:1022-1030)
         if self.ls is not None and getattr(getattr(model, "config", None), "concat_imagine_with", None) == "language":
             rep = lambda x: x          # the language side is handed over ready-made (lang_side=): `visual` only checks these for presence
         with tape.ghost("visual", compute=self.ghost_compute):

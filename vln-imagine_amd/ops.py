@@ -1106,15 +1106,16 @@ class ShadowCache:
         return True
 
 
-    def current_for_replay(self):
+    def current_for_replay(self, ids=None):
         """For captured graphs that hold the copies' ADDRESSES (vln_imagine_amd/graphed.py): re-casts every stale refreshable copy in place and
-        says whether every cached copy is now current - False when one could only be rebuilt by a new allocation (the graphs are then dropped)."""
+        says whether every cached copy (of the parameters whose id() is in `ids`; None = all) is now current - False when one could only be
+        rebuilt by a new allocation (the graphs are then dropped)."""
         self._refresh_plain()
         for key, e in self._c.items():
             if e[2]:
                 continue                                   # aliases memory that is current by construction
             p0 = e[4]()
-            if p0 is None:
+            if p0 is None or (ids is not None and id(p0) not in ids):
                 continue
             if len(e) > 5:
                 ps = [r() for r in e[5]]
