@@ -685,7 +685,7 @@ def main():
             per_shape.append({"M": m_, "N": n_, "K": k_, "kind": kind, "launches": cnt, "us": round(ms_ / cnt * 1e3, 1), "tflops": round(f / ms_ / 1e9, 1),
                               "mfma_us": round(mfma_us, 1), "hbm_us": round(hbm_us, 1), "bound": "hbm" if hbm_us > mfma_us else "mfma",
                               "frac_of_floor": round(max(mfma_us, hbm_us) / (ms_ / cnt * 1e3), 3)})
-        if os.environ.get("VLNI_GEMM_SHAPES_OUT"):           # tools/gemm_shapes.py replays these shapes beside the vendor library
+        if os.environ.get("VLNI_GEMM_SHAPES_OUT") and with_ceiling:     # (the line's own workload, not the DUET extra) tools/gemm_shapes.py replays these shapes beside the vendor library
             json.dump(per_shape, open(os.environ["VLNI_GEMM_SHAPES_OUT"], "w"), indent=1)
         def fam_sum(prefixes):
             sel = [f_ for f_ in fam if f_[0].startswith(prefixes)]
@@ -713,6 +713,9 @@ def main():
                 "hbm_bound_launches": sum(x["launches"] for x in per_shape if x["bound"] == "hbm"),
                 "bound_per_shape": per_shape[:12], "traffic": traffic,
                 "traffic_source": traffic_src, "traffic_ratio": round(traffic / (alg / len(rec)), 3) if traffic else None,
+                # the same against A + B + C + what the fused epilogues read / write besides C; the rest is the weight panel fetched once per XCD's
+                # L2 (8 copies from the Infinity Cache: profiles/r06_gemm_traffic.md)
+                "traffic_ratio_with_epilogue_operands": round(traffic / ((alg + epi[0]) / len(rec)), 3) if traffic else None,
                 "algorithmic_bytes_per_launch": round(alg / len(rec)),
                 "algorithmic_bytes_per_launch_with_epilogue": round((alg + epi[0]) / len(rec)),
                 "launches_per_step": len(rec), "avg_launch_us": round(tot_ms * 1e3 / len(rec), 2),

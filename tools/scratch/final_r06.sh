@@ -35,6 +35,8 @@ rocprofv3 --kernel-trace --output-format csv -d $O/trace_shapes_$f -o t -- pytho
 done
 python3 tools/gemm_shapes.py report $O/shapes_run_hamt.json $O/trace_shapes_hamt "Forward / dgrad GEMM launches of one HAMT step (BASELINE.json configs[1]) by shape, beside the vendor library (r06)" > $O/r06_gemm_shapes.md
 python3 tools/gemm_shapes.py report $O/shapes_run_duet.json $O/trace_shapes_duet "Forward / dgrad GEMM launches of one DUET step (BASELINE.json configs[3]) by shape, beside the vendor library (r06)" > $O/r06_duet_gemm_shapes.md
+python3 tools/gemm_traffic.py $O/shapes_run_hamt.json profiles/r06_pmc_traffic.json "Fabric traffic of the forward / dgrad GEMM family, HAMT step (r06)" > $O/r06_gemm_traffic.md
+python3 tools/gemm_traffic.py $O/shapes_run_duet.json profiles/r06_duet_pmc_traffic.json "Fabric traffic of the forward / dgrad GEMM family, DUET step (r06)" > $O/r06_duet_gemm_traffic.md
 echo "shapes done"
 VLNI_FORCE_COLLECTIVES=1 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-parity --no-roofline > $O/bench_forced_rccl.json 2> $O/bench_forced_rccl.err
 cp profiles/r06* $O/ 2>/dev/null || true
