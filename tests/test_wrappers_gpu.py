@@ -384,3 +384,54 @@ def test_graphed_wrapper_calls_draw_new_dropout_masks_every_iteration():
     # replayed iterations 3 and 4 (both from the same graphs): logits differ by more than an optimizer step of 2e-5 would move them
     d = max((a - b)[torch.isfinite(a)].abs().max().item() for a, b in zip(got[3][1], got[4][1]))
     assert d > 1e-3, d
+
+
+def test_graphed_wrapper_calls_two_rollouts_one_backward_and_state_gradients():
+    """The HAMT agent's training iteration is TWO rollouts (teacher-forced, then sampled) and ONE backward of the summed loss (agent_cmt.py:809-832), and its
+    critic differentiates the returned states (:700-745): the k-th `visual` call of the second rollout is occurrence T + k of its signature (its own graphs and
+    buffers), and an output that carries a gradient only sometimes (states) is served from the same backward graph (zero-filled when absent)."""
+    from tests.golden.variants import HAMT_C1
+    from tests.test_hamt_gpu import build_product
+    from vln_imagine_amd import dropin, graphed, ops, synth
+    from vln_imagine_amd.hamt.config import HamtConfig
+    from vln_imagine_amd.hamt.episode import EpisodeTensors
+    cfg = HamtConfig(**HAMT_C1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, pred_head_dropout_prob=0.0)
+    et = EpisodeTensors(synth.HamtEpisode(tag="two", B=8, L=80, V=37, I=4, T=2, ragged=True), "cuda")
+
+    def program(on):
+        was = graphed.ENABLED
+        graphed.ENABLED = on
+        try:
+            ops.reseed(3)
+            torch.manual_seed(5)
+            m = build_product(cfg, torch.bfloat16).train()
+            w = dropin.wrap_hamt(m, feat_dropout=0.0)
+            out = []
+            for it in range(4):
+                for p in m.parameters():
+                    p.grad = None
+                k1, k2 = {}, {}
+                l1, _ = dropin.hamt_agent_loss(w, et, keep=k1)
+                l2, _ = dropin.hamt_agent_loss(w, et, use_aux=False, keep=k2)
+                loss = l1 + 0.5 * l2
+                if it % 2 == 1:                                        # every other iteration the critic's term: the states carry a gradient
+                    loss = loss + 1e-2 * sum((s.float() ** 2).mean() for s in k2["states"])
+                loss.backward()
+                out.append((float(loss.detach()), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}))
+                with torch.no_grad():
+                    for i, p in enumerate(m.parameters()):
+                        p.mul_(1.0 + 1e-3 * ((i % 5) - 2))
+            return out, dict(graphed.of(m).stats)
+        finally:
+            graphed.ENABLED = was
+            ops.set_seed_base(None)
+
+    (ref, _), (got, stats) = program(False), program(True)
+    assert stats["captured"] >= 2 * (2 * 2 + 2) - 1 and stats["replayed"] >= 2 * stats["captured"], stats      # both rollouts' calls have entries of their own
+    for it, ((l0, g0), (l1, g1)) in enumerate(zip(ref, got)):
+        assert abs(l0 - l1) <= 2e-3 * max(1.0, abs(l0)), (it, l0, l1)
+        assert set(g0) == set(g1), (it, sorted(set(g0) ^ set(g1))[:5])
+        top = max(v.abs().max().item() for v in g0.values())
+        for n in g0:
+            d = (g0[n].float() - g1[n].float()).abs().max().item()
+            assert d <= 2e-2 * top, (it, n, d, top)
