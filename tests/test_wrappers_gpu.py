@@ -304,7 +304,7 @@ def test_second_backward_without_zero_grad_keeps_the_first_pass_gradients():
         assert d <= 1e-4 * top and d <= 2e-3 * max(g0[n].abs().max().item(), 1e-4 * top), (n, n in f1, d, top)
 
 
-def _graphed_program(on, iters, p_drop, T=3, adam=False, family="hamt"):
+def _graphed_program(on, iters, p_drop, T=3, adam=False, family="hamt", L=80, V=None):
     """iters agent iterations (dropin.*_agent_loss + backward [+ torch.optim.AdamW]) on a wrapper with the per-call graphs on / off."""
     from tests.golden.variants import DUET_C1, HAMT_C1
     from vln_imagine_amd import dropin, graphed, ops, synth
@@ -314,14 +314,14 @@ def _graphed_program(on, iters, p_drop, T=3, adam=False, family="hamt"):
         from vln_imagine_amd.hamt.config import HamtConfig
         from vln_imagine_amd.hamt.episode import EpisodeTensors
         cfg = HamtConfig(**HAMT_C1, pred_head_dropout_prob=p_drop, **drops)
-        et = EpisodeTensors(synth.HamtEpisode(tag="graphed", B=8, L=80, V=37, I=4, T=T, ragged=True), "cuda")
+        et = EpisodeTensors(synth.HamtEpisode(tag="graphed", B=8, L=L, V=V or 37, I=4, T=T, ragged=True), "cuda")
         wrap, loss_of = dropin.wrap_hamt, dropin.hamt_agent_loss
     else:
         from tests.test_duet_gpu import build_product
         from vln_imagine_amd.duet.config import DuetConfig
         from vln_imagine_amd.duet.episode import DuetEpisodeTensors
         cfg = DuetConfig(**DUET_C1, **drops)
-        et = DuetEpisodeTensors(synth.DuetEpisode(tag="graphed", B=8, L=80, V=36, I=4, T=T, ragged=True), "cuda")
+        et = DuetEpisodeTensors(synth.DuetEpisode(tag="graphed", B=8, L=L, V=V or 36, I=4, T=T, ragged=True), "cuda")
         wrap, loss_of = dropin.wrap_duet, dropin.duet_agent_loss
     was = graphed.ENABLED
     graphed.ENABLED = on
@@ -352,6 +352,31 @@ def _graphed_program(on, iters, p_drop, T=3, adam=False, family="hamt"):
     finally:
         graphed.ENABLED = was
         ops.set_seed_base(None)
+
+
+@pytest.mark.parametrize("family", ["hamt", "duet"])
+def test_graphed_wrapper_calls_pad_ragged_shapes_to_buckets(family):
+    """graphed.BUCKETS: 73 text tokens, 35 candidate views (HAMT) / maps of 5, 8, 11 nodes (DUET) are padded to 80 / 36 / 8, 8, 16 with the agents' own
+    padding values before the captured call and sliced back after it: the outputs have the caller's shapes and, with the gradients, equal the unpadded
+    eager calls' to summation-order rounding (padded keys are masked, padded candidates / nodes score -inf)."""
+    kw = dict(family=family, L=73, V=35 if family == "hamt" else None)
+    (ref, _), (got, stats) = _graphed_program(False, 3, 0.0, **kw), _graphed_program(True, 3, 0.0, **kw)
+    assert stats["replayed"] > 0
+    for it, ((l0, lg0, g0), (l1, lg1, g1)) in enumerate(zip(ref, got)):
+        assert abs(l0 - l1) <= 2e-3 * max(1.0, abs(l0)), (it, l0, l1)
+        for a, b in zip(lg0, lg1):
+            assert a.shape == b.shape
+            fin = torch.isfinite(a)
+            assert torch.equal(fin, torch.isfinite(b)) and (a[fin] - b[fin]).abs().max().item() <= 3e-2, it
+        assert set(g0) == set(g1)
+        top = max(v.abs().max().item() for v in g0.values())
+        # (padding changes the launches' row counts, hence tile shapes and summation orders: bf16 noise of a different draw than the equal-shape test's;
+        #  the whole gradient agrees to a few percent of its norm, any single entry to 5 % of the largest one)
+        num = sum(float((g0[n].double() - g1[n].double()).pow(2).sum()) for n in g0)
+        den = sum(float(g0[n].double().pow(2).sum()) for n in g0)
+        assert (num / den) ** 0.5 <= 0.05, (it, (num / den) ** 0.5)
+        for n in g0:
+            assert (g0[n].float() - g1[n].float()).abs().max().item() <= 5e-2 * top, (it, n)
 
 
 @pytest.mark.parametrize("family", ["hamt", "duet"])

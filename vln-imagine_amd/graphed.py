@@ -329,6 +329,29 @@ class ModeGraphs:
         self.static_ptrs.clear()
 
 
+# ---- shape buckets of the wrapper calls -------------------------------------------------------------------------------------------
+# Real batches are ragged: the text length, the candidate count and DUET's map size are padded to the batch maximum by the agents
+# (agent_cmt.py:130-176, agent.py:98-207) and change from batch to batch. The wrappers pad them up to the next multiple of a bucket size with
+# the agents' own padding values (pad ids / False masks / zero features: padded keys are masked, padded candidates score -inf) before the call
+# and slice the outputs back, so that a handful of signatures covers the data and their graphs get replayed. Results equal the unpadded
+# call's to summation-order rounding (the same property the reference's own batches have). VLNI_GRAPHED_BUCKETS = "text,candidates,map nodes"
+# multiples (0 = that dimension as given).
+BUCKETS = tuple(int(v) for v in os.environ.get("VLNI_GRAPHED_BUCKETS", "16,4,8").split(","))
+
+
+def bucket(n, m):
+    return n if m <= 1 else -(-n // m) * m
+
+
+def pad_dim(t, dim, to, value=0):
+    """t padded with `value` along `dim` up to length `to` (None stays None; no copy when nothing is to pad)."""
+    if t is None or t.shape[dim] >= to:
+        return t
+    shape = list(t.shape)
+    shape[dim] = to - t.shape[dim]
+    return torch.cat([t, t.new_full(shape, value)], dim)
+
+
 def of(model):
     g = getattr(model, "_vlni_mode_graphs", None)
     if g is None:

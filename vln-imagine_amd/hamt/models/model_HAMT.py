@@ -43,9 +43,17 @@ class VLNBertCMT(nn.Module):
                  align_txt_embeds, align_imagine_embeds, sub_instr_segs, sub_instr_imag_flag, noun_phrase_segs, obs_instr_ids, return_states,
                  return_cross_attention_probs):
         m = self.vln_bert
+        from vln_imagine_amd import graphed
+        padding = graphed.of(m)._ready() is not None                       # shape buckets only where the per-call graphs can run (graphed.BUCKETS)
         if mode == "language":
+            L0 = txt_ids.shape[1]
+            if padding:
+                Lb = graphed.bucket(L0, graphed.BUCKETS[0])
+                txt_ids, txt_masks = graphed.pad_dim(txt_ids, 1, Lb, 0), graphed.pad_dim(txt_masks, 1, Lb, False)
             out = self._graphed(mode, (), lambda **k: m(mode, **k), txt_ids=txt_ids, txt_masks=txt_masks)
-            return list(out) if isinstance(out, tuple) else out          # no_lang_ca: the per-layer text states (a list, :1022-1030)
+            if isinstance(out, (tuple, list)):                           # no_lang_ca: the per-layer text states (a list, :1022-1030)
+                return [o[:, :L0] for o in out]
+            return out[:, :L0]
         if mode == "imagine":
             def imagine(imagine_pano_img_feats=None, imagine_masks=None):
                 if imagine_pano_img_feats is not None:
@@ -89,6 +97,14 @@ class VLNBertCMT(nn.Module):
             if isinstance(txt_embeds, list) or return_cross_attention_probs:      # per-layer text states / probability maps: the plain call
                 return visual(txt_embeds, txt_masks, hist, hist_masks, ob_img_feats, ob_ang_feats, ob_nav_types, ob_masks, imagine_embeds,
                               imagine_masks)
+            V0 = ob_masks.shape[1]
+            if padding:
+                # text keys and candidate views up to their buckets: padded keys are masked (additive -10000 like every padded token of a ragged
+                # batch), padded candidates have navigation type 0 and an off mask, i.e. a -inf logit that is sliced away below
+                Lb, Vb = graphed.bucket(txt_masks.shape[1], graphed.BUCKETS[0]), graphed.bucket(V0, graphed.BUCKETS[1])
+                txt_embeds, txt_masks = graphed.pad_dim(txt_embeds, 1, Lb), graphed.pad_dim(txt_masks, 1, Lb, False)
+                ob_img_feats, ob_ang_feats = graphed.pad_dim(ob_img_feats, 1, Vb), graphed.pad_dim(ob_ang_feats, 1, Vb)
+                ob_nav_types, ob_masks = graphed.pad_dim(ob_nav_types, 1, Vb, 0), graphed.pad_dim(ob_masks, 1, Vb, False)
 
             def visual_own_language_side(**k):
                 # one captured call = one self-contained autograd graph: the episode's language side (concatenation, masks, first-layer Q / K / V)
@@ -98,7 +114,8 @@ class VLNBertCMT(nn.Module):
             out = self._graphed(mode, (bool(return_states),), visual_own_language_side, txt_embeds=txt_embeds, txt_masks=txt_masks, hist_embeds=hist,
                                 hist_masks=hist_masks, ob_img_feats=ob_img_feats, ob_ang_feats=ob_ang_feats, ob_nav_types=ob_nav_types,
                                 ob_masks=ob_masks, imagine_embeds=imagine_embeds, imagine_masks=imagine_masks)
-            return out if isinstance(out, tuple) else (out,)
+            out = out if isinstance(out, tuple) else (out,)
+            return (out[0][:, :V0],) + tuple(out[1:])
         raise NotImplementedError("wrong mode: %s" % mode)
 
     # A host -> device copy of pageable memory waits for everything queued on the stream: one per `history` / `visual` call stalled the host on
