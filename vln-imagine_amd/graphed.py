@@ -38,12 +38,13 @@ MAX_OCCURRENCE = 48
 
 class _Entry:
     __slots__ = ("sig", "fn", "pool", "fwd", "bwd", "ins", "ins_w", "in_req", "outs", "live_outs", "out_req", "gouts", "gins", "queued",
-                 "touched", "seen", "broken", "session")
+                 "touched", "seen", "used", "broken", "session")
 
     def __init__(self, sig, fn):
         self.sig, self.fn = sig, fn
         self.fwd = self.bwd = None
-        self.seen, self.broken = 0, False
+        self.outs = None
+        self.seen, self.used, self.broken = 0, 0, False
 
 
 class _Call(torch.autograd.Function):
@@ -229,6 +230,7 @@ class ModeGraphs:
         self.static_ptrs = set()
         self.seed_base = None
         self.anchor = None
+        self.iteration = 0
         self._ids = None
         self.stream, self.depth = None, 0
         self.epoch = -1               # the gradient session's epoch at the last call: a backward pass in between starts a new iteration
@@ -268,6 +270,7 @@ class ModeGraphs:
             # first call since a backward pass (the session's epoch moved): occurrences count from 0 again, the in-kernel dropout draws new masks
             # (forward and backward replays of one iteration read the same base), and the weights' 16-bit copies follow the optimizer IN PLACE
             self.epoch = ses.epoch
+            self.iteration += 1
             self.counts.clear()
             if self.seed_base is not None:
                 self.seed_base.add_(1)
@@ -278,11 +281,19 @@ class ModeGraphs:
         self.counts[sig] = k + 1
         e = self.entries.get((sig, k))
         if e is None:
+            if len(self.entries) >= MAX_ENTRIES:
+                # full: entries no rollout has used for a while (a signature the data has moved away from) make room - never one of this iteration
+                old = [key for key, v in self.entries.items() if v.used < self.iteration - 8]
+                for key in sorted(old, key=lambda q: self.entries[q].used)[:max(1, len(self.entries) // 4)]:
+                    for o in self.entries[key].outs or ():
+                        self.static_ptrs.discard(o.data_ptr())
+                    del self.entries[key]
             if k >= MAX_OCCURRENCE or len(self.entries) >= MAX_ENTRIES:
                 self.stats["eager"] += 1
                 return fn(*tensors)
             e = self.entries[(sig, k)] = _Entry(sig, fn)
         e.seen += 1
+        e.used = self.iteration
         e.fn = fn
         if e.seen == 1 or e.broken or not self._grads_in_place(ses):
             self.stats["eager"] += 1
@@ -298,10 +309,15 @@ class ModeGraphs:
                 _capture_backward(e, ses)
                 self.epoch = ses.epoch                    # (the capture's own session moved it)
                 self.stats["captured"] += 1
-            except Exception:
-                e.broken = True
-                e.fwd = None
-                raise
+            except Exception as err:
+                # an operator that cannot be captured (a host read of a tensor value, an allocation the capture forbids): this signature stays on the
+                # eager path for good; the agent's iteration goes on
+                import warnings
+                e.broken, e.fwd, e.bwd = True, None, None
+                self.epoch = ses.epoch
+                self.stats["eager"] += 1
+                warnings.warn(f"vln_imagine_amd.graphed: mode {mode!r} could not be captured ({type(err).__name__}: {err}); its calls stay eager")
+                return fn(*tensors)
             finally:
                 self.capturing = False
         self.stats["replayed"] += 1
