@@ -37,7 +37,7 @@ MAX_OCCURRENCE = 48
 
 
 class _Entry:
-    __slots__ = ("sig", "fn", "pool", "fwd", "bwd", "ins", "ins_w", "in_req", "outs", "live_outs", "out_req", "gouts", "gins", "queued",
+    __slots__ = ("sig", "fn", "pool", "fwd", "bwd", "ins", "ins_w", "aliased", "in_req", "outs", "live_outs", "out_req", "gouts", "gins", "queued",
                  "touched", "seen", "used", "broken", "session")
 
     def __init__(self, sig, fn):
@@ -101,12 +101,14 @@ def _open(ses):
 
 def _capture_forward(e, ins, g):
     e.pool = torch.cuda.graph_pool_handle()
-    e.ins = []
+    e.ins, e.aliased = [], []
     for t in ins:
         if t.data_ptr() in g.static_ptrs:                 # another entry's static output (txt_embeds of the `language` call): read in place
             e.ins.append(t.detach().requires_grad_(t.requires_grad))
+            e.aliased.append(True)
         else:
             e.ins.append(t.detach().clone().requires_grad_(t.requires_grad))
+            e.aliased.append(False)
     e.in_req = [t.requires_grad for t in ins]
     e.ins_w = [t.data for t in e.ins]
     torch.cuda.synchronize()
@@ -231,6 +233,7 @@ class ModeGraphs:
         self.seed_base = None
         self.anchor = None
         self.iteration = 0
+        self.in_place = None
         self._ids = None
         self.stream, self.depth = None, 0
         self.epoch = -1               # the gradient session's epoch at the last call: a backward pass in between starts a new iteration
@@ -271,6 +274,7 @@ class ModeGraphs:
             # (forward and backward replays of one iteration read the same base), and the weights' 16-bit copies follow the optimizer IN PLACE
             self.epoch = ses.epoch
             self.iteration += 1
+            self.in_place = None
             self.counts.clear()
             if self.seed_base is not None:
                 self.seed_base.add_(1)
@@ -295,7 +299,9 @@ class ModeGraphs:
         e.seen += 1
         e.used = self.iteration
         e.fn = fn
-        if e.seen == 1 or e.broken or not self._grads_in_place(ses):
+        if self.in_place is None:                         # once per iteration (nobody swaps gradient tensors in the middle of a rollout)
+            self.in_place = self._grads_in_place(ses)
+        if e.seen == 1 or e.broken or not self.in_place:
             self.stats["eager"] += 1
             return fn(*tensors)                           # first sight: eager (times the GEMM pipelines of these shapes, forward and backward)
         if e.fwd is None:
@@ -320,6 +326,11 @@ class ModeGraphs:
                 return fn(*tensors)
             finally:
                 self.capturing = False
+        if any(a and s_.data_ptr() != t.data_ptr() for a, s_, t in zip(e.aliased, e.ins, tensors)):
+            # an input that was another entry's static output when this entry was captured is a different tensor now: copying into that buffer
+            # would overwrite the other entry's output under its consumers - this call runs eagerly
+            self.stats["eager"] += 1
+            return fn(*tensors)
         self.stats["replayed"] += 1
         if self.anchor is None:
             self.anchor = torch.zeros(1, device=tensors[0].device, requires_grad=True)   # makes the node differentiable when no INPUT needs a gradient
